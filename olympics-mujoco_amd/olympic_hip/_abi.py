@@ -1,0 +1,93 @@
+"""ctypes mirror of include/olympic_hip.h: constants, structs and the argument lists of
+every exported entry point.  Declarations only - no library is loaded here (that is
+_ffi.py for the HIP library).  tests/test_abi.py checks this table against the header.
+"""
+import ctypes as C
+
+OLY_OK = 0
+OLY_EINVAL, OLY_ENOTCONF, OLY_EHIP, OLY_ENOMEM, OLY_ERANGE, OLY_ENODEV = -1, -2, -3, -4, -5, -6
+OLY_MAX_OBS, OLY_MAX_ACT, OLY_MAX_FALL, OLY_MAX_SEQ, OLY_MAX_PERIOD = 128, 64, 16, 20, 256
+
+REWARD_NONE, REWARD_TARGET_VELOCITY, REWARD_X_POS = 0, 1, 2
+OUT_OBS_F64, OUT_CTRL_F64 = 1, 2
+MODE_STANDING, MODE_FORWARD, MODE_BACKWARD, MODE_LATERAL = 1, 2, 3, 4
+SCAN_RETURN, SCAN_GAE = 0, 1
+FLAG_ABSORBING, FLAG_LAST = 1, 2
+
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+
+class IlModel(C.Structure):
+    _fields_ = [
+        ("nq", C.c_int32), ("nv", C.c_int32), ("n_pos", C.c_int32), ("n_vel", C.c_int32),
+        ("n_drop", C.c_int32), ("n_grf", C.c_int32), ("n_act", C.c_int32), ("nu", C.c_int32),
+        ("qpos_adr", i32p), ("qvel_adr", i32p), ("act_to_ctrl", i32p),
+        ("act_mean", f64p), ("act_delta", f64p), ("ctrl_lo", f64p), ("ctrl_hi", f64p),
+        ("n_fall", C.c_int32), ("fall_idx", i32p), ("fall_lo", f64p), ("fall_hi", f64p),
+        ("use_absorbing_states", C.c_int32), ("reward_type", C.c_int32),
+        ("reward_idx", C.c_int32), ("target_velocity", C.c_double),
+    ]
+
+
+class A3Model(C.Structure):
+    _fields_ = [
+        ("nq", C.c_int32), ("nv", C.c_int32), ("nu", C.c_int32), ("period", C.c_int32),
+        ("delay_frames", C.c_int32), ("target_radius", C.c_double), ("mass", C.c_double),
+        ("goal_height_ref", C.c_double), ("goal_speed_ref", C.c_double),
+        ("clock_lut", f64p), ("motor_offset", f64p), ("gear", f64p),
+    ]
+
+
+A3_INPUT_FIELDS = ["qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel", "rf_vel",
+                   "root_pos", "root_quat", "head_pos", "grf_l", "grf_r", "min_z", "n_r", "n_l", "bad"]
+A3_STATE_FIELDS = ["phase", "t1", "t2", "reached_frames", "target_reached", "mode", "seq_len",
+                   "sequence", "goal"]
+
+
+class A3Inputs(C.Structure):
+    _fields_ = [(n, vp) for n in A3_INPUT_FIELDS]
+
+
+class A3State(C.Structure):
+    _fields_ = [(n, vp) for n in A3_STATE_FIELDS]
+
+
+# name -> (restype, argtypes); device/host pointers are void*.
+SIGNATURES = {
+    "oly_strerror": (C.c_char_p, [C.c_int]),
+    "oly_last_error": (C.c_char_p, [vp]),
+    "oly_version": (C.c_char_p, []),
+    "oly_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "oly_destroy": (None, [vp]),
+    "oly_il_configure": (C.c_int, [vp, C.POINTER(IlModel)]),
+    "oly_il_obs_dim": (C.c_int, [vp]),
+    "oly_il_step": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                              C.c_int, vp]),
+    "oly_traj_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    "oly_traj_reset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "oly_traj_next": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "oly_traj_euler": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]),
+    "oly_contact_configure": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
+    "oly_contact_reduce": (C.c_int, [vp, C.c_int, C.c_int] + [vp] * 13 + [vp]),
+    "oly_a3_configure": (C.c_int, [vp, C.POINTER(A3Model)]),
+    "oly_a3_step": (C.c_int, [vp, C.c_int, C.POINTER(A3Inputs), C.POINTER(A3State), vp, vp, vp, vp,
+                              C.c_int, vp]),
+    "oly_a3_pd_target": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "oly_a3_pd_torque": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "oly_return_scan": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                  vp, vp, vp, vp, vp, vp, vp]),
+    "oly_adv_stats": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    "oly_adv_normalize": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int, C.c_double, vp]),
+    "oly_col_stats": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
+    "oly_disc_standardize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "oly_disc_reparam": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp]),
+    "oly_disc_reward": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    "oly_event_create": (C.c_int, [C.POINTER(vp)]),
+    "oly_event_destroy": (C.c_int, [vp]),
+    "oly_event_record": (C.c_int, [vp, vp]),
+    "oly_event_sync": (C.c_int, [vp]),
+    "oly_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    "oly_stream_sync": (C.c_int, [vp]),
+}

@@ -1,0 +1,627 @@
+/*
+ * oly_oracle.c - CPU restatement of the reference's per-environment hot path.
+ * TEST INFRASTRUCTURE (see oly_oracle.h): the checker for the HIP kernels and the
+ * "port" CPU baseline of bench.py.  Never linked into or loaded by the product.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off: no fused multiply-add, so that
+ * every fp64 expression rounds exactly as numpy evaluates it in the reference).
+ * Citations are file:line under /root/reference.
+ */
+#include "oly_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI 3.141592653589793 /* numpy.pi */
+
+/* ===================================================================== K1 + K5 (IL) */
+
+/* One (step, env) row.  `prev` is the reward input carried by self._obs. */
+static void il_row(const oly_il_model* m, const double* qpos, const double* qvel,
+                   const float* action, const double* grf, double* prev, void* obs_out,
+                   float* reward, uint8_t* absorbing, uint8_t* fall_code, void* ctrl_out,
+                   int out_flags, double* reward_f64) {
+  double full[OLY_MAX_OBS + 16];
+  double obs[OLY_MAX_OBS + 16];
+  int n_spec = m->n_pos + m->n_vel;
+  /* mushroom ObservationHelper._build_obs driven by the spec, UnitreeH1.py:303-355:
+     data.joint(name).qpos for JOINT_POS entries, .qvel for JOINT_VEL, in spec order.  */
+  for (int i = 0; i < m->n_pos; ++i) full[i] = qpos[m->qpos_adr[i]];
+  for (int i = 0; i < m->n_vel; ++i) full[m->n_pos + i] = qvel[m->qvel_adr[i]];
+  /* LocoEnvBase._create_observation, loco_env_base.py:737-767: obs[2:], (+ mean_grf/1000) */
+  int n_obs = 0;
+  for (int i = m->n_drop; i < n_spec; ++i) obs[n_obs++] = full[i];
+  for (int i = 0; i < m->n_grf; ++i) obs[n_obs++] = grf[i] / 1000.0;
+
+  /* BaseHumanoidRobot.is_absorbing -> UnitreeH1._has_fallen, base_humanoid_robot.py:246-260,
+     UnitreeH1.py:176-198: strict comparisons on the float64 values; first violated test.  */
+  int code = 0;
+  for (int k = 0; k < m->n_fall && !code; ++k) {
+    double v = obs[m->fall_idx[k]];
+    if (v < m->fall_lo[k] || v > m->fall_hi[k]) code = k + 1;
+  }
+  *absorbing = (uint8_t)((code != 0) && m->use_absorbing_states);
+  if (fall_code) *fall_code = (uint8_t)code;
+
+  /* LocoEnvBase.reward(state=self._obs, ...), loco_env_base.py:776-781 -> the reward object
+     reads `state`, the PREVIOUS observation (utils/reward.py:41,50,73-74).                */
+  double r = 0.0;
+  if (m->reward_type == OLY_REWARD_TARGET_VELOCITY) {
+    double d = *prev - m->target_velocity;
+    r = exp(-(d * d));
+  } else if (m->reward_type == OLY_REWARD_X_POS) {
+    r = *prev;
+  }
+  *reward = (float)r;
+  if (reward_f64) *reward_f64 = r;
+  if (m->reward_type != OLY_REWARD_NONE) *prev = obs[m->reward_idx]; /* self._obs = cur_obs */
+
+  if (out_flags & OLY_OUT_OBS_F64) {
+    memcpy(obs_out, obs, sizeof(double) * (size_t)n_obs);
+  } else {
+    float* o = (float*)obs_out;
+    for (int i = 0; i < n_obs; ++i) o[i] = (float)obs[i];
+  }
+
+  /* LocoEnvBase._preprocess_action, loco_env_base.py:1066: a*delta + mean in float64;
+     mushroom scatters into data.ctrl[action_indices]; MuJoCo clamps to ctrlrange.       */
+  if (ctrl_out) {
+    double c[OLY_MAX_ACT];
+    for (int j = 0; j < m->nu; ++j) c[j] = 0.0;
+    for (int k = 0; k < m->n_act; ++k) {
+      double u = (double)action[k] * m->act_delta[k] + m->act_mean[k];
+      if (u < m->ctrl_lo[k]) u = m->ctrl_lo[k];
+      if (u > m->ctrl_hi[k]) u = m->ctrl_hi[k];
+      c[m->act_to_ctrl[k]] = u;
+    }
+    if (out_flags & OLY_OUT_CTRL_F64) {
+      memcpy(ctrl_out, c, sizeof(double) * (size_t)m->nu);
+    } else {
+      float* o = (float*)ctrl_out;
+      for (int j = 0; j < m->nu; ++j) o[j] = (float)c[j];
+    }
+  }
+}
+
+static int il_check(const oly_il_model* m) {
+  if (!m || m->n_pos + m->n_vel > OLY_MAX_OBS || m->n_act > OLY_MAX_ACT || m->nu > OLY_MAX_ACT ||
+      m->n_fall > OLY_MAX_FALL)
+    return OLY_EINVAL;
+  return OLY_OK;
+}
+
+int oly_il_step_cpu(const oly_il_model* m, int T, int N, const double* qpos, const double* qvel,
+                    const float* action, const double* grf_mean, double* prev_inout, void* obs,
+                    float* reward, uint8_t* absorbing, uint8_t* fall_code, void* ctrl,
+                    int out_flags, double* reward_f64) {
+  if (il_check(m) || T < 0 || N < 0 || !qpos || !qvel || !prev_inout || !obs || !reward || !absorbing)
+    return OLY_EINVAL;
+  int n_obs = m->n_pos + m->n_vel - m->n_drop + m->n_grf;
+  size_t osz = (out_flags & OLY_OUT_OBS_F64) ? 8 : 4, csz = (out_flags & OLY_OUT_CTRL_F64) ? 8 : 4;
+  for (int t = 0; t < T; ++t)
+    for (int n = 0; n < N; ++n) {
+      size_t r = (size_t)t * N + n;
+      il_row(m, qpos + r * m->nq, qvel + r * m->nv, action ? action + r * m->n_act : NULL,
+             grf_mean ? grf_mean + r * m->n_grf : NULL, prev_inout + n,
+             (char*)obs + r * n_obs * osz, reward + r, absorbing + r,
+             fall_code ? fall_code + r : NULL, ctrl ? (char*)ctrl + r * m->nu * csz : NULL,
+             out_flags, reward_f64 ? reward_f64 + r : NULL);
+    }
+  return OLY_OK;
+}
+
+int oly_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+int oly_il_step_cpu_mt(const oly_il_model* m, int T, int N, const double* qpos,
+                       const double* qvel, const float* action, double* prev_inout, void* obs,
+                       float* reward, uint8_t* absorbing, void* ctrl, int out_flags, int threads) {
+  if (il_check(m)) return OLY_EINVAL;
+  int n_obs = m->n_pos + m->n_vel - m->n_drop + m->n_grf;
+  size_t osz = (out_flags & OLY_OUT_OBS_F64) ? 8 : 4, csz = (out_flags & OLY_OUT_CTRL_F64) ? 8 : 4;
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+  for (int n = 0; n < N; ++n)
+    for (int t = 0; t < T; ++t) {
+      size_t r = (size_t)t * N + n;
+      il_row(m, qpos + r * m->nq, qvel + r * m->nv, action ? action + r * m->n_act : NULL, NULL,
+             prev_inout + n, (char*)obs + r * n_obs * osz, reward + r, absorbing + r, NULL,
+             ctrl ? (char*)ctrl + r * m->nu * csz : NULL, out_flags, NULL);
+    }
+  (void)threads;
+  return OLY_OK;
+}
+
+/* ============================================================================== K4 */
+
+#define TAB(k, j, s) table[((size_t)(k) * n_traj + (j)) * len + (s)]
+
+/* Trajectory.reset_trajectory, utils/trajectory.py:289-323: the chosen sub-trajectory is
+   COPIED (_get_subtraj :458-464) and keys 0,1 are shifted by their value at `step`.    */
+int oly_traj_reset_cpu(int n_keys, int n_traj, int len, const double* table, int N,
+                       const int32_t* traj_no, const int32_t* step, int32_t* cur_traj,
+                       int32_t* cur_step, double* origin, double* sample) {
+  for (int n = 0; n < N; ++n) {
+    int j = traj_no[n], s = step[n];
+    if (j < 0 || j >= n_traj || s < 0 || s >= len) return OLY_ERANGE;
+    cur_traj[n] = j;
+    cur_step[n] = s;
+    double x0 = TAB(0, j, s), y0 = TAB(1, j, s);
+    origin[2 * n] = x0;
+    origin[2 * n + 1] = y0;
+    for (int k = 0; k < n_keys; ++k) {
+      double v = TAB(k, j, s);
+      if (k == 0) v -= x0; /* self.subtraj[0] -= self.subtraj[0][step]  :319 */
+      if (k == 1) v -= y0; /*                                           :320 */
+      sample[(size_t)n * n_keys + k] = v;
+    }
+  }
+  return OLY_OK;
+}
+
+/* Trajectory.get_next_sample, utils/trajectory.py:389-401. */
+int oly_traj_next_cpu(int n_keys, int n_traj, int len, const double* table, int N,
+                      const uint8_t* active, const int32_t* cur_traj, int32_t* cur_step,
+                      const double* origin, double* sample, uint8_t* at_end) {
+  for (int n = 0; n < N; ++n) {
+    if (active && !active[n]) {
+      at_end[n] = 0;
+      continue;
+    }
+    int j = cur_traj[n];
+    int s = cur_step[n] + 1; /* self.subtraj_step_no += 1 */
+    cur_step[n] = s;
+    if (s == len) { /* sample = None */
+      at_end[n] = 1;
+      continue;
+    }
+    at_end[n] = 0;
+    for (int k = 0; k < n_keys; ++k) {
+      double v = TAB(k, j, s);
+      if (k == 0) v -= origin[2 * n];
+      if (k == 1) v -= origin[2 * n + 1];
+      sample[(size_t)n * n_keys + k] = v;
+    }
+  }
+  return OLY_OK;
+}
+
+/* play_trajectory_from_velocity, loco_env_base.py:515-519:
+   qpos = [qp + self.dt * qv for qp, qv in zip(curr_qpos, qvel)]; sample[:len(qpos)] = qpos */
+int oly_traj_euler_cpu(int n_keys, int N, int n_qpos, double dt, const double* curr_qpos,
+                       double* sample) {
+  for (int n = 0; n < N; ++n)
+    for (int j = 0; j < n_qpos; ++j) {
+      double* s = sample + (size_t)n * n_keys;
+      s[j] = curr_qpos[(size_t)n * n_qpos + j] + dt * s[n_qpos + j];
+    }
+  return OLY_OK;
+}
+
+/* ============================================================================== K3 */
+
+/* MujocoRobotInterface.get_{r,l}foot_floor_contacts :245-273 (floor must be geom1),
+   get_{r,l}foot_grf :275-297 (np.linalg.norm of the 6-vector, summed in contact order),
+   check_bad_collisions :393-399, and the contact point of _calc_height_reward
+   (tasks/rewards.py:29-33).                                                            */
+int oly_contact_reduce_cpu(int ngeom, const int32_t* geom_bodyid, int floor_body, int rfoot_body,
+                           int lfoot_body, int N, int C, const int32_t* ncon,
+                           const int32_t* geom1, const int32_t* geom2, const double* force6,
+                           const double* pos_z, int32_t* n_r, int32_t* n_l, int32_t* idx_r,
+                           int32_t* idx_l, double* grf_r, double* grf_l, double* min_z,
+                           uint8_t* bad) {
+  for (int n = 0; n < N; ++n) {
+    int nc = ncon[n];
+    if (nc < 0 || nc > C) return OLY_ERANGE;
+    int nr = 0, nl = 0;
+    double gr = 0.0, gl = 0.0, mz = 0.0;
+    int have = 0;
+    /* the reference builds the right list fully, then the left list; min() runs over
+       rcontacts + lcontacts.  Sums and the minimum are order-independent across the two
+       lists except for fp addition order WITHIN a list, which is contact order.        */
+    for (int i = 0; i < nc; ++i) {
+      size_t e = (size_t)n * C + i;
+      int g1 = geom1[e], g2 = geom2[e];
+      if (g1 < 0 || g1 >= ngeom || g2 < 0 || g2 >= ngeom) return OLY_ERANGE;
+      int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
+      int is_r = (b1 == floor_body) && (b2 == rfoot_body);
+      int is_l = (b1 == floor_body) && (b2 == lfoot_body);
+      if (is_r || is_l) {
+        const double* f = force6 + e * 6;
+        double s = 0.0;
+        for (int k = 0; k < 6; ++k) s += f[k] * f[k];
+        double nrm = sqrt(s);
+        if (!have || pos_z[e] < mz) mz = pos_z[e];
+        have = 1;
+        if (is_r) {
+          if (idx_r) idx_r[(size_t)n * C + nr] = i;
+          gr += nrm;
+          ++nr;
+        }
+        if (is_l) { /* both can hold only if rfoot_body == lfoot_body */
+          if (idx_l) idx_l[(size_t)n * C + nl] = i;
+          gl += nrm;
+          ++nl;
+        }
+      }
+    }
+    if (idx_r) for (int i = nr; i < C; ++i) idx_r[(size_t)n * C + i] = -1;
+    if (idx_l) for (int i = nl; i < C; ++i) idx_l[(size_t)n * C + i] = -1;
+    n_r[n] = nr;
+    n_l[n] = nl;
+    grf_r[n] = gr;
+    grf_l[n] = gl;
+    min_z[n] = have ? mz : 0.0;
+    bad[n] = (uint8_t)((nr + nl) != nc);
+  }
+  return OLY_OK;
+}
+
+/* ========================================================================== K2 (A3) */
+
+/* transforms3d.quaternions.quat2mat (w,x,y,z) - restated from the package docs. */
+static void quat2mat(const double* q, double R[3][3]) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  double nq = w * w + x * x + y * y + z * z;
+  if (nq < 2.220446049250313e-16) {
+    memset(R, 0, sizeof(double) * 9);
+    R[0][0] = R[1][1] = R[2][2] = 1.0;
+    return;
+  }
+  double s = 2.0 / nq;
+  double X = x * s, Y = y * s, Z = z * s;
+  double wX = w * X, wY = w * Y, wZ = w * Z;
+  double xX = x * X, xY = x * Y, xZ = x * Z;
+  double yY = y * Y, yZ = y * Z, zZ = z * Z;
+  R[0][0] = 1.0 - (yY + zZ); R[0][1] = xY - wZ;         R[0][2] = xZ + wY;
+  R[1][0] = xY + wZ;         R[1][1] = 1.0 - (xX + zZ); R[1][2] = yZ - wX;
+  R[2][0] = xZ - wY;         R[2][1] = yZ + wX;         R[2][2] = 1.0 - (xX + yY);
+}
+
+static double norm3(const double* a, const double* b) {
+  double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+  return sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+}
+
+static void a3_row(const oly_a3_model* m, int n, const oly_a3_inputs* in, const oly_a3_state* st,
+                   double* obs, double* rew, double* total, uint8_t* done) {
+  const double* lf = in->lf_pos + 3 * n;
+  const double* rf = in->rf_pos + 3 * n;
+  const double* seq = st->sequence + (size_t)n * OLY_MAX_SEQ * 4;
+  int mode = st->mode[n];
+
+  /* ---- WalkingTask.step, walking_task.py:246-293 */
+  int phase = st->phase[n] + 1;
+  if (phase >= m->period) phase = 0;
+  int t1 = st->t1[n], t2 = st->t2[n];
+  const double* target = seq + 4 * t1;
+  double dl = norm3(lf, target), dr = norm3(rf, target);
+  int reached;
+  int frames = st->reached_frames[n];
+  if (dl < m->target_radius || dr < m->target_radius) {
+    reached = 1;
+    frames += 1;
+  } else {
+    reached = 0;
+    frames = 0;
+  }
+  if (reached && frames >= m->delay_frames) {
+    /* update_target_steps :228-244 */
+    t1 = t2;
+    t2 += 1;
+    if (t2 == st->seq_len[n]) t2 = st->seq_len[n] - 1;
+    reached = 0;
+    frames = 0;
+  }
+  st->phase[n] = phase;
+  st->t1[n] = t1;
+  st->t2[n] = t2;
+  st->reached_frames[n] = frames;
+  st->target_reached[n] = (uint8_t)reached;
+
+  /* ---- update_goal_steps :184-225: relative = inv(T_root) . T_target.  T_root is rigid
+     ([R p; 0 1], R from quat2mat), so inv = [R^T, -R^T p]; goal xyz = R^T (target - p),
+     theta = mat2euler(R^T Rz(yaw))[2] = atan2(M[1][0], M[0][0]).                        */
+  double* goal = st->goal + 8 * n;
+  for (int i = 0; i < 8; ++i) goal[i] = 0.0;
+  const double* rp = in->root_pos + 3 * n;
+  const double* rq = in->root_quat + 4 * n;
+  if (mode != OLY_MODE_STANDING) {
+    double R[3][3];
+    quat2mat(rq, R);
+    int tt[2] = {t1, t2};
+    for (int i = 0; i < 2; ++i) {
+      const double* s = seq + 4 * tt[i];
+      double d[3] = {s[0] - rp[0], s[1] - rp[1], s[2] - rp[2]};
+      goal[0 + i] = R[0][0] * d[0] + R[1][0] * d[1] + R[2][0] * d[2];
+      goal[2 + i] = R[0][1] * d[0] + R[1][1] * d[1] + R[2][1] * d[2];
+      goal[4 + i] = R[0][2] * d[0] + R[1][2] * d[1] + R[2][2] * d[2];
+      double c = cos(s[3]), sn = sin(s[3]);
+      /* M = R^T Rz: M[0][0] = R00 c + R10 s ; M[1][0] = R01 c + R11 s */
+      double m00 = R[0][0] * c + R[1][0] * sn;
+      double m10 = R[0][1] * c + R[1][1] * sn;
+      goal[6 + i] = atan2(m10, m00);
+    }
+  }
+
+  /* ---- WalkingTask.calc_reward :74-110 */
+  double c_rfrc, c_rvel, c_lfrc, c_lvel;
+  if (mode == OLY_MODE_STANDING) { /* :82-90 */
+    c_rfrc = 1.0; c_lfrc = 1.0; c_rvel = -1.0; c_lvel = -1.0;
+  } else {
+    c_rfrc = m->clock_lut[0 * m->period + phase];
+    c_rvel = m->clock_lut[1 * m->period + phase];
+    c_lfrc = m->clock_lut[2 * m->period + phase];
+    c_lvel = m->clock_lut[3 * m->period + phase];
+  }
+  /* _calc_foot_frc_clock_reward, tasks/rewards.py:65-83 */
+  double max_frc = m->mass * 9.8 * 0.5;
+  double nl = fmin(in->grf_l[n], max_frc) / max_frc;
+  double nr = fmin(in->grf_r[n], max_frc) / max_frc;
+  nl *= 2; nl -= 1; nr *= 2; nr -= 1;
+  double frc = (tan(PI / 4 * c_lfrc * nl) + tan(PI / 4 * c_rfrc * nr)) / 2;
+  /* _calc_foot_vel_clock_reward :85-102 */
+  static const double zero3[3] = {0, 0, 0};
+  double vl = fmin(norm3(in->lf_vel + 3 * n, zero3), 0.2) / 0.2;
+  double vr = fmin(norm3(in->rf_vel + 3 * n, zero3), 0.2) / 0.2;
+  vl *= 2; vl -= 1; vr *= 2; vr -= 1;
+  double vel = (tan(PI / 4 * c_lvel * vl) + tan(PI / 4 * c_rvel * vr)) / 2;
+  /* _calc_body_orient_reward :121-126 with quat_ref = euler2quat(0,0,yaw) = (cos(y/2),0,0,sin(y/2)) */
+  double yaw = seq[4 * t1 + 3];
+  double tq[4] = {cos(yaw / 2.0), 0.0, 0.0, sin(yaw / 2.0)};
+  double ip = tq[0] * rq[0] + tq[1] * rq[1] + tq[2] * rq[2] + tq[3] * rq[3];
+  double orient = exp(-(10 * (1 - ip * ip)));
+  /* _calc_height_reward :27-40 */
+  double contact_point = (in->n_r[n] > 0 || in->n_l[n] > 0) ? in->min_z[n] : 0.0;
+  double err = fabs((rp[2] - contact_point) - m->goal_height_ref);
+  double deadzone = 0.01 + 0.05 * m->goal_speed_ref;
+  if (err < deadzone) err = 0;
+  double height = exp(-40 * (err * err));
+  /* step_reward :56-72 (uses t1/t2/target_reached as updated by step()) */
+  const double* tp = seq + 4 * t1;
+  double fd = fmin(norm3(lf, tp), norm3(rf, tp));
+  double hit = reached ? exp(-fd / 0.25) : 0.0;
+  double mpx = (seq[4 * t1] + seq[4 * t2]) / 2, mpy = (seq[4 * t1 + 1] + seq[4 * t2 + 1]) / 2;
+  double rx = rp[0] - mpx, ry = rp[1] - mpy;
+  double progress = exp(-sqrt(rx * rx + ry * ry) / 2);
+  double step_r = 0.8 * hit + 0.2 * progress;
+  /* upper body :108 */
+  const double* hp = in->head_pos + 3 * n;
+  double hx = hp[0] - rp[0], hy = hp[1] - rp[1];
+  double hn = sqrt(hx * hx + hy * hy);
+  double upper = exp(-10 * (hn * hn));
+  rew[0] = 0.150 * frc;
+  rew[1] = 0.150 * vel;
+  rew[2] = 0.050 * orient;
+  rew[3] = 0.050 * height;
+  rew[4] = 0.450 * step_r;
+  rew[5] = 0.050 * upper;
+  double tot = 0.0; /* sum([float(i) for i in rewards.values()]) StickFigureA3.py:194 */
+  for (int i = 0; i < 6; ++i) tot += rew[i];
+  *total = tot;
+
+  /* ---- WalkingTask.done :298-319 */
+  double foot_z = fmin(lf[2], rf[2]);
+  *done = (uint8_t)(((rp[2] - foot_z) < 0.6) || in->bad[n]);
+
+  /* ---- StickFigureA3.get_obs, StickFigureA3.py:144-178 */
+  const double* qpos = in->qpos + (size_t)n * m->nq;
+  const double* qvel = in->qvel + (size_t)n * m->nv;
+  /* quat2euler(qpos[3:7])[0:2] (sxyz) then euler2quat(roll, pitch, 0) */
+  double Rb[3][3];
+  quat2mat(qpos + 3, Rb);
+  double cy = sqrt(Rb[0][0] * Rb[0][0] + Rb[1][0] * Rb[1][0]);
+  double roll, pitch;
+  if (cy > 4.0 * 2.220446049250313e-16) {
+    roll = atan2(Rb[2][1], Rb[2][2]);
+    pitch = atan2(-Rb[2][0], cy);
+  } else {
+    roll = atan2(-Rb[1][2], Rb[1][1]);
+    pitch = atan2(-Rb[2][0], cy);
+  }
+  double ci = cos(roll / 2.0), si = sin(roll / 2.0), cj = cos(pitch / 2.0), sj = sin(pitch / 2.0);
+  int o = 0;
+  obs[o++] = ci * cj;  /* ck = 1, sk = 0 */
+  obs[o++] = si * cj;
+  obs[o++] = ci * sj;
+  obs[o++] = -(si * sj);
+  for (int i = 3; i < 6; ++i) obs[o++] = qvel[i];
+  for (int i = 0; i < m->nu; ++i) obs[o++] = in->act_len[(size_t)n * m->nu + i] / m->gear[i];
+  for (int i = 0; i < m->nu; ++i) obs[o++] = in->act_vel[(size_t)n * m->nu + i] / m->gear[i];
+  double ang = 2 * PI * phase / (double)m->period;
+  obs[o++] = sin(ang);
+  obs[o++] = cos(ang);
+  for (int i = 0; i < 8; ++i) obs[o++] = goal[i];
+}
+
+int oly_a3_step_cpu(const oly_a3_model* m, int N, const oly_a3_inputs* in, const oly_a3_state* st,
+                    void* obs, float* rew6, float* reward, uint8_t* done, int out_flags,
+                    double* rew6_f64, double* reward_f64) {
+  if (!m || !in || !st || m->nu > 16) return OLY_EINVAL;
+  int n_obs = 7 + 2 * m->nu + 10;
+  for (int n = 0; n < N; ++n) {
+    double o[64], r[6], tot;
+    a3_row(m, n, in, st, o, r, &tot, done + n);
+    if (out_flags & OLY_OUT_OBS_F64)
+      memcpy((double*)obs + (size_t)n * n_obs, o, sizeof(double) * (size_t)n_obs);
+    else
+      for (int i = 0; i < n_obs; ++i) ((float*)obs)[(size_t)n * n_obs + i] = (float)o[i];
+    for (int i = 0; i < 6; ++i) {
+      rew6[6 * (size_t)n + i] = (float)r[i];
+      if (rew6_f64) rew6_f64[6 * (size_t)n + i] = r[i];
+    }
+    reward[n] = (float)tot;
+    if (reward_f64) reward_f64[n] = tot;
+  }
+  return OLY_OK;
+}
+
+/* robot.JVRC.step, environments/robot.py:88-95 (actuators = identity list 0..nu-1). */
+int oly_a3_pd_target_cpu(const oly_a3_model* m, int N, const float* action, double* target) {
+  for (int n = 0; n < N; ++n)
+    for (int i = 0; i < m->nu; ++i)
+      target[(size_t)n * m->nu + i] = (double)action[(size_t)n * m->nu + i] + m->motor_offset[i];
+  return OLY_OK;
+}
+
+/* MujocoRobotInterface.step_pd :425-443 + robot.JVRC.do_simulation robot.py:109-115. */
+int oly_a3_pd_torque_cpu(const oly_a3_model* m, int N, const double* kp, const double* kd,
+                         const double* target, const double* act_len, const double* act_vel,
+                         double* tau) {
+  for (int n = 0; n < N; ++n)
+    for (int i = 0; i < m->nu; ++i) {
+      size_t e = (size_t)n * m->nu + i;
+      double q = act_len[e] / m->gear[i], qd = act_vel[e] / m->gear[i];
+      double perror = target[e] - q, verror = 0.0 - qd;
+      tau[e] = (kp[i] * perror + kd[i] * verror) / m->gear[i];
+    }
+  return OLY_OK;
+}
+
+/* ============================================================================== K6 */
+
+int oly_return_scan_cpu(int mode, int T, int N, double gamma, double lam, const float* rew,
+                        const float* val, const float* next_val, const uint8_t* flags, float* ret,
+                        float* adv) {
+  if (mode == OLY_SCAN_RETURN) {
+    /* PPOBuffer.finish_path, rl/algos/ppo.py:68-84, as numpy 2.x evaluates it:
+       R = last_val (float32 array), R = gamma*R + reward: the FIRST product is a python
+       float times a float32 array = float32 arithmetic; adding the float64 reward
+       promotes to float64, where the scan stays.  torch.Tensor(...) narrows (:328);
+       advantages = returns - values in float32 (:335).                                */
+    float g32 = (float)gamma;
+    for (int n = 0; n < N; ++n) {
+      double R = 0.0;
+      for (int t = T - 1; t >= 0; --t) {
+        size_t e = (size_t)t * N + n;
+        uint8_t f = flags[e];
+        if ((f & OLY_FLAG_LAST) || t == T - 1) {
+          float r0 = (f & OLY_FLAG_ABSORBING) ? 0.0f : next_val[e]; /* (not done) * value */
+          float p = g32 * r0;
+          R = (double)p + (double)rew[e];
+        } else {
+          R = gamma * R + (double)rew[e];
+        }
+        ret[e] = (float)R;
+        adv[e] = ret[e] - val[e];
+      }
+    }
+    return OLY_OK;
+  }
+  if (mode == OLY_SCAN_GAE) {
+    /* mushroom_rl.utils.value_functions.compute_gae (mushroom-rl 1.10, absent here:
+       parity unpinned), call site imitation_lib/imitation/gail_TRPO.py:126-127.  All
+       operands are float32 arrays / python floats, so numpy works in float32.         */
+    float g32 = (float)gamma, gl32 = (float)(gamma * lam);
+    for (int n = 0; n < N; ++n) {
+      float a_next = 0.0f;
+      for (int t = T - 1; t >= 0; --t) {
+        size_t e = (size_t)t * N + n;
+        uint8_t f = flags[e];
+        float a;
+        if ((f & OLY_FLAG_LAST) || t == T - 1) {
+          a = rew[e] - val[e];
+          if (!(f & OLY_FLAG_ABSORBING)) a += g32 * next_val[e];
+        } else {
+          a = rew[e] + g32 * next_val[e] - val[e] + gl32 * a_next;
+        }
+        adv[e] = a;
+        ret[e] = a + val[e];
+        a_next = a;
+      }
+    }
+    return OLY_OK;
+  }
+  return OLY_EINVAL;
+}
+
+/* ============================================================================== K7 */
+
+int oly_adv_stats_cpu(int64_t n, const float* x, double* stats3_out) {
+  double s = 0.0, ss = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    double v = (double)x[i];
+    s += v;
+    ss += v * v;
+  }
+  stats3_out[0] = (double)n;
+  stats3_out[1] = s;
+  stats3_out[2] = ss;
+  return OLY_OK;
+}
+
+/* rl/algos/ppo.py:335-336 (ddof 1, eps 1e-5) / gail_TRPO.py:128 (ddof 0, eps 1e-8). */
+int oly_adv_normalize_cpu(int64_t n, float* x, const double* stats3, int ddof, double eps) {
+  double cnt = stats3[0], mean = stats3[1] / cnt;
+  double var = (stats3[2] - cnt * mean * mean) / (cnt - (double)ddof);
+  if (var < 0.0) var = 0.0;
+  double denom = sqrt(var) + eps;
+  for (int64_t i = 0; i < n; ++i) x[i] = (float)(((double)x[i] - mean) / denom);
+  return OLY_OK;
+}
+
+/* Standardizer.update_mean_std sums, imitation_lib/utils/networks.py:76-79. */
+int oly_col_stats_cpu(int B, int D, const float* x, double* colstats, int accumulate) {
+  for (int j = 0; j < D; ++j) {
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < B; ++b) {
+      double v = (double)x[(size_t)b * D + j];
+      s += v;
+      ss += v * v;
+    }
+    if (accumulate) {
+      colstats[j] += (double)B;
+      colstats[D + j] += s;
+      colstats[2 * D + j] += ss;
+    } else {
+      colstats[j] = (double)B;
+      colstats[D + j] = s;
+      colstats[2 * D + j] = ss;
+    }
+  }
+  return OLY_OK;
+}
+
+/* ============================================================================== K8 */
+
+/* prepare_discrim_inputs (gail_TRPO.py:297-313) + Standardizer.forward (networks.py:68-74):
+   float32 batch minus float64 mean, divided by float64 std, narrowed by .float().       */
+int oly_disc_standardize_cpu(int B, int Dx, int D, const float* x, const int32_t* mask,
+                             const double* mean, const double* std, float* out) {
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < D; ++j) {
+      int c = mask ? mask[j] : j;
+      if (c < 0 || c >= Dx) return OLY_ERANGE;
+      out[(size_t)b * D + j] = (float)(((double)x[(size_t)b * Dx + c] - mean[j]) / std[j]);
+    }
+  return OLY_OK;
+}
+
+/* reparameterize, networks.py:21-24 (float32 torch ops). */
+int oly_disc_reparam_cpu(int64_t n, const float* mu, const float* logvar, const float* eps,
+                         float* z) {
+  for (int64_t i = 0; i < n; ++i) z[i] = mu[i] + expf(logvar[i] / 2.0f) * eps[i];
+  return OLY_OK;
+}
+
+/* GAIL.make_discrim_reward, gail_TRPO.py:326-327 on a float32 logit array. */
+int oly_disc_reward_cpu(int64_t B, const float* logits, float* reward) {
+  for (int64_t i = 0; i < B; ++i) {
+    float e = expf(-logits[i]);
+    float p = 1.0f / (1.0f + e);
+    float q = 1.0f - p + 1e-8f;
+    reward[i] = -logf(q);
+  }
+  return OLY_OK;
+}

@@ -1,0 +1,86 @@
+/*
+ * oly_oracle.h - CPU restatement ("oracle") of the reference's hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may build, load or call this library; the product
+ * (libolympic_hip.so and the olympic_hip host package) never does and fails loudly
+ * when its HIP library is missing.
+ *
+ * Every function is the plain-C, one-row-at-a-time restatement of the reference Python
+ * named in its comment (file:line under /root/reference) and takes the same arguments
+ * as its oly_* twin in include/olympic_hip.h, with HOST pointers, an explicit model
+ * struct instead of a ctx, and no stream.
+ *
+ * Pinning (see DESIGN.md "Oracle"): checked in tests/test_oracle_golden.py against the
+ * golden vectors of tests/golden/, which were produced by executing the reference's own
+ * functions (tests/golden/gen_golden.py).  Not pinned by any reference output, because
+ * the arithmetic lives in packages absent from /root/reference and from this image:
+ *   - mushroom-rl (>=1.10, unpinned in requirements.txt): ObservationHelper._build_obs
+ *     (the qpos/qvel gather order), compute_gae, RunningAveragedWindow;
+ *   - transforms3d (unpinned): quat2euler / euler2quat / quat2mat / mat2euler / compose
+ *     used by StickFigureA3.get_obs and WalkingTask.update_goal_steps;
+ *   - mujoco 2.3.6: everything upstream of the arrays these functions receive.
+ * Those pieces are restated from the packages' published definitions: PARITY UNPINNED.
+ */
+#ifndef OLY_ORACLE_H
+#define OLY_ORACLE_H
+
+#include "../include/olympic_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int oly_il_step_cpu(const oly_il_model* m, int T, int N, const double* qpos, const double* qvel,
+                    const float* action, const double* grf_mean, double* prev_inout, void* obs,
+                    float* reward, uint8_t* absorbing, uint8_t* fall_code, void* ctrl,
+                    int out_flags, double* reward_f64 /* [T,N] or NULL: un-narrowed reward */);
+
+int oly_traj_reset_cpu(int n_keys, int n_traj, int len, const double* table, int N,
+                       const int32_t* traj_no, const int32_t* step, int32_t* cur_traj,
+                       int32_t* cur_step, double* origin, double* sample);
+int oly_traj_next_cpu(int n_keys, int n_traj, int len, const double* table, int N,
+                      const uint8_t* active, const int32_t* cur_traj, int32_t* cur_step,
+                      const double* origin, double* sample, uint8_t* at_end);
+int oly_traj_euler_cpu(int n_keys, int N, int n_qpos, double dt, const double* curr_qpos,
+                       double* sample);
+
+int oly_contact_reduce_cpu(int ngeom, const int32_t* geom_bodyid, int floor_body, int rfoot_body,
+                           int lfoot_body, int N, int C, const int32_t* ncon,
+                           const int32_t* geom1, const int32_t* geom2, const double* force6,
+                           const double* pos_z, int32_t* n_r, int32_t* n_l, int32_t* idx_r,
+                           int32_t* idx_l, double* grf_r, double* grf_l, double* min_z,
+                           uint8_t* bad);
+
+int oly_a3_step_cpu(const oly_a3_model* m, int N, const oly_a3_inputs* in, const oly_a3_state* st,
+                    void* obs, float* rew6, float* reward, uint8_t* done, int out_flags,
+                    double* rew6_f64 /* [N,6] or NULL */, double* reward_f64 /* [N] or NULL */);
+int oly_a3_pd_target_cpu(const oly_a3_model* m, int N, const float* action, double* target);
+int oly_a3_pd_torque_cpu(const oly_a3_model* m, int N, const double* kp, const double* kd,
+                         const double* target, const double* act_len, const double* act_vel,
+                         double* tau);
+
+int oly_return_scan_cpu(int mode, int T, int N, double gamma, double lam, const float* rew,
+                        const float* val, const float* next_val, const uint8_t* flags, float* ret,
+                        float* adv);
+
+int oly_adv_stats_cpu(int64_t n, const float* x, double* stats3_out);
+int oly_adv_normalize_cpu(int64_t n, float* x, const double* stats3, int ddof, double eps);
+int oly_col_stats_cpu(int B, int D, const float* x, double* colstats, int accumulate);
+
+int oly_disc_standardize_cpu(int B, int Dx, int D, const float* x, const int32_t* mask,
+                             const double* mean, const double* std, float* out);
+int oly_disc_reparam_cpu(int64_t n, const float* mu, const float* logvar, const float* eps,
+                         float* z);
+int oly_disc_reward_cpu(int64_t B, const float* logits, float* reward);
+
+/* OpenMP-parallel variant used only by bench.py's cpu_baseline leg (threads <= 0: all). */
+int oly_il_step_cpu_mt(const oly_il_model* m, int T, int N, const double* qpos,
+                       const double* qvel, const float* action, double* prev_inout, void* obs,
+                       float* reward, uint8_t* absorbing, void* ctrl, int out_flags, int threads);
+int oly_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

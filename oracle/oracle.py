@@ -1,0 +1,241 @@
+"""numpy front-end to the CPU oracle (oracle/liboly_oracle.so).
+
+TEST INFRASTRUCTURE: importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (olympic_hip) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.join(os.path.dirname(_HERE), "olympics-mujoco_amd")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+from olympic_hip import _abi  # noqa: E402  (struct declarations only)
+
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboly_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("oly_oracle.c", "oly_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboly_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oly_oracle_max_threads.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def max_threads():
+    return int(lib().oly_oracle_max_threads())
+
+
+def il_step(spec, qpos, qvel, action, prev, grf_mean=None, obs_f64=False, ctrl_f64=False):
+    """qpos [T,N,nq] ... -> dict(obs, reward, reward_f64, absorbing, fall_code, ctrl, prev)."""
+    qpos, qvel = _c(qpos, np.float64), _c(qvel, np.float64)
+    T, N = qpos.shape[:2]
+    action = _c(action, np.float32)
+    grf_mean = _c(grf_mean, np.float64)
+    prev = np.array(prev, dtype=np.float64, copy=True)
+    m = spec.to_c()
+    flags = (_abi.OUT_OBS_F64 if obs_f64 else 0) | (_abi.OUT_CTRL_F64 if ctrl_f64 else 0)
+    obs = np.empty((T, N, spec.n_obs), np.float64 if obs_f64 else np.float32)
+    reward = np.empty((T, N), np.float32)
+    reward64 = np.empty((T, N), np.float64)
+    absorbing = np.empty((T, N), np.uint8)
+    code = np.empty((T, N), np.uint8)
+    ctrl = None if action is None else np.empty((T, N, spec.nu), np.float64 if ctrl_f64 else np.float32)
+    rc = lib().oly_il_step_cpu(C.byref(m), T, N, _p(qpos), _p(qvel), _p(action), _p(grf_mean),
+                               _p(prev), _p(obs), _p(reward), _p(absorbing), _p(code), _p(ctrl),
+                               flags, _p(reward64))
+    _chk(rc, "il_step")
+    return dict(obs=obs, reward=reward, reward_f64=reward64, absorbing=absorbing, fall_code=code,
+                ctrl=ctrl, prev=prev)
+
+
+def il_step_mt(spec, qpos, qvel, action, prev, out, threads=0):
+    """In-place multi-threaded variant for the cpu_baseline leg; `out` holds preallocated
+    obs/reward/absorbing/ctrl arrays."""
+    m = spec.to_c()
+    T, N = qpos.shape[:2]
+    rc = lib().oly_il_step_cpu_mt(C.byref(m), T, N, _p(qpos), _p(qvel), _p(action), _p(prev),
+                                  _p(out["obs"]), _p(out["reward"]), _p(out["absorbing"]),
+                                  _p(out["ctrl"]), 0, int(threads))
+    _chk(rc, "il_step_mt")
+
+
+def traj_reset(table, traj_no, step):
+    table = _c(table, np.float64)
+    K, J, L = table.shape
+    traj_no, step = _c(traj_no, np.int32), _c(step, np.int32)
+    N = len(traj_no)
+    ct, cs = np.empty(N, np.int32), np.empty(N, np.int32)
+    origin, sample = np.empty((N, 2)), np.empty((N, K))
+    _chk(lib().oly_traj_reset_cpu(K, J, L, _p(table), N, _p(traj_no), _p(step), _p(ct), _p(cs),
+                                  _p(origin), _p(sample)), "traj_reset")
+    return ct, cs, origin, sample
+
+
+def traj_next(table, cur_traj, cur_step, origin, sample, active=None):
+    table = _c(table, np.float64)
+    K, J, L = table.shape
+    N = len(cur_traj)
+    cur_step = np.array(cur_step, dtype=np.int32, copy=True)
+    sample = np.array(sample, dtype=np.float64, copy=True)
+    at_end = np.empty(N, np.uint8)
+    active = _c(active, np.uint8)
+    _chk(lib().oly_traj_next_cpu(K, J, L, _p(table), N, _p(active), _p(_c(cur_traj, np.int32)),
+                                 _p(cur_step), _p(_c(origin, np.float64)), _p(sample), _p(at_end)),
+         "traj_next")
+    return cur_step, sample, at_end
+
+
+def traj_euler(n_qpos, dt, curr_qpos, sample):
+    sample = np.array(sample, dtype=np.float64, copy=True)
+    N, K = sample.shape
+    _chk(lib().oly_traj_euler_cpu(K, N, n_qpos, C.c_double(dt), _p(_c(curr_qpos, np.float64)),
+                                  _p(sample)), "traj_euler")
+    return sample
+
+
+def contact_reduce(geom_bodyid, floor, rfoot, lfoot, ncon, geom1, geom2, force6, pos_z):
+    gb = _c(geom_bodyid, np.int32)
+    ncon, geom1, geom2 = _c(ncon, np.int32), _c(geom1, np.int32), _c(geom2, np.int32)
+    force6, pos_z = _c(force6, np.float64), _c(pos_z, np.float64)
+    N, Cc = geom1.shape
+    o = dict(n_r=np.empty(N, np.int32), n_l=np.empty(N, np.int32), idx_r=np.empty((N, Cc), np.int32),
+             idx_l=np.empty((N, Cc), np.int32), grf_r=np.empty(N), grf_l=np.empty(N),
+             min_z=np.empty(N), bad=np.empty(N, np.uint8))
+    _chk(lib().oly_contact_reduce_cpu(len(gb), _p(gb), floor, rfoot, lfoot, N, Cc, _p(ncon),
+                                      _p(geom1), _p(geom2), _p(force6), _p(pos_z), _p(o["n_r"]),
+                                      _p(o["n_l"]), _p(o["idx_r"]), _p(o["idx_l"]), _p(o["grf_r"]),
+                                      _p(o["grf_l"]), _p(o["min_z"]), _p(o["bad"])), "contact_reduce")
+    return o
+
+
+_A3_IN_DT = dict(n_r=np.int32, n_l=np.int32, bad=np.uint8)
+_A3_ST_DT = dict(phase=np.int32, t1=np.int32, t2=np.int32, reached_frames=np.int32,
+                 target_reached=np.uint8, mode=np.int32, seq_len=np.int32, sequence=np.float64,
+                 goal=np.float64)
+
+
+def a3_step(spec, clock_lut, inputs, state, obs_f64=True):
+    """inputs/state: dicts of numpy arrays named as in oly_a3_inputs / oly_a3_state.
+    State arrays are updated IN PLACE (they must be contiguous and correctly typed)."""
+    m = spec.to_c(np.ascontiguousarray(clock_lut, dtype=np.float64))
+    keep = []
+    cin, cst = _abi.A3Inputs(), _abi.A3State()
+    for n in _abi.A3_INPUT_FIELDS:
+        a = _c(inputs[n], _A3_IN_DT.get(n, np.float64))
+        keep.append(a)
+        setattr(cin, n, a.ctypes.data)
+    for n in _abi.A3_STATE_FIELDS:
+        a = state[n]
+        assert a.dtype == _A3_ST_DT[n] and a.flags.c_contiguous, n
+        setattr(cst, n, a.ctypes.data)
+    N = len(state["phase"])
+    obs = np.empty((N, spec.n_obs), np.float64 if obs_f64 else np.float32)
+    rew6, reward, done = np.empty((N, 6), np.float32), np.empty(N, np.float32), np.empty(N, np.uint8)
+    rew6_64, reward_64 = np.empty((N, 6)), np.empty(N)
+    _chk(lib().oly_a3_step_cpu(C.byref(m), N, C.byref(cin), C.byref(cst), _p(obs), _p(rew6),
+                               _p(reward), _p(done), _abi.OUT_OBS_F64 if obs_f64 else 0,
+                               _p(rew6_64), _p(reward_64)), "a3_step")
+    return dict(obs=obs, rew6=rew6, reward=reward, done=done, rew6_f64=rew6_64, reward_f64=reward_64)
+
+
+def a3_pd_target(spec, action):
+    m = spec.to_c(np.zeros((4, spec.period)))
+    action = _c(action, np.float32)
+    out = np.empty(action.shape, np.float64)
+    _chk(lib().oly_a3_pd_target_cpu(C.byref(m), len(action), _p(action), _p(out)), "pd_target")
+    return out
+
+
+def a3_pd_torque(spec, target, act_len, act_vel):
+    m = spec.to_c(np.zeros((4, spec.period)))
+    target, act_len, act_vel = (_c(a, np.float64) for a in (target, act_len, act_vel))
+    kp, kd = _c(spec.kp, np.float64), _c(spec.kd, np.float64)
+    out = np.empty_like(target)
+    _chk(lib().oly_a3_pd_torque_cpu(C.byref(m), len(target), _p(kp), _p(kd), _p(target), _p(act_len),
+                                    _p(act_vel), _p(out)), "pd_torque")
+    return out
+
+
+def return_scan(mode, gamma, lam, rew, val, next_val, flags):
+    rew, val, next_val = (_c(a, np.float32) for a in (rew, val, next_val))
+    flags = _c(flags, np.uint8)
+    T, N = rew.shape
+    ret, adv = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    _chk(lib().oly_return_scan_cpu(mode, T, N, C.c_double(gamma), C.c_double(lam), _p(rew), _p(val),
+                                   _p(next_val), _p(flags), _p(ret), _p(adv)), "return_scan")
+    return ret, adv
+
+
+def adv_stats(x):
+    x = _c(x, np.float32).reshape(-1)
+    s = np.empty(3)
+    _chk(lib().oly_adv_stats_cpu(C.c_int64(x.size), _p(x), _p(s)), "adv_stats")
+    return s
+
+
+def adv_normalize(x, stats3, ddof, eps):
+    x = np.array(x, dtype=np.float32, copy=True)
+    _chk(lib().oly_adv_normalize_cpu(C.c_int64(x.size), _p(x), _p(_c(stats3, np.float64)), int(ddof),
+                                     C.c_double(eps)), "adv_normalize")
+    return x
+
+
+def col_stats(x, colstats=None):
+    x = _c(x, np.float32)
+    B, D = x.shape
+    acc = colstats is not None
+    cs = np.array(colstats, dtype=np.float64, copy=True) if acc else np.empty((3, D))
+    _chk(lib().oly_col_stats_cpu(B, D, _p(x), _p(cs), int(acc)), "col_stats")
+    return cs
+
+
+def disc_standardize(x, mask, mean, std):
+    x = _c(x, np.float32)
+    B, Dx = x.shape
+    mask = _c(mask, np.int32)
+    D = Dx if mask is None else len(mask)
+    out = np.empty((B, D), np.float32)
+    _chk(lib().oly_disc_standardize_cpu(B, Dx, D, _p(x), _p(mask), _p(_c(mean, np.float64)),
+                                        _p(_c(std, np.float64)), _p(out)), "disc_standardize")
+    return out
+
+
+def disc_reparam(mu, logvar, eps):
+    mu, logvar, eps = (_c(a, np.float32) for a in (mu, logvar, eps))
+    z = np.empty_like(mu)
+    _chk(lib().oly_disc_reparam_cpu(C.c_int64(mu.size), _p(mu), _p(logvar), _p(eps), _p(z)), "reparam")
+    return z
+
+
+def disc_reward(logits):
+    logits = _c(logits, np.float32).reshape(-1)
+    r = np.empty_like(logits)
+    _chk(lib().oly_disc_reward_cpu(C.c_int64(logits.size), _p(logits), _p(r)), "disc_reward")
+    return r

@@ -1,0 +1,343 @@
+"""Pins the CPU oracle (oracle/oly_oracle.c) to the golden vectors that were produced by
+executing the reference's own functions (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from olympic_hip import _abi, specs
+from helpers import h1_rows_from_full, a3_fixture_arrays, ulp_diff
+
+
+# ------------------------------------------------------------------------------ K1/K5
+def test_h1_obs_fallen_reward_action(golden, oracle):
+    g = golden("h1_step.npz")
+    spec = specs.unitree_h1("walk")
+    qpos, qvel = h1_rows_from_full(spec, g["full_obs"])
+    M = len(qpos)
+    prev = g["obs"][:, spec.reward_idx]            # reward(state=obs_i): prev obs := obs_i
+    o = oracle.il_step(spec, qpos[None], qvel[None], g["action"][None].astype(np.float32), prev,
+                       obs_f64=True, ctrl_f64=True)
+    assert np.array_equal(o["obs"][0], g["obs"])                    # bit-exact float64
+    assert np.array_equal(o["absorbing"][0].astype(bool), g["absorbing"])
+    assert np.array_equal(o["absorbing"][0].astype(bool), g["fallen"])
+    assert np.array_equal(o["fall_code"][0], g["msg_code"])
+    assert ulp_diff(o["reward_f64"][0], g["reward_walk"]).max() <= 2   # libm exp vs numpy exp
+    assert np.array_equal(o["prev"], g["obs"][:, spec.reward_idx])
+    # action: golden action is float64; the kernel contract takes float32 actions
+    a32 = g["action"].astype(np.float32).astype(np.float64)
+    un = a32 * spec.act_delta + spec.act_mean
+    exp_ctrl = np.zeros((M, spec.nu))
+    exp_ctrl[:, spec.act_to_ctrl] = np.clip(un, spec.ctrl_lo, spec.ctrl_hi)
+    assert np.array_equal(o["ctrl"][0], exp_ctrl)
+    # and the reference's own un-normalisation on the float64 action
+    assert np.array_equal(g["action"] * spec.act_delta + spec.act_mean, g["unnorm_action"])
+    # fp32 outputs are the correctly rounded fp64 ones
+    o32 = oracle.il_step(spec, qpos[None], qvel[None], g["action"][None].astype(np.float32), prev)
+    assert np.array_equal(o32["obs"][0], g["obs"].astype(np.float32))
+    assert np.array_equal(o32["ctrl"][0], exp_ctrl.astype(np.float32))
+
+
+def test_h1_run_reward_and_no_absorbing(golden, oracle):
+    g = golden("h1_step.npz")
+    spec = specs.unitree_h1("run", use_absorbing_states=False)
+    qpos, qvel = h1_rows_from_full(spec, g["full_obs"])
+    o = oracle.il_step(spec, qpos[None], qvel[None], None, g["obs"][:, spec.reward_idx], obs_f64=True)
+    assert ulp_diff(o["reward_f64"][0], g["reward_run"]).max() <= 2
+    assert not o["absorbing"].any()                         # base_humanoid_robot.py:260
+    assert np.array_equal(o["fall_code"][0], g["msg_code"])  # _has_fallen itself is unchanged
+
+
+def test_h1_reward_reads_previous_obs(golden, oracle):
+    """reward[t] = f(obs[t-1]); reward[0] = f(carried prev); prev_out = obs[T-1] (utils/reward.py:72)."""
+    g = golden("h1_step.npz")
+    spec = specs.unitree_h1("walk")
+    T, N = 12, 100
+    qpos, qvel = h1_rows_from_full(spec, g["full_obs"][:T * N])
+    qpos, qvel = qpos.reshape(T, N, -1), qvel.reshape(T, N, -1)
+    prev0 = np.linspace(-1, 3, N)
+    o = oracle.il_step(spec, qpos, qvel, None, prev0, obs_f64=True)
+    rw = g["reward_walk"][:T * N].reshape(T, N)
+    assert ulp_diff(o["reward_f64"][1:], rw[:-1]).max() <= 2
+    assert ulp_diff(o["reward_f64"][0], np.exp(-np.square(prev0 - 1.25))).max() <= 2
+    assert np.array_equal(o["prev"], g["obs"][:T * N].reshape(T, N, -1)[-1, :, spec.reward_idx])
+
+
+def test_h1_x_pos_reward_negative_index_quirk(golden, oracle):
+    """PosReward index is get_obs_idx('q_pelvis_tx') = -2: python wraps to obs[n_obs-2]
+    (loco_env_base.py:810,1203)."""
+    g = golden("h1_step.npz")
+    spec = specs.unitree_h1("walk", reward_type="x_pos")
+    assert spec.reward_idx == spec.n_obs - 2
+    qpos, qvel = h1_rows_from_full(spec, g["full_obs"][:64])
+    o = oracle.il_step(spec, qpos[None], qvel[None], None, g["obs"][:64, -2], obs_f64=True)
+    assert np.array_equal(o["reward_f64"][0], g["obs"][:64, -2])
+    spec0 = specs.unitree_h1("walk", reward_type=None)
+    o0 = oracle.il_step(spec0, qpos[None], qvel[None], None, np.zeros(64))
+    assert not o0["reward"].any()
+
+
+# --------------------------------------------------------------------------------- K6
+def _ppo_block(g):
+    """Lay the ragged golden episodes out as a [T,1] rollout block with flags."""
+    L = g["ep_len"]
+    n = int(L.sum())
+    flags = np.zeros(n, np.uint8)
+    next_val = np.zeros(n, np.float32)
+    end = np.cumsum(L) - 1
+    for e, dn, lv in zip(end, g["done_tail"], g["last_val"]):
+        flags[e] = _abi.FLAG_LAST | (_abi.FLAG_ABSORBING if dn else 0)
+        next_val[e] = lv
+    return flags, next_val
+
+
+def test_ppo_finish_path(golden, oracle):
+    g = golden("ppo_returns.npz")
+    flags, next_val = _ppo_block(g)
+    ret, adv = oracle.return_scan(_abi.SCAN_RETURN, float(g["gamma"]), 0.95, g["rewards"][:, None],
+                                  g["values"][:, None], next_val[:, None], flags[:, None])
+    assert np.array_equal(ret[:, 0], g["returns"])          # bit-exact float32
+    assert np.array_equal(adv[:, 0], g["adv"])
+    st = oracle.adv_stats(adv)
+    assert st[0] == adv.size
+    out = oracle.adv_normalize(adv, st, ddof=1, eps=float(g["eps"]))
+    np.testing.assert_allclose(out[:, 0], g["adv_norm"], rtol=2e-6, atol=2e-7)
+
+
+def test_ppo_reference_smoke_value():
+    """r=[1,2,3], gamma=.99, V_last=10 -> [15.62329, 14.771, 12.9]."""
+    from oracle import oracle as orc
+    ret, _ = orc.return_scan(_abi.SCAN_RETURN, 0.99, 0.0, np.array([[1.], [2.], [3.]]),
+                             np.zeros((3, 1)), np.array([[0.], [0.], [10.]]),
+                             np.array([[0], [0], [_abi.FLAG_LAST]]))
+    np.testing.assert_allclose(ret[:, 0], [15.62329, 14.771, 12.9], rtol=1e-6)
+
+
+def _gae_py(v, vn, r, absorbing, last, gamma, lam):
+    """mushroom_rl.utils.value_functions.compute_gae restated (float32 numpy, as called)."""
+    adv = np.empty_like(v)
+    for rev_k in range(len(v)):
+        k = len(v) - rev_k - 1
+        if last[k] or rev_k == 0:
+            adv[k] = r[k] - v[k]
+            if not absorbing[k]:
+                adv[k] += gamma * vn[k]
+        else:
+            adv[k] = r[k] + gamma * vn[k] - v[k] + gamma * lam * adv[k + 1]
+    return adv + v, adv
+
+
+def test_gae_matches_restated_mushroom(oracle):
+    rng = np.random.default_rng(0)
+    T, N = 257, 7
+    r = rng.uniform(-0.3, 1, (T, N)).astype(np.float32)
+    v = rng.normal(0, 1, (T, N)).astype(np.float32)
+    vn = rng.normal(0, 1, (T, N)).astype(np.float32)
+    last = rng.uniform(size=(T, N)) < 0.02
+    absorbing = last & (rng.uniform(size=(T, N)) < 0.5)
+    flags = (last * _abi.FLAG_LAST + absorbing * _abi.FLAG_ABSORBING).astype(np.uint8)
+    ret, adv = oracle.return_scan(_abi.SCAN_GAE, 0.99, 0.97, r, v, vn, flags)
+    for n in range(N):
+        e_ret, e_adv = _gae_py(v[:, n:n + 1], vn[:, n:n + 1], r[:, n], absorbing[:, n], last[:, n],
+                               0.99, 0.97)
+        assert np.array_equal(adv[:, n], e_adv[:, 0])
+        assert np.array_equal(ret[:, n], e_ret[:, 0])
+
+
+def test_gae_hand_computed_toy(oracle):
+    # 3 steps, no episode end inside, gamma=.5, lam=.5, v=0 everywhere, v_next=0:
+    # adv2 = r2 = 4 ; adv1 = r1 + .25*adv2 = 3 ; adv0 = r0 + .25*adv1 = 1.75
+    r = np.array([[1.], [2.], [4.]], np.float32)
+    z = np.zeros((3, 1), np.float32)
+    ret, adv = oracle.return_scan(_abi.SCAN_GAE, 0.5, 0.5, r, z, z, np.zeros((3, 1), np.uint8))
+    assert adv[:, 0].tolist() == [1.75, 3.0, 4.0]
+    assert ret[:, 0].tolist() == [1.75, 3.0, 4.0]
+
+
+def test_gae_lambda1_equals_discounted_return(oracle):
+    """GAE(lam=1) + v is the bootstrapped discounted return of finish_path (ppo.py:68-84)
+    when v_next[t] = v[t+1] inside an episode."""
+    rng = np.random.default_rng(1)
+    T, N = 64, 5
+    r = rng.uniform(0, 1, (T, N)).astype(np.float32)
+    v = rng.normal(0, 1, (T, N)).astype(np.float32)
+    vn = np.roll(v, -1, axis=0)
+    vn[-1] = rng.normal(0, 1, N)
+    flags = np.zeros((T, N), np.uint8)
+    flags[20, 1] = _abi.FLAG_LAST | _abi.FLAG_ABSORBING
+    flags[40, 3] = _abi.FLAG_LAST
+    ret_g, _ = oracle.return_scan(_abi.SCAN_GAE, 0.99, 1.0, r, v, vn, flags)
+    ret_r, _ = oracle.return_scan(_abi.SCAN_RETURN, 0.99, 1.0, r, v, vn, flags)
+    np.testing.assert_allclose(ret_g, ret_r, rtol=2e-5, atol=2e-5)
+
+
+# --------------------------------------------------------------------------------- K7
+def test_col_stats_vs_standardizer_and_rms(golden, oracle):
+    g = golden("running_stats.npz")
+    x = g["x"]
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    cs = None
+    # Standardizer: _sum=0, _sumsq=1e-2, _count=1e-2 (networks.py:54-56)
+    for i in range(len(g["lens"])):
+        xb = x[off[i]:off[i + 1]].astype(np.float32)
+        cs = oracle.col_stats(xb, cs)
+        cnt = cs[0] + 1e-2
+        mean = cs[1] / cnt
+        std = np.sqrt(np.maximum((cs[2] + 1e-2) / cnt - mean ** 2, 1e-2))
+        np.testing.assert_allclose(mean, g["st_mean"][i], rtol=1e-5, atol=1e-6)   # ref sums in f32
+        np.testing.assert_allclose(std, g["st_std"][i], rtol=1e-5, atol=1e-6)
+    out = oracle.disc_standardize(g["st_fwd_in"], None, g["st_fwd_mean"], g["st_fwd_std"])
+    assert np.array_equal(out, g["st_fwd_out"].astype(np.float32))
+    # RunningMeanStd (normalize.py:182-208) from the same (count,sum,sumsq) triples
+    cs = None
+    for i in range(len(g["lens"])):
+        cs = oracle.col_stats(x[off[i]:off[i + 1]].astype(np.float32), cs)
+    xs32 = x.astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(cs[1] / cs[0], xs32.mean(0), rtol=1e-12)
+    np.testing.assert_allclose(cs[2] / cs[0] - (cs[1] / cs[0]) ** 2, xs32.var(0), rtol=1e-10)
+    np.testing.assert_allclose(g["rms_mean"][-1], x.mean(0), rtol=1e-4)   # count starts at eps=1e-4
+
+
+# --------------------------------------------------------------------------------- K4
+def test_trajectory_cursor(golden, oracle):
+    g = golden("trajectory.npz")
+    table = g["table"]
+    resets = g["resets"]
+    ct, cs, origin, sample = oracle.traj_reset(table, resets[:, 1], resets[:, 0])
+    assert np.array_equal(sample, g["reset_samples"])
+    assert np.array_equal(ct, resets[:, 1]) and np.array_equal(cs, resets[:, 0])
+    # random reset then walk to the end
+    sub, tno = g["rnd_reset"]
+    ct, cs, origin, sample = oracle.traj_reset(table, [tno], [sub])
+    walk = [sample[0].copy()]
+    L = table.shape[2]
+    while True:
+        cs, sample, at_end = oracle.traj_next(table, ct, cs, origin, sample)
+        if at_end[0]:
+            assert cs[0] == L                                  # reference: step == trajectory_length
+            break
+        walk.append(sample[0].copy())
+    assert np.array_equal(np.array(walk), g["walk"])
+
+
+def test_trajectory_euler(golden, oracle):
+    g = golden("trajectory.npz")
+    s = g["walk"][:5].copy()
+    cur = np.random.default_rng(0).normal(size=(5, 17))
+    out = oracle.traj_euler(17, 0.01, cur, s)
+    exp = s.copy()
+    for n in range(5):
+        exp[n, :17] = [qp + 0.01 * qv for qp, qv in zip(cur[n], s[n, 17:34])]   # loco_env_base.py:517
+    assert np.array_equal(out, exp)
+
+
+# --------------------------------------------------------------------------------- K3
+def test_contact_reduce(golden, oracle):
+    g = golden("contacts.npz")
+    o = oracle.contact_reduce(g["geom_bodyid"], int(g["floor_body"]), int(g["rfoot_body"]),
+                              int(g["lfoot_body"]), g["ncon"], g["geom1"], g["geom2"], g["force6"],
+                              g["pos"][:, :, 2])
+    for k in ("n_r", "n_l", "idx_r", "idx_l"):
+        assert np.array_equal(o[k], g[k]), k
+    assert np.array_equal(o["bad"].astype(bool), g["bad"])
+    np.testing.assert_allclose(o["grf_r"], g["grf_r"], rtol=1e-14)     # norm: BLAS vs plain loop
+    np.testing.assert_allclose(o["grf_l"], g["grf_l"], rtol=1e-14)
+    assert np.array_equal(o["min_z"], g["min_z"])
+    assert np.array_equal((o["n_r"] + o["n_l"]) > 0, g["any_foot"])
+
+
+# --------------------------------------------------------------------------------- K2
+def test_a3_task_step_reward_done_obs(golden, oracle):
+    g = golden("a3_task.npz")
+    spec = specs.A3Spec(mass=float(g["mass"]))
+    assert spec.period == int(g["period"]) and spec.delay_frames == int(g["delay_frames"])
+    E, K = g["phase"].shape
+    st, _ = a3_fixture_arrays(g, 0)
+    for k in range(K):
+        _, inp = a3_fixture_arrays(g, k)
+        cr = oracle.contact_reduce(g["geom_bodyid"], int(g["floor_body"]), int(g["rfoot_body"]),
+                                   int(g["lfoot_body"]), g["ncon"][:, k], g["geom1"][:, k],
+                                   g["geom2"][:, k], g["force6"][:, k], g["cpos_z"][:, k])
+        np.testing.assert_allclose(cr["grf_l"], g["grf_l"][:, k], rtol=1e-14)
+        inp.update(grf_l=cr["grf_l"], grf_r=cr["grf_r"], min_z=cr["min_z"], n_r=cr["n_r"],
+                   n_l=cr["n_l"], bad=cr["bad"])
+        o = oracle.a3_step(spec, g["clock_lut"], inp, st)
+        # integer task state: bit-exact
+        assert np.array_equal(st["phase"], g["phase"][:, k]), k
+        assert np.array_equal(st["t1"], g["t1"][:, k]) and np.array_equal(st["t2"], g["t2"][:, k])
+        assert np.array_equal(st["target_reached"].astype(bool), g["target_reached"][:, k])
+        assert np.array_equal(st["reached_frames"], g["reached_frames"][:, k])
+        assert np.array_equal(o["done"].astype(bool), g["done"][:, k])
+        # float: goal uses LAPACK inverse in the reference, analytic rigid inverse here
+        np.testing.assert_allclose(st["goal"], g["goal"][:, k], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(o["rew6_f64"], g["rew6"][:, k], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(o["reward_f64"], g["reward"][:, k], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(o["obs"], g["obs"][:, k], rtol=1e-12, atol=1e-13)
+
+
+def test_a3_pd_target_and_torque(golden, oracle):
+    g = golden("a3_task.npz")
+    spec = specs.A3Spec()
+    assert np.array_equal(spec.motor_offset, g["motor_offset"])
+    assert np.array_equal(spec.kp, g["pd_kp"]) and np.array_equal(spec.kd, g["pd_kd"])
+    a32 = g["pd_action"].astype(np.float32)
+    tgt = oracle.a3_pd_target(spec, a32)
+    assert np.array_equal(tgt, a32.astype(np.float64) + g["motor_offset"])
+    np.testing.assert_allclose(tgt, g["pd_target"], rtol=0, atol=1e-7)     # f32 action contract
+    B, S, _ = g["pd_q"].shape
+    for s in range(S):
+        tau = oracle.a3_pd_torque(spec, g["pd_target"], g["pd_q"][:, s], g["pd_qd"][:, s])
+        assert np.array_equal(tau, g["pd_tau"][:, s])                      # bit-exact float64
+
+
+def test_clock_lut_range(golden):
+    g = golden("a3_task.npz")
+    lut = g["clock_lut"]
+    assert lut.shape == (4, 88) and np.abs(lut).max() <= 1.0 + 1e-12
+
+
+# --------------------------------------------------------------------------------- K8
+def test_disc_reward(golden, oracle):
+    g = golden("vail_disc.npz")
+    d = g["d"].reshape(-1)
+    r = oracle.disc_reward(d)
+    # 1 - sigmoid(d) cancels: an error of k ulp in p becomes k*2^-24/(1-p+1e-8) in the reward.
+    p = 1.0 / (1.0 + np.exp(-d.astype(np.float64)))
+    tol = 4 * 2.0 ** -24 / (1 - p + 1e-8) + 4e-7 * np.abs(g["reward"]) + 1e-7
+    assert (np.abs(r - g["reward"]) <= tol).all()
+    re = oracle.disc_reward(g["d_ext"])
+    pe = 1.0 / (1.0 + np.exp(-g["d_ext"].reshape(-1).astype(np.float64)))
+    tole = 4 * 2.0 ** -24 / (1 - pe + 1e-8) + 4e-7 * np.abs(g["reward_ext"]) + 1e-7
+    assert (np.abs(re - g["reward_ext"]) <= tole).all()
+    assert np.isfinite(re).all() and re[-1] == pytest.approx(-np.log(np.float32(1e-8)), rel=1e-6)
+
+
+def test_disc_standardize_and_reparam(golden, oracle):
+    g = golden("vail_disc.npz")
+    # the forward updated the statistics with x BEFORE standardising (networks.py:68-74)
+    xs = oracle.disc_standardize(g["x"], np.arange(32), g["st_mean"], g["st_std"])
+    ref = ((g["x"].astype(np.float64) - g["st_mean"]) / g["st_std"]).astype(np.float32)
+    assert np.array_equal(xs, ref)
+    z = oracle.disc_reparam(g["mu"], g["logvar"], g["eps"])
+    import torch
+    zt = (torch.tensor(g["mu"]) + torch.exp(torch.tensor(g["logvar"]) / 2) * torch.tensor(g["eps"])).numpy()
+    np.testing.assert_allclose(z, zt, rtol=3e-7, atol=1e-7)
+
+
+def test_vail_forward_end_to_end(golden, oracle):
+    """Pre-amble + torch GEMMs + epilogue reproduce the reference network's logits/reward."""
+    import torch
+    g = golden("vail_disc.npz")
+    cs = oracle.col_stats(g["x"])
+    cnt = cs[0] + 1e-2
+    mean = cs[1] / cnt
+    std = np.sqrt(np.maximum((cs[2] + 1e-2) / cnt - mean ** 2, 1e-2))
+    np.testing.assert_allclose(mean, g["st_mean"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(std, g["st_std"], rtol=2e-5, atol=2e-6)
+    xs = torch.tensor(oracle.disc_standardize(g["x"], None, g["st_mean"], g["st_std"]))
+    t = lambda k: torch.tensor(g[k])
+    h = torch.relu(xs @ t("enc_w0").T + t("enc_b0"))
+    h = torch.relu(h @ t("enc_w1").T + t("enc_b1"))
+    mu, lv = h @ t("mu_w").T + t("mu_b"), h @ t("lv_w").T + t("lv_b")
+    np.testing.assert_allclose(mu.numpy(), g["mu"], rtol=1e-4, atol=1e-5)
+    z = torch.tensor(oracle.disc_reparam(mu.numpy(), lv.numpy(), g["eps"]))
+    d = z @ t("dec_w").T + t("dec_b")
+    np.testing.assert_allclose(d.numpy(), g["d"], rtol=1e-3, atol=1e-3)
