@@ -1,0 +1,338 @@
+// K2 + K5: StickFigureA3 reinforcement-learning step (A1 / Jvrc share the code).
+//   WalkingTask.step           tasks/walking_task.py:246-293 (+ :228-244, :184-225)
+//   WalkingTask.calc_reward    :74-110, step_reward :56-72, tasks/rewards.py:27-40,65-102,121-126
+//   WalkingTask.done           :298-319
+//   StickFigureA3.get_obs      real_humanoid_robots/StickFigureA3.py:144-178
+//   robot.JVRC.step target     environments/robot.py:88-95, PD torque :109-115 with
+//                              MujocoRobotInterface.step_pd mujoco_robot_interface.py:425-443
+//
+// One lane per environment for the task logic (integer state machine + ~10 transcendental
+// calls in fp64); the 41-wide observation rows are assembled in LDS and leave as a dense
+// stream.  Integer state (phase, t1, t2, frame counters, flags) is bit-exact; every fp64
+// expression keeps the reference's evaluation order (compiled with -ffp-contract=off).
+// Bound: HBM, ~930 B read + ~257 B written per env.
+#include "oly_common.h"
+
+namespace {
+constexpr int THREADS = 128;
+constexpr double PI = 3.141592653589793;
+
+struct A3Args {
+  const A3Dev* md;
+  int N;
+  oly_a3_inputs in;
+  oly_a3_state st;
+  void* obs;
+  float* rew6;
+  float* reward;
+  uint8_t* done;
+};
+
+__device__ __forceinline__ void quat2mat(const double* q, double R[3][3]) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double nq = w * w + x * x + y * y + z * z;
+  if (nq < 2.220446049250313e-16) {
+    R[0][0] = 1; R[0][1] = 0; R[0][2] = 0;
+    R[1][0] = 0; R[1][1] = 1; R[1][2] = 0;
+    R[2][0] = 0; R[2][1] = 0; R[2][2] = 1;
+    return;
+  }
+  const double s = 2.0 / nq;
+  const double X = x * s, Y = y * s, Z = z * s;
+  const double wX = w * X, wY = w * Y, wZ = w * Z;
+  const double xX = x * X, xY = x * Y, xZ = x * Z;
+  const double yY = y * Y, yZ = y * Z, zZ = z * Z;
+  R[0][0] = 1.0 - (yY + zZ); R[0][1] = xY - wZ;         R[0][2] = xZ + wY;
+  R[1][0] = xY + wZ;         R[1][1] = 1.0 - (xX + zZ); R[1][2] = yZ - wX;
+  R[2][0] = xZ - wY;         R[2][1] = yZ + wX;         R[2][2] = 1.0 - (xX + yY);
+}
+
+__device__ __forceinline__ double norm3d(double a0, double a1, double a2) {
+  return sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+}
+
+template <bool OBS64>
+__global__ __launch_bounds__(THREADS) void a3_step_kernel(A3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double* s_obs = reinterpret_cast<double*>(lds_raw);  // [THREADS][n_obs]
+  const A3Dev* __restrict__ m = p.md;
+  const int n_obs = m->n_obs, nu = m->nu, nq = m->nq, nv = m->nv, period = m->period;
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * THREADS;
+  const int n = n0 + tid;
+  if (n < p.N) {
+    const double* lf = p.in.lf_pos + 3 * (size_t)n;
+    const double* rf = p.in.rf_pos + 3 * (size_t)n;
+    const double lf0 = lf[0], lf1 = lf[1], lf2 = lf[2], rf0 = rf[0], rf1 = rf[1], rf2 = rf[2];
+    const double* seq = p.st.sequence + (size_t)n * OLY_MAX_SEQ * 4;
+    const int mode = p.st.mode[n];
+    const int seq_len = p.st.seq_len[n];
+
+    // ---- WalkingTask.step
+    int phase = p.st.phase[n] + 1;
+    if (phase >= period) phase = 0;
+    int t1 = p.st.t1[n], t2 = p.st.t2[n];
+    t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
+    t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
+    double tx = seq[4 * t1], ty = seq[4 * t1 + 1], tz = seq[4 * t1 + 2];
+    const double dl = norm3d(lf0 - tx, lf1 - ty, lf2 - tz);
+    const double dr = norm3d(rf0 - tx, rf1 - ty, rf2 - tz);
+    int reached, frames = p.st.reached_frames[n];
+    if (dl < m->target_radius || dr < m->target_radius) {
+      reached = 1;
+      frames += 1;
+    } else {
+      reached = 0;
+      frames = 0;
+    }
+    if (reached && frames >= m->delay_frames) {  // update_target_steps
+      t1 = t2;
+      t2 += 1;
+      if (t2 == seq_len) t2 = seq_len - 1;
+      t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
+      reached = 0;
+      frames = 0;
+    }
+    p.st.phase[n] = phase;
+    p.st.t1[n] = t1;
+    p.st.t2[n] = t2;
+    p.st.reached_frames[n] = frames;
+    p.st.target_reached[n] = (uint8_t)reached;
+
+    // ---- update_goal_steps
+    const double* rp = p.in.root_pos + 3 * (size_t)n;
+    const double* rqp = p.in.root_quat + 4 * (size_t)n;
+    const double rp0 = rp[0], rp1 = rp[1], rp2 = rp[2];
+    double rq[4] = {rqp[0], rqp[1], rqp[2], rqp[3]};
+    double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (mode != OLY_MODE_STANDING) {
+      double R[3][3];
+      quat2mat(rq, R);
+      const int tt[2] = {t1, t2};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const double* s = seq + 4 * tt[i];
+        const double d0 = s[0] - rp0, d1 = s[1] - rp1, d2 = s[2] - rp2;
+        goal[0 + i] = R[0][0] * d0 + R[1][0] * d1 + R[2][0] * d2;
+        goal[2 + i] = R[0][1] * d0 + R[1][1] * d1 + R[2][1] * d2;
+        goal[4 + i] = R[0][2] * d0 + R[1][2] * d1 + R[2][2] * d2;
+        const double c = cos(s[3]), sn = sin(s[3]);
+        const double m00 = R[0][0] * c + R[1][0] * sn;
+        const double m10 = R[0][1] * c + R[1][1] * sn;
+        goal[6 + i] = atan2(m10, m00);
+      }
+    }
+    double* gout = p.st.goal + 8 * (size_t)n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gout[i] = goal[i];
+
+    // ---- calc_reward
+    double c_rfrc, c_rvel, c_lfrc, c_lvel;
+    if (mode == OLY_MODE_STANDING) {
+      c_rfrc = 1.0; c_lfrc = 1.0; c_rvel = -1.0; c_lvel = -1.0;
+    } else {
+      c_rfrc = m->clock_lut[0 * period + phase];
+      c_rvel = m->clock_lut[1 * period + phase];
+      c_lfrc = m->clock_lut[2 * period + phase];
+      c_lvel = m->clock_lut[3 * period + phase];
+    }
+    const double max_frc = m->mass * 9.8 * 0.5;
+    double nl = fmin(p.in.grf_l[n], max_frc) / max_frc;
+    double nr = fmin(p.in.grf_r[n], max_frc) / max_frc;
+    nl *= 2; nl -= 1; nr *= 2; nr -= 1;
+    const double frc = (tan(PI / 4 * c_lfrc * nl) + tan(PI / 4 * c_rfrc * nr)) / 2;
+    const double* lv = p.in.lf_vel + 3 * (size_t)n;
+    const double* rv = p.in.rf_vel + 3 * (size_t)n;
+    double vl = fmin(norm3d(lv[0], lv[1], lv[2]), 0.2) / 0.2;
+    double vr = fmin(norm3d(rv[0], rv[1], rv[2]), 0.2) / 0.2;
+    vl *= 2; vl -= 1; vr *= 2; vr -= 1;
+    const double vel = (tan(PI / 4 * c_lvel * vl) + tan(PI / 4 * c_rvel * vr)) / 2;
+    const double yaw = seq[4 * t1 + 3];
+    const double tq0 = cos(yaw / 2.0), tq3 = sin(yaw / 2.0);
+    const double ip = tq0 * rq[0] + 0.0 * rq[1] + 0.0 * rq[2] + tq3 * rq[3];
+    const double orient = exp(-(10 * (1 - ip * ip)));
+    const double contact_point = (p.in.n_r[n] > 0 || p.in.n_l[n] > 0) ? p.in.min_z[n] : 0.0;
+    double err = fabs((rp2 - contact_point) - m->goal_height_ref);
+    const double deadzone = 0.01 + 0.05 * m->goal_speed_ref;
+    if (err < deadzone) err = 0;
+    const double height = exp(-40 * (err * err));
+    tx = seq[4 * t1]; ty = seq[4 * t1 + 1]; tz = seq[4 * t1 + 2];
+    const double fd = fmin(norm3d(lf0 - tx, lf1 - ty, lf2 - tz), norm3d(rf0 - tx, rf1 - ty, rf2 - tz));
+    const double hit = reached ? exp(-fd / 0.25) : 0.0;
+    const double mpx = (seq[4 * t1] + seq[4 * t2]) / 2, mpy = (seq[4 * t1 + 1] + seq[4 * t2 + 1]) / 2;
+    const double rx = rp0 - mpx, ry = rp1 - mpy;
+    const double progress = exp(-sqrt(rx * rx + ry * ry) / 2);
+    const double step_r = 0.8 * hit + 0.2 * progress;
+    const double* hp = p.in.head_pos + 3 * (size_t)n;
+    const double hx = hp[0] - rp0, hy = hp[1] - rp1;
+    const double hn = sqrt(hx * hx + hy * hy);
+    const double upper = exp(-10 * (hn * hn));
+    double rew[6];
+    rew[0] = 0.150 * frc;
+    rew[1] = 0.150 * vel;
+    rew[2] = 0.050 * orient;
+    rew[3] = 0.050 * height;
+    rew[4] = 0.450 * step_r;
+    rew[5] = 0.050 * upper;
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      tot += rew[i];
+      p.rew6[6 * (size_t)n + i] = (float)rew[i];
+    }
+    p.reward[n] = (float)tot;
+
+    // ---- done
+    const double foot_z = fmin(lf2, rf2);
+    p.done[n] = (uint8_t)(((rp2 - foot_z) < 0.6) || p.in.bad[n]);
+
+    // ---- get_obs (root part; motor columns are filled cooperatively below)
+    const double* qpos = p.in.qpos + (size_t)n * nq;
+    const double* qvel = p.in.qvel + (size_t)n * nv;
+    double bq[4] = {qpos[3], qpos[4], qpos[5], qpos[6]};
+    double Rb[3][3];
+    quat2mat(bq, Rb);
+    const double cy = sqrt(Rb[0][0] * Rb[0][0] + Rb[1][0] * Rb[1][0]);
+    double roll, pitch;
+    if (cy > 4.0 * 2.220446049250313e-16) {
+      roll = atan2(Rb[2][1], Rb[2][2]);
+      pitch = atan2(-Rb[2][0], cy);
+    } else {
+      roll = atan2(-Rb[1][2], Rb[1][1]);
+      pitch = atan2(-Rb[2][0], cy);
+    }
+    const double ci = cos(roll / 2.0), si = sin(roll / 2.0), cj = cos(pitch / 2.0), sj = sin(pitch / 2.0);
+    double* o = s_obs + (size_t)tid * n_obs;
+    o[0] = ci * cj;
+    o[1] = si * cj;
+    o[2] = ci * sj;
+    o[3] = -(si * sj);
+    o[4] = qvel[3]; o[5] = qvel[4]; o[6] = qvel[5];
+    const double ang = 2 * PI * phase / (double)period;
+    o[7 + 2 * nu] = sin(ang);
+    o[8 + 2 * nu] = cos(ang);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[9 + 2 * nu + i] = goal[i];
+  }
+  // motor position / velocity columns: dense [N,nu] streams, one element per lane
+  const int rows = min(THREADS, p.N - n0);
+  for (int e = tid; e < rows * nu; e += THREADS) {
+    const int r = e / nu, i = e - r * nu;
+    const double g = m->gear[i];
+    s_obs[(size_t)r * n_obs + 7 + i] = p.in.act_len[(size_t)n0 * nu + e] / g;
+    s_obs[(size_t)r * n_obs + 7 + nu + i] = p.in.act_vel[(size_t)n0 * nu + e] / g;
+  }
+  __syncthreads();
+  for (int e = tid; e < rows * n_obs; e += THREADS) {
+    if (OBS64)
+      static_cast<double*>(p.obs)[(size_t)n0 * n_obs + e] = s_obs[e];
+    else
+      static_cast<float*>(p.obs)[(size_t)n0 * n_obs + e] = (float)s_obs[e];
+  }
+}
+
+__global__ void pd_target_kernel(const A3Dev* __restrict__ m, long total, const float* __restrict__ action,
+                                 double* __restrict__ target) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int nu = m->nu;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
+    target[e] = (double)action[e] + m->motor_offset[e % nu];
+}
+
+__global__ void pd_torque_kernel(const A3Dev* __restrict__ m, long total, const double* __restrict__ kp,
+                                 const double* __restrict__ kd, const double* __restrict__ target,
+                                 const double* __restrict__ act_len, const double* __restrict__ act_vel,
+                                 double* __restrict__ tau) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int nu = m->nu;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int i = (int)(e % nu);
+    const double g = m->gear[i];
+    const double q = act_len[e] / g, qd = act_vel[e] / g;
+    const double perror = target[e] - q, verror = 0.0 - qd;
+    tau[e] = (kp[i] * perror + kd[i] * verror) / g;
+  }
+}
+
+inline int blocks_for(long n, int t) {
+  long b = (n + t - 1) / t;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+}  // namespace
+
+extern "C" int oly_a3_configure(oly_ctx* ctx, const oly_a3_model* m) {
+  if (!ctx || !m) return OLY_EINVAL;
+  if (m->nu <= 0 || m->nu > 16 || m->nq < 7 || m->nv < 6 || m->period <= 0 || m->period > OLY_MAX_PERIOD ||
+      !m->clock_lut || !m->motor_offset || !m->gear)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_configure: bad model (nu=%d period=%d)", m->nu, m->period);
+  A3Dev& h = ctx->a3_host;
+  memset(&h, 0, sizeof(h));
+  h.nq = m->nq; h.nv = m->nv; h.nu = m->nu; h.period = m->period; h.delay_frames = m->delay_frames;
+  h.n_obs = 7 + 2 * m->nu + 10;
+  h.target_radius = m->target_radius; h.mass = m->mass; h.goal_height_ref = m->goal_height_ref;
+  h.goal_speed_ref = m->goal_speed_ref;
+  memcpy(h.clock_lut, m->clock_lut, sizeof(double) * 4 * m->period);
+  for (int i = 0; i < m->nu; ++i) {
+    h.motor_offset[i] = m->motor_offset[i];
+    h.gear[i] = m->gear[i];
+    if (m->gear[i] == 0.0) OLY_FAIL(ctx, OLY_ERANGE, "oly_a3_configure: gear[%d] is zero", i);
+  }
+  OLY_HIP(ctx, hipSetDevice(ctx->device));
+  OLY_HIP(ctx, hipMemcpy(ctx->a3_dev, &h, sizeof(h), hipMemcpyHostToDevice));
+  ctx->a3_ok = true;
+  return OLY_OK;
+}
+
+extern "C" int oly_a3_step(oly_ctx* ctx, int N, const oly_a3_inputs* in, const oly_a3_state* st, void* obs,
+                           float* rew6, float* reward, uint8_t* done, int out_flags, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_step before oly_a3_configure");
+  if (N < 0 || !in || !st) OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_step: bad argument");
+  if (N == 0) return OLY_OK;
+  const void* req[] = {in->qpos, in->qvel, in->act_len, in->act_vel, in->lf_pos, in->rf_pos, in->lf_vel,
+                       in->rf_vel, in->root_pos, in->root_quat, in->head_pos, in->grf_l, in->grf_r,
+                       in->min_z, in->n_r, in->n_l, in->bad, st->phase, st->t1, st->t2,
+                       st->reached_frames, st->target_reached, st->mode, st->seq_len, st->sequence,
+                       st->goal, obs, rew6, reward, done};
+  for (const void* q : req)
+    if (!q) OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_step: NULL pointer in inputs/state/outputs");
+  A3Args a;
+  a.md = ctx->a3_dev; a.N = N; a.in = *in; a.st = *st; a.obs = obs; a.rew6 = rew6; a.reward = reward;
+  a.done = done;
+  const size_t lds = sizeof(double) * THREADS * ctx->a3_host.n_obs;
+  dim3 grid((N + THREADS - 1) / THREADS), block(THREADS);
+  if (out_flags & OLY_OUT_OBS_F64)
+    hipLaunchKernelGGL(a3_step_kernel<true>, grid, block, lds, oly_s(stream), a);
+  else
+    hipLaunchKernelGGL(a3_step_kernel<false>, grid, block, lds, oly_s(stream), a);
+  OLY_LAUNCH_CHECK(ctx, "a3_step_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_a3_pd_target(oly_ctx* ctx, int N, const float* action, double* target,
+                                oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_pd_target before oly_a3_configure");
+  if (N < 0 || (N > 0 && (!action || !target))) OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_pd_target: bad argument");
+  if (N == 0) return OLY_OK;
+  const long total = (long)N * ctx->a3_host.nu;
+  hipLaunchKernelGGL(pd_target_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, oly_s(stream), ctx->a3_dev,
+                     total, action, target);
+  OLY_LAUNCH_CHECK(ctx, "pd_target_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_a3_pd_torque(oly_ctx* ctx, int N, const double* kp, const double* kd,
+                                const double* target, const double* act_len, const double* act_vel,
+                                double* tau, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_pd_torque before oly_a3_configure");
+  if (N < 0 || !kp || !kd || (N > 0 && (!target || !act_len || !act_vel || !tau)))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_pd_torque: bad argument");
+  if (N == 0) return OLY_OK;
+  const long total = (long)N * ctx->a3_host.nu;
+  hipLaunchKernelGGL(pd_torque_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, oly_s(stream), ctx->a3_dev,
+                     total, kp, kd, target, act_len, act_vel, tau);
+  OLY_LAUNCH_CHECK(ctx, "pd_torque_kernel");
+  return OLY_OK;
+}

@@ -1,0 +1,144 @@
+// K3: foot-contact reduction for the RL robots.
+//   get_{r,l}foot_floor_contacts   mujoco_robot_interface.py:245-273  (floor must be geom1)
+//   get_{r,l}foot_grf              :275-297  (sum of ||force6||_2 in contact order)
+//   check_bad_collisions           :393-399
+//   contact point of _calc_height_reward   tasks/rewards.py:29-33
+//
+// Layout: SLOTS = 16 lanes (one DPP row of the 64-wide wave) per environment, one lane per
+// contact slot, 4 environments per wave.  Each lane loads its own geom pair and force6 vector:
+// a wave reads 4 x (64 + 64 + 768 + 128) contiguous bytes, fully coalesced.  The per-env
+// reductions run inside the 16-lane group with wave shuffles: counts and index lists by ballot
+// + popcount (bit-exact), the force sum as an IN-ORDER serial chain over the group (same
+// rounding as the reference's python loop), the minimum by a shuffle tree.
+// Bound: HBM, 4 + C*(4+4+48+8) B read per env (1028 B at C = 16).
+#include "oly_common.h"
+
+namespace {
+constexpr int THREADS = 256;
+constexpr int SLOTS = 16;
+
+__global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, int C,
+                                                          const int* __restrict__ ncon,
+                                                          const int* __restrict__ geom1,
+                                                          const int* __restrict__ geom2,
+                                                          const double* __restrict__ force6,
+                                                          const double* __restrict__ pos_z,
+                                                          int* __restrict__ n_r, int* __restrict__ n_l,
+                                                          int* __restrict__ idx_r, int* __restrict__ idx_l,
+                                                          double* __restrict__ grf_r,
+                                                          double* __restrict__ grf_l,
+                                                          double* __restrict__ min_z,
+                                                          uint8_t* __restrict__ bad) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane & (SLOTS - 1);
+  const int grp = lane / SLOTS;  // env within the wave
+  const long wave = ((long)blockIdx.x * THREADS + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * THREADS) >> 6;
+  const int passes = (C + SLOTS - 1) / SLOTS;
+  for (long base = wave * 4; base < N; base += nwaves * 4) {
+    const long n = base + grp;
+    const bool env_ok = n < N;
+    const int nc = env_ok ? min(max(ncon[n], 0), C) : 0;
+    int cnt_r = 0, cnt_l = 0;
+    double sum_r = 0.0, sum_l = 0.0, mz = 0.0;
+    bool have = false;
+    for (int ps = 0; ps < passes; ++ps) {
+      const int i = ps * SLOTS + slot;
+      bool is_r = false, is_l = false;
+      double nrm = 0.0, pz = 0.0;
+      if (env_ok && i < nc) {
+        const size_t e = (size_t)n * C + i;
+        const int g1 = geom1[e], g2 = geom2[e];
+        if (g1 >= 0 && g1 < cd.ngeom && g2 >= 0 && g2 < cd.ngeom) {
+          const int b1 = cd.geom_bodyid[g1], b2 = cd.geom_bodyid[g2];
+          is_r = (b1 == cd.floor_body) && (b2 == cd.rfoot_body);
+          is_l = (b1 == cd.floor_body) && (b2 == cd.lfoot_body);
+        }
+        if (is_r || is_l) {
+          const double* f = force6 + e * 6;
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s += f[k] * f[k];
+          nrm = sqrt(s);
+          pz = pos_z[e];
+        }
+      }
+      // ballots over the whole wave, then this env's 16-bit field
+      const unsigned long long br = __ballot(is_r), bl = __ballot(is_l);
+      const unsigned mr = (unsigned)((br >> (grp * SLOTS)) & 0xffffu);
+      const unsigned ml = (unsigned)((bl >> (grp * SLOTS)) & 0xffffu);
+      const unsigned below = (1u << slot) - 1u;
+      if (is_r && idx_r) idx_r[(size_t)n * C + cnt_r + __popc(mr & below)] = i;
+      if (is_l && idx_l) idx_l[(size_t)n * C + cnt_l + __popc(ml & below)] = i;
+      cnt_r += __popc(mr);
+      cnt_l += __popc(ml);
+      // in-order sums: walk the 16 slots of the group, every lane of the group ends up with
+      // the same chain ((0 + n0) + n1) + ... as the reference's loop
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) {
+        const double vk = __shfl(nrm, grp * SLOTS + k, 64);
+        if ((mr >> k) & 1u) sum_r += vk;
+        if ((ml >> k) & 1u) sum_l += vk;
+        const double zk = __shfl(pz, grp * SLOTS + k, 64);
+        if (((mr | ml) >> k) & 1u) {
+          if (!have || zk < mz) mz = zk;
+          have = true;
+        }
+      }
+    }
+    if (env_ok) {
+      // -1 padding of the index lists
+      for (int i = slot; i < C; i += SLOTS) {
+        if (idx_r && i >= cnt_r) idx_r[(size_t)n * C + i] = -1;
+        if (idx_l && i >= cnt_l) idx_l[(size_t)n * C + i] = -1;
+      }
+      if (slot == 0) {
+        n_r[n] = cnt_r;
+        n_l[n] = cnt_l;
+        grf_r[n] = sum_r;
+        grf_l[n] = sum_l;
+        min_z[n] = have ? mz : 0.0;
+        bad[n] = (uint8_t)((cnt_r + cnt_l) != nc);
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int oly_contact_configure(oly_ctx* ctx, int ngeom, const int32_t* geom_bodyid_host,
+                                     int floor_body, int rfoot_body, int lfoot_body) {
+  if (!ctx) return OLY_EINVAL;
+  if (ngeom <= 0 || !geom_bodyid_host) OLY_FAIL(ctx, OLY_EINVAL, "oly_contact_configure: bad argument");
+  OLY_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->contact.geom_bodyid) { (void)hipFree(ctx->contact.geom_bodyid); ctx->contact.geom_bodyid = nullptr; }
+  ctx->contact_ok = false;
+  if (hipMalloc(&ctx->contact.geom_bodyid, sizeof(int) * ngeom) != hipSuccess)
+    OLY_FAIL(ctx, OLY_ENOMEM, "oly_contact_configure: hipMalloc failed");
+  OLY_HIP(ctx, hipMemcpy(ctx->contact.geom_bodyid, geom_bodyid_host, sizeof(int) * ngeom,
+                         hipMemcpyHostToDevice));
+  ctx->contact.ngeom = ngeom; ctx->contact.floor_body = floor_body;
+  ctx->contact.rfoot_body = rfoot_body; ctx->contact.lfoot_body = lfoot_body;
+  ctx->contact_ok = true;
+  return OLY_OK;
+}
+
+extern "C" int oly_contact_reduce(oly_ctx* ctx, int N, int C, const int32_t* ncon, const int32_t* geom1,
+                                  const int32_t* geom2, const double* force6, const double* pos_z,
+                                  int32_t* n_r, int32_t* n_l, int32_t* idx_r, int32_t* idx_l,
+                                  double* grf_r, double* grf_l, double* min_z, uint8_t* bad,
+                                  oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->contact_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_contact_reduce before oly_contact_configure");
+  if (N < 0 || C <= 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_contact_reduce: bad N or C");
+  if (N == 0) return OLY_OK;
+  if (!ncon || !geom1 || !geom2 || !force6 || !pos_z || !n_r || !n_l || !grf_r || !grf_l || !min_z || !bad)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_contact_reduce: NULL pointer");
+  long waves = ((long)N + 3) / 4;
+  long blocks = (waves * 64 + THREADS - 1) / THREADS;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(contact_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->contact,
+                     N, C, ncon, geom1, geom2, force6, pos_z, n_r, n_l, idx_r, idx_l, grf_r, grf_l, min_z,
+                     bad);
+  OLY_LAUNCH_CHECK(ctx, "contact_kernel");
+  return OLY_OK;
+}

@@ -1,0 +1,90 @@
+// K8: discriminator-reward pre-amble and epilogue (the MLP GEMMs stay in PyTorch-ROCm).
+//   oly_disc_standardize  prepare_discrim_inputs gail_TRPO.py:297-313 + Standardizer.forward
+//                         imitation_lib/utils/networks.py:68-74
+//   oly_disc_reparam      reparameterize networks.py:21-24
+//   oly_disc_reward       GAIL.make_discrim_reward gail_TRPO.py:320-327
+// Elementwise, HBM-bound: 8 B/element (standardise), 16 B (reparam), 8 B (reward).
+#include "oly_common.h"
+
+namespace {
+constexpr int THREADS = 256;
+
+__global__ __launch_bounds__(THREADS) void standardize_kernel(int B, int Dx, int D,
+                                                              const float* __restrict__ x,
+                                                              const int* __restrict__ mask,
+                                                              const double* __restrict__ mean,
+                                                              const double* __restrict__ sd,
+                                                              float* __restrict__ out) {
+  const long total = (long)B * D;
+  const long stride = (long)gridDim.x * THREADS;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += stride) {
+    const int b = (int)(e / D), j = (int)(e - (long)b * D);
+    const int c = mask ? mask[j] : j;
+    // float32 batch minus float64 mean, over float64 std, narrowed by .float()
+    out[e] = (float)(((double)x[(size_t)b * Dx + c] - mean[j]) / sd[j]);
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void reparam_kernel(long n, const float* __restrict__ mu,
+                                                          const float* __restrict__ logvar,
+                                                          const float* __restrict__ eps,
+                                                          float* __restrict__ z) {
+  const long stride = (long)gridDim.x * THREADS;
+  for (long i = (long)blockIdx.x * THREADS + threadIdx.x; i < n; i += stride)
+    z[i] = mu[i] + expf(logvar[i] / 2.0f) * eps[i];
+}
+
+__global__ __launch_bounds__(THREADS) void reward_kernel(long n, const float* __restrict__ d,
+                                                         float* __restrict__ r) {
+  const long stride = (long)gridDim.x * THREADS;
+  for (long i = (long)blockIdx.x * THREADS + threadIdx.x; i < n; i += stride) {
+    // numpy evaluates every step in float32; exp/log are taken in fp64 and narrowed so that the
+    // fp32 intermediate is the correctly rounded one (the 1 - p cancellation amplifies any error).
+    const float e = (float)exp(-(double)d[i]);
+    const float p = 1.0f / (1.0f + e);
+    const float q = 1.0f - p + 1e-8f;
+    r[i] = -(float)log((double)q);
+  }
+}
+
+inline int blocks_for(long n) {
+  long b = (n + THREADS - 1) / THREADS;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+}  // namespace
+
+extern "C" int oly_disc_standardize(oly_ctx* ctx, int B, int Dx, int D, const float* x,
+                                    const int32_t* mask, const double* mean, const double* sd,
+                                    float* out, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (B < 0 || Dx <= 0 || D <= 0 || (!mask && D != Dx) || !mean || !sd || (B > 0 && (!x || !out)))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_disc_standardize: bad argument");
+  if (B == 0) return OLY_OK;
+  hipLaunchKernelGGL(standardize_kernel, dim3(blocks_for((long)B * D)), dim3(THREADS), 0, oly_s(stream),
+                     B, Dx, D, x, mask, mean, sd, out);
+  OLY_LAUNCH_CHECK(ctx, "standardize_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_disc_reparam(oly_ctx* ctx, int64_t n, const float* mu, const float* logvar,
+                                const float* eps, float* z, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (n < 0 || (n > 0 && (!mu || !logvar || !eps || !z)))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_disc_reparam: bad argument");
+  if (n == 0) return OLY_OK;
+  hipLaunchKernelGGL(reparam_kernel, dim3(blocks_for(n)), dim3(THREADS), 0, oly_s(stream), (long)n, mu,
+                     logvar, eps, z);
+  OLY_LAUNCH_CHECK(ctx, "reparam_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_disc_reward(oly_ctx* ctx, int64_t B, const float* logits, float* reward,
+                               oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (B < 0 || (B > 0 && (!logits || !reward))) OLY_FAIL(ctx, OLY_EINVAL, "oly_disc_reward: bad argument");
+  if (B == 0) return OLY_OK;
+  hipLaunchKernelGGL(reward_kernel, dim3(blocks_for(B)), dim3(THREADS), 0, oly_s(stream), (long)B, logits,
+                     reward);
+  OLY_LAUNCH_CHECK(ctx, "reward_kernel");
+  return OLY_OK;
+}

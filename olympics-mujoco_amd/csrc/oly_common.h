@@ -1,0 +1,94 @@
+// Internal definitions shared by the HIP translation units of libolympic_hip.so (gfx950).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/olympic_hip.h"
+
+// ---------------------------------------------------------------- device-side tables
+// One copy per ctx in device memory; kernels receive a pointer and read the fields with
+// wave-uniform (scalar) loads, or stage the per-column tables in LDS.
+
+struct IlDev {
+  int nq, nv, n_pos, n_vel, n_drop, n_grf, n_act, nu, n_obs, n_fall;
+  int reward_type, reward_idx, use_absorbing, pad0;
+  double target_velocity;
+  // created-observation column c reads staged row element src[c]; the staged row is
+  // [qpos (nq) | qvel (nv) | grf (n_grf)] and grf columns are divided by 1000.
+  short src[OLY_MAX_OBS];
+  int fall_idx[OLY_MAX_FALL];
+  double fall_lo[OLY_MAX_FALL], fall_hi[OLY_MAX_FALL];
+  short ctrl_src[OLY_MAX_ACT];  // actuator j <- action slot, or -1
+  double act_mean[OLY_MAX_ACT], act_delta[OLY_MAX_ACT], ctrl_lo[OLY_MAX_ACT], ctrl_hi[OLY_MAX_ACT];
+};
+
+struct A3Dev {
+  int nq, nv, nu, period, delay_frames, n_obs, pad0, pad1;
+  double target_radius, mass, goal_height_ref, goal_speed_ref;
+  double clock_lut[4 * OLY_MAX_PERIOD];
+  double motor_offset[16], gear[16];
+};
+
+struct ContactDev {
+  int ngeom, floor_body, rfoot_body, lfoot_body;
+  int* geom_bodyid;  // device [ngeom]
+};
+
+struct TrajDev {
+  int n_keys, n_traj, len, pad;
+  double* rows;  // device [n_traj, len, n_keys] (sample-major copy of the reference table)
+};
+
+#define OLY_STATS_MAX_BLOCKS 1024
+
+struct oly_ctx {
+  int device;
+  char err[512];
+  IlDev* il_dev;
+  IlDev il_host;
+  bool il_ok;
+  A3Dev* a3_dev;
+  A3Dev a3_host;
+  bool a3_ok;
+  ContactDev contact;
+  bool contact_ok;
+  TrajDev traj;
+  bool traj_ok;
+  double* stats_ws;  // device [OLY_STATS_MAX_BLOCKS * 2 * OLY_MAX_OBS... ] partial sums
+  size_t stats_ws_bytes;
+  int num_cu;
+};
+
+#define OLY_FAIL(ctx, code, ...)                                \
+  do {                                                          \
+    if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \
+    return (code);                                              \
+  } while (0)
+
+#define OLY_HIP(ctx, expr)                                                             \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      OLY_FAIL(ctx, OLY_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+               __FILE__, __LINE__);                                                    \
+  } while (0)
+
+#define OLY_LAUNCH_CHECK(ctx, what)                                                           \
+  do {                                                                                        \
+    hipError_t e__ = hipGetLastError();                                                       \
+    if (e__ != hipSuccess)                                                                    \
+      OLY_FAIL(ctx, OLY_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e__));       \
+  } while (0)
+
+static inline hipStream_t oly_s(oly_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// 64-wide wavefront helpers (gfx950).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}

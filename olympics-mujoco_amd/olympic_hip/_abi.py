@@ -63,7 +63,7 @@ SIGNATURES = {
     "oly_destroy": (None, [vp]),
     "oly_il_configure": (C.c_int, [vp, C.POINTER(IlModel)]),
     "oly_il_obs_dim": (C.c_int, [vp]),
-    "oly_il_step": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+    "oly_il_step": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                               C.c_int, vp]),
     "oly_traj_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "oly_traj_reset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),

@@ -1,0 +1,309 @@
+"""Typed torch front-end over the C ABI: one method per entry point of
+include/olympic_hip.h.  Tensors are validated (device, dtype, contiguity, shape) on the
+host before any kernel is launched - a wrong shape must never reach the GPU.  PyTorch is
+only the allocator/stream provider here; every computation is a HIP kernel of
+libolympic_hip.so running on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._ffi import Context, OlyError, ptr
+
+
+def _req(t, name, shape, dtype, device, optional=False):
+    if t is None:
+        if optional:
+            return None
+        raise OlyError(f"{name}: required tensor is None")
+    if not isinstance(t, torch.Tensor):
+        raise OlyError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if t.device != device:
+        raise OlyError(f"{name}: tensor on {t.device}, engine on {device}")
+    if t.dtype != dtype:
+        raise OlyError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise OlyError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if not t.is_contiguous():
+        raise OlyError(f"{name}: tensor must be contiguous")
+    return t
+
+
+class Engine:
+    """HIP hot-path engine bound to one device."""
+
+    def __init__(self, device=None):
+        self.ctx = Context(device)
+        self.device = self.ctx.device
+        self.il_spec = None
+        self.a3_spec = None
+        self.traj_shape = None
+        self.contact_ok = False
+
+    # -------------------------------------------------------------- helpers
+    def _new(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _s(self):
+        return self.ctx.stream()
+
+    # -------------------------------------------------------------- K1 / K5
+    def il_configure(self, spec):
+        self.ctx.call("oly_il_configure", C.byref(spec.to_c()))
+        self.il_spec = spec
+        return self
+
+    def il_step(self, qpos, qvel, action, prev_in, prev_out=None, grf_mean=None, out=None,
+                obs_f64=False, ctrl_f64=False, want_fall_code=True, want_ctrl=True):
+        """qpos [T,N,nq] f64, qvel [T,N,nv] f64, action [T,N,n_act] f32 (or None).
+        Returns dict(obs, reward, absorbing, fall_code, ctrl, prev)."""
+        sp = self.il_spec
+        if sp is None:
+            raise OlyError("il_step before il_configure")
+        if qpos.dim() != 3:
+            raise OlyError(f"qpos: expected [T,N,nq], got {tuple(qpos.shape)}")
+        T, N = int(qpos.shape[0]), int(qpos.shape[1])
+        dv = self.device
+        _req(qpos, "qpos", (T, N, sp.nq), torch.float64, dv)
+        _req(qvel, "qvel", (T, N, sp.nv), torch.float64, dv)
+        want_ctrl = want_ctrl and action is not None
+        _req(action, "action", (T, N, sp.n_act), torch.float32, dv, optional=True)
+        _req(grf_mean, "grf_mean", (T, N, sp.n_grf), torch.float64, dv, optional=sp.n_grf == 0)
+        _req(prev_in, "prev_in", (N,), torch.float64, dv)
+        if prev_out is None:
+            prev_out = prev_in if T == 1 else self._new((N,), torch.float64)
+        _req(prev_out, "prev_out", (N,), torch.float64, dv)
+        if T > 1 and prev_out.data_ptr() == prev_in.data_ptr():
+            raise OlyError("prev_out must not alias prev_in when T > 1")
+        out = out or {}
+        od = torch.float64 if obs_f64 else torch.float32
+        cd = torch.float64 if ctrl_f64 else torch.float32
+        obs = _req(out.get("obs", self._new((T, N, sp.n_obs), od)), "obs", (T, N, sp.n_obs), od, dv)
+        reward = _req(out.get("reward", self._new((T, N), torch.float32)), "reward", (T, N), torch.float32, dv)
+        absorbing = _req(out.get("absorbing", self._new((T, N), torch.uint8)), "absorbing", (T, N), torch.uint8, dv)
+        code = None
+        if want_fall_code:
+            code = _req(out.get("fall_code", self._new((T, N), torch.uint8)), "fall_code", (T, N), torch.uint8, dv)
+        ctrl = None
+        if want_ctrl:
+            ctrl = _req(out.get("ctrl", self._new((T, N, sp.nu), cd)), "ctrl", (T, N, sp.nu), cd, dv)
+        flags = (_abi.OUT_OBS_F64 if obs_f64 else 0) | (_abi.OUT_CTRL_F64 if ctrl_f64 else 0)
+        self.ctx.call("oly_il_step", T, N, ptr(qpos), ptr(qvel), ptr(action), ptr(grf_mean), ptr(prev_in),
+                      ptr(prev_out), ptr(obs), ptr(reward), ptr(absorbing), ptr(code), ptr(ctrl), flags,
+                      self._s())
+        return dict(obs=obs, reward=reward, absorbing=absorbing, fall_code=code, ctrl=ctrl, prev=prev_out)
+
+    # -------------------------------------------------------------- K4
+    def traj_upload(self, table):
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        if table.ndim != 3:
+            raise OlyError(f"trajectory table must be [n_keys,n_traj,len], got {table.shape}")
+        K, J, L = table.shape
+        self.ctx.call("oly_traj_upload", K, J, L, ptr(table))
+        self.traj_shape = (K, J, L)
+        return self
+
+    def traj_reset(self, traj_no, step, cur_traj=None, cur_step=None, origin=None, sample=None):
+        if self.traj_shape is None:
+            raise OlyError("traj_reset before traj_upload")
+        K = self.traj_shape[0]
+        N = int(traj_no.shape[0])
+        dv = self.device
+        _req(traj_no, "traj_no", (N,), torch.int32, dv)
+        _req(step, "step", (N,), torch.int32, dv)
+        cur_traj = _req(cur_traj if cur_traj is not None else self._new((N,), torch.int32), "cur_traj", (N,), torch.int32, dv)
+        cur_step = _req(cur_step if cur_step is not None else self._new((N,), torch.int32), "cur_step", (N,), torch.int32, dv)
+        origin = _req(origin if origin is not None else self._new((N, 2), torch.float64), "origin", (N, 2), torch.float64, dv)
+        sample = _req(sample if sample is not None else self._new((N, K), torch.float64), "sample", (N, K), torch.float64, dv)
+        self.ctx.call("oly_traj_reset", N, ptr(traj_no), ptr(step), ptr(cur_traj), ptr(cur_step), ptr(origin),
+                      ptr(sample), self._s())
+        return cur_traj, cur_step, origin, sample
+
+    def traj_next(self, cur_traj, cur_step, origin, sample, active=None, at_end=None):
+        if self.traj_shape is None:
+            raise OlyError("traj_next before traj_upload")
+        K = self.traj_shape[0]
+        N = int(cur_traj.shape[0])
+        dv = self.device
+        _req(cur_traj, "cur_traj", (N,), torch.int32, dv)
+        _req(cur_step, "cur_step", (N,), torch.int32, dv)
+        _req(origin, "origin", (N, 2), torch.float64, dv)
+        _req(sample, "sample", (N, K), torch.float64, dv)
+        _req(active, "active", (N,), torch.uint8, dv, optional=True)
+        at_end = _req(at_end if at_end is not None else self._new((N,), torch.uint8), "at_end", (N,), torch.uint8, dv)
+        self.ctx.call("oly_traj_next", N, ptr(active), ptr(cur_traj), ptr(cur_step), ptr(origin), ptr(sample),
+                      ptr(at_end), self._s())
+        return at_end
+
+    def traj_euler(self, n_qpos, dt, curr_qpos, sample):
+        if self.traj_shape is None:
+            raise OlyError("traj_euler before traj_upload")
+        K = self.traj_shape[0]
+        N = int(sample.shape[0])
+        _req(curr_qpos, "curr_qpos", (N, n_qpos), torch.float64, self.device)
+        _req(sample, "sample", (N, K), torch.float64, self.device)
+        self.ctx.call("oly_traj_euler", N, int(n_qpos), C.c_double(dt), ptr(curr_qpos), ptr(sample), self._s())
+        return sample
+
+    # -------------------------------------------------------------- K3
+    def contact_configure(self, geom_bodyid, floor_body, rfoot_body, lfoot_body):
+        gb = np.ascontiguousarray(geom_bodyid, dtype=np.int32)
+        self.ctx.call("oly_contact_configure", len(gb), ptr(gb), int(floor_body), int(rfoot_body), int(lfoot_body))
+        self.contact_ok = True
+        return self
+
+    def contact_reduce(self, ncon, geom1, geom2, force6, pos_z, want_idx=True):
+        if not self.contact_ok:
+            raise OlyError("contact_reduce before contact_configure")
+        dv = self.device
+        if geom1.dim() != 2:
+            raise OlyError(f"geom1: expected [N,C], got {tuple(geom1.shape)}")
+        N, Cc = int(geom1.shape[0]), int(geom1.shape[1])
+        _req(ncon, "ncon", (N,), torch.int32, dv)
+        _req(geom1, "geom1", (N, Cc), torch.int32, dv)
+        _req(geom2, "geom2", (N, Cc), torch.int32, dv)
+        _req(force6, "force6", (N, Cc, 6), torch.float64, dv)
+        _req(pos_z, "pos_z", (N, Cc), torch.float64, dv)
+        o = dict(n_r=self._new((N,), torch.int32), n_l=self._new((N,), torch.int32),
+                 idx_r=self._new((N, Cc), torch.int32) if want_idx else None,
+                 idx_l=self._new((N, Cc), torch.int32) if want_idx else None,
+                 grf_r=self._new((N,), torch.float64), grf_l=self._new((N,), torch.float64),
+                 min_z=self._new((N,), torch.float64), bad=self._new((N,), torch.uint8))
+        self.ctx.call("oly_contact_reduce", N, Cc, ptr(ncon), ptr(geom1), ptr(geom2), ptr(force6), ptr(pos_z),
+                      ptr(o["n_r"]), ptr(o["n_l"]), ptr(o["idx_r"]), ptr(o["idx_l"]), ptr(o["grf_r"]),
+                      ptr(o["grf_l"]), ptr(o["min_z"]), ptr(o["bad"]), self._s())
+        return o
+
+    # -------------------------------------------------------------- K2
+    _A3_IN = dict(qpos=("nq", torch.float64), qvel=("nv", torch.float64), act_len=("nu", torch.float64),
+                  act_vel=("nu", torch.float64), lf_pos=(3, torch.float64), rf_pos=(3, torch.float64),
+                  lf_vel=(3, torch.float64), rf_vel=(3, torch.float64), root_pos=(3, torch.float64),
+                  root_quat=(4, torch.float64), head_pos=(3, torch.float64), grf_l=(None, torch.float64),
+                  grf_r=(None, torch.float64), min_z=(None, torch.float64), n_r=(None, torch.int32),
+                  n_l=(None, torch.int32), bad=(None, torch.uint8))
+    _A3_ST = dict(phase=(None, torch.int32), t1=(None, torch.int32), t2=(None, torch.int32),
+                  reached_frames=(None, torch.int32), target_reached=(None, torch.uint8),
+                  mode=(None, torch.int32), seq_len=(None, torch.int32),
+                  sequence=((_abi.OLY_MAX_SEQ, 4), torch.float64), goal=(8, torch.float64))
+
+    def a3_configure(self, spec, clock_lut):
+        lut = np.ascontiguousarray(clock_lut, dtype=np.float64)
+        self.ctx.call("oly_a3_configure", C.byref(spec.to_c(lut)))
+        self.a3_spec = spec
+        return self
+
+    def _a3_struct(self, cls, table, tensors, N):
+        sp = self.a3_spec
+        st = cls()
+        for name, (w, dt) in table.items():
+            if isinstance(w, str):
+                w = getattr(sp, w)
+            shape = (N,) if w is None else ((N,) + tuple(w) if isinstance(w, tuple) else (N, w))
+            t = _req(tensors.get(name), name, shape, dt, self.device)
+            setattr(st, name, t.data_ptr())
+        return st
+
+    def a3_step(self, inputs, state, obs_f64=False, out=None):
+        sp = self.a3_spec
+        if sp is None:
+            raise OlyError("a3_step before a3_configure")
+        N = int(state["phase"].shape[0])
+        cin = self._a3_struct(_abi.A3Inputs, self._A3_IN, inputs, N)
+        cst = self._a3_struct(_abi.A3State, self._A3_ST, state, N)
+        out = out or {}
+        od = torch.float64 if obs_f64 else torch.float32
+        obs = _req(out.get("obs", self._new((N, sp.n_obs), od)), "obs", (N, sp.n_obs), od, self.device)
+        rew6 = _req(out.get("rew6", self._new((N, 6), torch.float32)), "rew6", (N, 6), torch.float32, self.device)
+        reward = _req(out.get("reward", self._new((N,), torch.float32)), "reward", (N,), torch.float32, self.device)
+        done = _req(out.get("done", self._new((N,), torch.uint8)), "done", (N,), torch.uint8, self.device)
+        self.ctx.call("oly_a3_step", N, C.byref(cin), C.byref(cst), ptr(obs), ptr(rew6), ptr(reward), ptr(done),
+                      _abi.OUT_OBS_F64 if obs_f64 else 0, self._s())
+        return dict(obs=obs, rew6=rew6, reward=reward, done=done)
+
+    def a3_pd_target(self, action):
+        sp = self.a3_spec
+        N = int(action.shape[0])
+        _req(action, "action", (N, sp.nu), torch.float32, self.device)
+        target = self._new((N, sp.nu), torch.float64)
+        self.ctx.call("oly_a3_pd_target", N, ptr(action), ptr(target), self._s())
+        return target
+
+    def a3_pd_torque(self, kp, kd, target, act_len, act_vel):
+        sp = self.a3_spec
+        N = int(target.shape[0])
+        for t, nme in ((target, "target"), (act_len, "act_len"), (act_vel, "act_vel")):
+            _req(t, nme, (N, sp.nu), torch.float64, self.device)
+        _req(kp, "kp", (sp.nu,), torch.float64, self.device)
+        _req(kd, "kd", (sp.nu,), torch.float64, self.device)
+        tau = self._new((N, sp.nu), torch.float64)
+        self.ctx.call("oly_a3_pd_torque", N, ptr(kp), ptr(kd), ptr(target), ptr(act_len), ptr(act_vel), ptr(tau),
+                      self._s())
+        return tau
+
+    # -------------------------------------------------------------- K6
+    def return_scan(self, mode, gamma, lam, rew, val, next_val, flags, ret=None, adv=None):
+        if rew.dim() != 2:
+            raise OlyError(f"rew: expected [T,N], got {tuple(rew.shape)}")
+        T, N = int(rew.shape[0]), int(rew.shape[1])
+        dv = self.device
+        _req(rew, "rew", (T, N), torch.float32, dv)
+        _req(val, "val", (T, N), torch.float32, dv)
+        _req(next_val, "next_val", (T, N), torch.float32, dv)
+        _req(flags, "flags", (T, N), torch.uint8, dv)
+        ret = _req(ret if ret is not None else self._new((T, N), torch.float32), "ret", (T, N), torch.float32, dv)
+        adv = _req(adv if adv is not None else self._new((T, N), torch.float32), "adv", (T, N), torch.float32, dv)
+        self.ctx.call("oly_return_scan", int(mode), T, N, C.c_double(gamma), C.c_double(lam), ptr(rew), ptr(val),
+                      ptr(next_val), ptr(flags), ptr(ret), ptr(adv), self._s())
+        return ret, adv
+
+    # -------------------------------------------------------------- K7
+    def adv_stats(self, x, stats3=None):
+        _req(x, "x", x.shape, torch.float32, self.device)
+        stats3 = _req(stats3 if stats3 is not None else self._new((3,), torch.float64), "stats3", (3,), torch.float64, self.device)
+        self.ctx.call("oly_adv_stats", C.c_int64(x.numel()), ptr(x), ptr(stats3), self._s())
+        return stats3
+
+    def adv_normalize(self, x, stats3, ddof, eps):
+        _req(x, "x", x.shape, torch.float32, self.device)
+        _req(stats3, "stats3", (3,), torch.float64, self.device)
+        self.ctx.call("oly_adv_normalize", C.c_int64(x.numel()), ptr(x), ptr(stats3), int(ddof), C.c_double(eps),
+                      self._s())
+        return x
+
+    def col_stats(self, x, colstats=None):
+        if x.dim() != 2:
+            raise OlyError(f"x: expected [B,D], got {tuple(x.shape)}")
+        B, D = int(x.shape[0]), int(x.shape[1])
+        _req(x, "x", (B, D), torch.float32, self.device)
+        acc = colstats is not None
+        colstats = _req(colstats if acc else self._new((3, D), torch.float64), "colstats", (3, D), torch.float64, self.device)
+        self.ctx.call("oly_col_stats", B, D, ptr(x), ptr(colstats), int(acc), self._s())
+        return colstats
+
+    # -------------------------------------------------------------- K8
+    def disc_standardize(self, x, mask, mean, std, out=None):
+        B, Dx = int(x.shape[0]), int(x.shape[1])
+        _req(x, "x", (B, Dx), torch.float32, self.device)
+        D = Dx if mask is None else int(mask.shape[0])
+        _req(mask, "mask", (D,), torch.int32, self.device, optional=True)
+        _req(mean, "mean", (D,), torch.float64, self.device)
+        _req(std, "std", (D,), torch.float64, self.device)
+        out = _req(out if out is not None else self._new((B, D), torch.float32), "out", (B, D), torch.float32, self.device)
+        self.ctx.call("oly_disc_standardize", B, Dx, D, ptr(x), ptr(mask), ptr(mean), ptr(std), ptr(out), self._s())
+        return out
+
+    def disc_reparam(self, mu, logvar, eps, z=None):
+        for t, nme in ((mu, "mu"), (logvar, "logvar"), (eps, "eps")):
+            _req(t, nme, mu.shape, torch.float32, self.device)
+        z = _req(z if z is not None else torch.empty_like(mu), "z", mu.shape, torch.float32, self.device)
+        self.ctx.call("oly_disc_reparam", C.c_int64(mu.numel()), ptr(mu), ptr(logvar), ptr(eps), ptr(z), self._s())
+        return z
+
+    def disc_reward(self, logits, reward=None):
+        _req(logits, "logits", logits.shape, torch.float32, self.device)
+        reward = _req(reward if reward is not None else self._new((logits.numel(),), torch.float32), "reward",
+                      (logits.numel(),), torch.float32, self.device)
+        self.ctx.call("oly_disc_reward", C.c_int64(logits.numel()), ptr(logits), ptr(reward), self._s())
+        return reward

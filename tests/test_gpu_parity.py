@@ -1,0 +1,437 @@
+"""GPU parity: the HIP kernels (through the C ABI) against the CPU oracle on the same seeded
+inputs, against the golden vectors, and - at full BASELINE sizes - through size-independent
+properties.  Bars: integers / flags / indices bit-exact; floating point within the tolerance
+written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+from olympic_hip import _abi, specs
+from helpers import a3_fixture_arrays, h1_rows_from_full, h1_synthetic_block, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from olympic_hip.engine import Engine
+    return Engine(0)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------ K1/K5
+def _run_il(eng, spec, qpos, qvel, action, prev, **kw):
+    eng.il_configure(spec)
+    o = eng.il_step(dev(qpos), dev(qvel), None if action is None else dev(action, torch.float32),
+                    dev(prev, torch.float64), **kw)
+    torch.cuda.synchronize()
+    return {k: (None if v is None else host(v)) for k, v in o.items()}
+
+
+def _cmp_il(o, ref, f64):
+    assert np.array_equal(o["obs"], ref["obs"])                    # pure gather + rounding: bit-exact
+    assert np.array_equal(o["absorbing"], ref["absorbing"])        # bit-exact
+    assert np.array_equal(o["fall_code"], ref["fall_code"])        # bit-exact
+    assert ulp_diff(o["reward"], ref["reward"]).max() <= 1          # device exp vs libm exp, 1 ulp f32
+    assert np.array_equal(o["prev"], ref["prev"])
+    if ref["ctrl"] is not None:
+        assert np.array_equal(o["ctrl"], ref["ctrl"])               # mul/add/clamp in fp64: bit-exact
+
+
+@pytest.mark.parametrize("f64", [False, True])
+def test_h1_golden(eng, golden, oracle, f64):
+    g = golden("h1_step.npz")
+    spec = specs.unitree_h1("walk")
+    qpos, qvel = h1_rows_from_full(spec, g["full_obs"])
+    a = g["action"].astype(np.float32)
+    prev = g["obs"][:, spec.reward_idx].copy()
+    o = _run_il(eng, spec, qpos[None], qvel[None], a[None], prev, obs_f64=f64, ctrl_f64=f64)
+    ref = oracle.il_step(spec, qpos[None], qvel[None], a[None], prev, obs_f64=f64, ctrl_f64=f64)
+    _cmp_il(o, ref, f64)
+    # directly against the reference's outputs
+    exp_obs = g["obs"] if f64 else g["obs"].astype(np.float32)
+    assert np.array_equal(o["obs"][0], exp_obs)
+    assert np.array_equal(o["absorbing"][0].astype(bool), g["fallen"])
+    assert np.array_equal(o["fall_code"][0], g["msg_code"])
+    assert ulp_diff(o["reward"][0], g["reward_walk"].astype(np.float32)).max() <= 1
+
+
+@pytest.mark.parametrize("T,N", [(1, 1), (1, 127), (1, 128), (3, 129), (7, 333), (2, 4096), (5, 1000)])
+def test_h1_vs_oracle_shapes(eng, oracle, T, N):
+    """Ragged tails (R % 128 != 0), single row, T > 1 carry chain."""
+    spec = specs.unitree_h1("walk")
+    qpos, qvel, act = h1_synthetic_block(spec, T, N, seed=T * 1000 + N, fall_frac="wide")
+    prev = np.random.default_rng(5).normal(1.25, 0.5, N)
+    o = _run_il(eng, spec, qpos, qvel, act, prev)
+    ref = oracle.il_step(spec, qpos, qvel, act, prev)
+    _cmp_il(o, ref, False)
+
+
+def test_h1_variants(eng, oracle):
+    qp, qv, act = h1_synthetic_block(specs.unitree_h1("walk"), 2, 300, seed=3, fall_frac="wide")
+    prev = np.linspace(0, 2.5, 300)
+    for spec in (specs.unitree_h1("run"), specs.unitree_h1("walk", use_absorbing_states=False),
+                 specs.unitree_h1("walk", reward_type="x_pos"), specs.unitree_h1("walk", reward_type=None)):
+        o = _run_il(eng, spec, qp, qv, act, prev)
+        ref = oracle.il_step(spec, qp, qv, act, prev)
+        if spec.reward_type == _abi.REWARD_NONE:
+            ref["prev"] = o["prev"]            # untouched by both
+        _cmp_il(o, ref, False)
+    # no action -> no ctrl
+    o = _run_il(eng, specs.unitree_h1("walk"), qp, qv, None, prev)
+    assert o["ctrl"] is None
+
+
+def test_h1_generic_robot_path(eng, oracle):
+    """A spec that is not H1-shaped (arms kept: nq=25, n_obs=48, 19 actions) runs the
+    runtime-dimension kernel."""
+    spec = specs.unitree_h1("walk", disable_arms=False)
+    assert (spec.nq, spec.n_obs, spec.n_act) == (25, 48, 19)
+    rng = np.random.default_rng(9)
+    T, N = 3, 211
+    qpos = rng.uniform(-0.5, 0.5, (T, N, spec.nq))
+    qvel = rng.normal(0, 1, (T, N, spec.nv))
+    act = rng.uniform(-1.3, 1.3, (T, N, spec.n_act)).astype(np.float32)
+    prev = rng.normal(1.25, 0.5, N)
+    o = _run_il(eng, spec, qpos, qvel, act, prev)
+    ref = oracle.il_step(spec, qpos, qvel, act, prev)
+    _cmp_il(o, ref, False)
+
+
+def test_h1_full_size_properties(eng):
+    """BASELINE config 2 size (T=400, N=4096): properties that need no CPU pass."""
+    spec = specs.unitree_h1("walk")
+    eng.il_configure(spec)
+    T, N = 400, 4096
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    qpos = torch.empty((T, N, 17), dtype=torch.float64, device="cuda").uniform_(-0.4, 0.4, generator=g)
+    qvel = torch.empty((T, N, 17), dtype=torch.float64, device="cuda").normal_(0, 1.5, generator=g)
+    act = torch.empty((T, N, 11), dtype=torch.float32, device="cuda").uniform_(-1.2, 1.2, generator=g)
+    prev = torch.full((N,), 1.25, dtype=torch.float64, device="cuda")
+    o = eng.il_step(qpos, qvel, act, prev, obs_f64=True)
+    qa = torch.as_tensor(spec.qpos_adr.astype(np.int64)).cuda()
+    # (1) obs is exactly the permuted input
+    assert torch.equal(o["obs"][..., :15], qpos[..., qa[2:]])
+    assert torch.equal(o["obs"][..., 15:], qvel[..., qa])
+    # (2) flags agree with the thresholds evaluated by torch in fp64
+    ob = o["obs"]
+    pi = np.pi
+    fallen = ((ob[..., 0] < -0.3) | (ob[..., 0] > 0.1) | (ob[..., 1] < -pi / 4.5) | (ob[..., 1] > pi / 12) |
+              (ob[..., 2] < -pi / 12) | (ob[..., 2] > pi / 8) | (ob[..., 3] < -pi / 8) | (ob[..., 3] > pi / 8))
+    assert torch.equal(o["absorbing"].bool(), fallen)
+    assert torch.equal(o["fall_code"] > 0, fallen)
+    # (3) reward chain: reward[t] = exp(-(xvel[t-1]-1.25)^2), reward[0] from prev (=1 here)
+    xv = ob[..., 15]
+    exp_r = torch.exp(-(xv[:-1] - 1.25) ** 2).float()
+    assert (o["reward"][1:] - exp_r).abs().max().item() <= 1.2e-7      # 1 ulp f32 at <= 1.0
+    assert torch.equal(o["reward"][0], torch.ones(N, device="cuda"))
+    assert torch.equal(o["prev"], xv[-1])
+    # (4) ctrl: clamp(a*0.95) scattered; idempotent under the inverse permutation
+    a2c = torch.as_tensor(spec.act_to_ctrl.astype(np.int64)).cuda()
+    exp_c = torch.clamp(act.double() * 0.95, -0.95, 0.95).float()
+    assert torch.equal(o["ctrl"][..., a2c], exp_c)
+    # (5) f32 observation path = rounding of the f64 one
+    o32 = eng.il_step(qpos, qvel, act, prev)
+    assert torch.equal(o32["obs"], ob.float())
+    assert torch.equal(o32["absorbing"], o["absorbing"])
+
+
+def test_il_argument_errors(eng):
+    from olympic_hip._ffi import OlyError
+    spec = specs.unitree_h1("walk")
+    eng.il_configure(spec)
+    q = torch.zeros((2, 8, 17), dtype=torch.float64, device="cuda")
+    p = torch.zeros(8, dtype=torch.float64, device="cuda")
+    with pytest.raises(OlyError):
+        eng.il_step(q, q[..., :16].contiguous(), None, p)            # wrong nv
+    with pytest.raises(OlyError):
+        eng.il_step(q, q, None, p, prev_out=p)                        # aliasing with T > 1
+    with pytest.raises(OlyError):
+        eng.il_step(q.float(), q, None, p)                            # wrong dtype
+    with pytest.raises(OlyError):
+        eng.il_step(q.cpu(), q, None, p)                              # host tensor
+
+
+# --------------------------------------------------------------------------------- K6
+@pytest.mark.parametrize("mode", [_abi.SCAN_RETURN, _abi.SCAN_GAE])
+@pytest.mark.parametrize("T,N", [(1, 1), (5, 3), (400, 257), (33, 4096)])
+def test_scan_vs_oracle(eng, oracle, mode, T, N):
+    rng = np.random.default_rng(T * 7 + N)
+    r = rng.uniform(-0.3, 1, (T, N)).astype(np.float32)
+    v = rng.normal(0, 1, (T, N)).astype(np.float32)
+    vn = rng.normal(0, 1, (T, N)).astype(np.float32)
+    last = rng.uniform(size=(T, N)) < 1 / 30
+    ab = last & (rng.uniform(size=(T, N)) < 0.5)
+    flags = (last * _abi.FLAG_LAST + ab * _abi.FLAG_ABSORBING).astype(np.uint8)
+    ret, adv = eng.return_scan(mode, 0.99, 0.97, dev(r), dev(v), dev(vn), dev(flags))
+    e_ret, e_adv = oracle.return_scan(mode, 0.99, 0.97, r, v, vn, flags)
+    assert np.array_equal(host(ret), e_ret)        # same fp op sequence, no FMA: bit-exact
+    assert np.array_equal(host(adv), e_adv)
+
+
+def test_scan_golden_ppo(eng, golden):
+    g = golden("ppo_returns.npz")
+    L = g["ep_len"]
+    n = int(L.sum())
+    flags = np.zeros(n, np.uint8)
+    nv = np.zeros(n, np.float32)
+    end = np.cumsum(L) - 1
+    for e, dn, lv in zip(end, g["done_tail"], g["last_val"]):
+        flags[e] = _abi.FLAG_LAST | (_abi.FLAG_ABSORBING if dn else 0)
+        nv[e] = lv
+    ret, adv = eng.return_scan(_abi.SCAN_RETURN, float(g["gamma"]), 0.95, dev(g["rewards"][:, None]),
+                               dev(g["values"][:, None]), dev(nv[:, None]), dev(flags[:, None]))
+    assert np.array_equal(host(ret)[:, 0], g["returns"])       # bit-exact vs PPOBuffer.finish_path
+    assert np.array_equal(host(adv)[:, 0], g["adv"])
+    st = eng.adv_stats(adv)
+    eng.adv_normalize(adv, st, 1, float(g["eps"]))
+    np.testing.assert_allclose(host(adv)[:, 0], g["adv_norm"], rtol=2e-6, atol=2e-7)   # torch f32 mean/std
+
+
+# --------------------------------------------------------------------------------- K7
+@pytest.mark.parametrize("n", [1, 3, 1000, 4096 * 400 + 3])
+def test_adv_stats_normalize(eng, oracle, n):
+    rng = np.random.default_rng(n)
+    x = (rng.normal(0.3, 2.0, n)).astype(np.float32)
+    xd = dev(x)
+    st = eng.adv_stats(xd)
+    e_st = oracle.adv_stats(x)
+    s = host(st)
+    assert s[0] == n
+    np.testing.assert_allclose(s[1:], e_st[1:], rtol=1e-12)      # fp64 sums, different tree order
+    st2 = eng.adv_stats(xd)
+    assert torch.equal(st, st2)                                   # deterministic run to run
+    if n > 1:
+        for ddof, eps in ((1, 1e-5), (0, 1e-8)):
+            y = eng.adv_normalize(xd.clone(), st, ddof, eps)
+            e_y = oracle.adv_normalize(x, s, ddof, eps)
+            assert np.array_equal(host(y), e_y)                   # same stats -> bit-exact
+            xt = torch.as_tensor(x)
+            ref = (xt - xt.mean()) / (xt.std(unbiased=bool(ddof)) + eps)
+            np.testing.assert_allclose(host(y), ref.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,D", [(1, 32), (1000, 32), (4096, 41), (513, 12), (50000, 32)])
+def test_col_stats(eng, oracle, B, D):
+    rng = np.random.default_rng(B + D)
+    x = rng.normal(0.5, 1.5, (B, D)).astype(np.float32)
+    cs = eng.col_stats(dev(x))
+    e = oracle.col_stats(x)
+    np.testing.assert_allclose(host(cs), e, rtol=1e-12)
+    cs2 = eng.col_stats(dev(x), cs.clone())
+    np.testing.assert_allclose(host(cs2), 2 * e, rtol=1e-12)
+
+
+# --------------------------------------------------------------------------------- K8
+def test_disc_golden(eng, golden, oracle):
+    g = golden("vail_disc.npz")
+    d = g["d"].reshape(-1)
+    r = host(eng.disc_reward(dev(d)))
+    p = 1.0 / (1.0 + np.exp(-d.astype(np.float64)))
+    tol = 4 * 2.0 ** -24 / (1 - p + 1e-8) + 4e-7 * np.abs(g["reward"]) + 1e-7   # see test_oracle_golden
+    assert (np.abs(r - g["reward"]) <= tol).all()
+    re = host(eng.disc_reward(dev(g["d_ext"].reshape(-1))))
+    pe = 1.0 / (1.0 + np.exp(-g["d_ext"].reshape(-1).astype(np.float64)))
+    tole = 4 * 2.0 ** -24 / (1 - pe + 1e-8) + 4e-7 * np.abs(g["reward_ext"]) + 1e-7
+    assert (np.abs(re - g["reward_ext"]) <= tole).all() and np.isfinite(re).all()
+    xs = host(eng.disc_standardize(dev(g["x"]), dev(np.arange(32, dtype=np.int32)), dev(g["st_mean"]),
+                                   dev(g["st_std"])))
+    assert np.array_equal(xs, oracle.disc_standardize(g["x"], np.arange(32), g["st_mean"], g["st_std"]))
+    z = host(eng.disc_reparam(dev(g["mu"]), dev(g["logvar"]), dev(g["eps"])))
+    np.testing.assert_allclose(z, oracle.disc_reparam(g["mu"], g["logvar"], g["eps"]), rtol=3e-7, atol=1e-7)
+
+
+def test_vail_reward_end_to_end(eng, golden):
+    """mask+standardise (HIP) -> encoder/decoder GEMMs (torch-ROCm) -> reparam + reward (HIP)
+    reproduces the reference VariationalNet + make_discrim_reward."""
+    g = golden("vail_disc.npz")
+    t = lambda k: dev(g[k])
+    x = t("x")
+    cs = eng.col_stats(x)
+    cnt = cs[0] + 1e-2
+    mean = cs[1] / cnt
+    std = torch.sqrt(torch.clamp((cs[2] + 1e-2) / cnt - mean ** 2, min=1e-2))
+    np.testing.assert_allclose(host(mean), g["st_mean"], rtol=2e-5, atol=2e-6)
+    xs = eng.disc_standardize(x, None, mean, std)
+    with torch.no_grad():
+        h = torch.relu(xs @ t("enc_w0").T + t("enc_b0"))
+        h = torch.relu(h @ t("enc_w1").T + t("enc_b1"))
+        mu, lv = h @ t("mu_w").T + t("mu_b"), h @ t("lv_w").T + t("lv_b")
+        z = eng.disc_reparam(mu.contiguous(), lv.contiguous(), t("eps"))
+        d = (z @ t("dec_w").T + t("dec_b")).reshape(-1).contiguous()
+    np.testing.assert_allclose(host(d), g["d"].reshape(-1), rtol=2e-3, atol=2e-3)    # GEMM order
+    r = host(eng.disc_reward(d))
+    ok = np.abs(g["d"].reshape(-1)) < 8
+    np.testing.assert_allclose(r[ok], g["reward"][ok], rtol=5e-3, atol=5e-3)
+
+
+# --------------------------------------------------------------------------------- K4
+def test_traj_golden(eng, golden):
+    g = golden("trajectory.npz")
+    table = g["table"]
+    eng.traj_upload(table)
+    resets = g["resets"]
+    ct, cs, origin, sample = eng.traj_reset(dev(resets[:, 1], torch.int32), dev(resets[:, 0], torch.int32))
+    assert np.array_equal(host(sample), g["reset_samples"])
+    sub, tno = g["rnd_reset"]
+    ct, cs, origin, sample = eng.traj_reset(dev([tno], torch.int32), dev([sub], torch.int32))
+    walk = [host(sample)[0].copy()]
+    L = table.shape[2]
+    for _ in range(L + 2):
+        at_end = eng.traj_next(ct, cs, origin, sample)
+        if host(at_end)[0]:
+            assert host(cs)[0] == L
+            break
+        walk.append(host(sample)[0].copy())
+    assert np.array_equal(np.array(walk), g["walk"])
+
+
+def test_traj_vs_oracle_many_envs(eng, golden, oracle):
+    g = golden("trajectory.npz")
+    table = g["table"]
+    K, J, L = table.shape
+    eng.traj_upload(table)
+    N = 3000
+    rng = np.random.default_rng(4)
+    tn, st = rng.integers(0, J, N).astype(np.int32), rng.integers(0, L, N).astype(np.int32)
+    ct, cs, origin, sample = eng.traj_reset(dev(tn), dev(st))
+    e_ct, e_cs, e_or, e_sa = oracle.traj_reset(table, tn, st)
+    assert np.array_equal(host(sample), e_sa) and np.array_equal(host(origin), e_or)
+    active = (rng.uniform(size=N) < 0.7).astype(np.uint8)
+    for _ in range(4):
+        cur = rng.normal(size=(N, 17))
+        eng.traj_euler(17, 0.01, dev(cur), sample)
+        e_sa = oracle.traj_euler(17, 0.01, cur, e_sa)
+        assert np.array_equal(host(sample), e_sa)
+        at_end = eng.traj_next(ct, cs, origin, sample, active=dev(active))
+        e_cs, e_sa, e_end = oracle.traj_next(table, e_ct, e_cs, e_or, e_sa, active=active)
+        assert np.array_equal(host(cs), e_cs) and np.array_equal(host(at_end), e_end)
+        assert np.array_equal(host(sample), e_sa)
+
+
+# --------------------------------------------------------------------------------- K3
+def test_contacts_golden_and_oracle(eng, golden, oracle):
+    g = golden("contacts.npz")
+    eng.contact_configure(g["geom_bodyid"], int(g["floor_body"]), int(g["rfoot_body"]), int(g["lfoot_body"]))
+    pz = np.ascontiguousarray(g["pos"][:, :, 2])
+    o = eng.contact_reduce(dev(g["ncon"]), dev(g["geom1"]), dev(g["geom2"]), dev(g["force6"]), dev(pz))
+    o = {k: host(v) for k, v in o.items()}
+    for k in ("n_r", "n_l", "idx_r", "idx_l"):
+        assert np.array_equal(o[k], g[k]), k                          # bit-exact integers
+    assert np.array_equal(o["bad"].astype(bool), g["bad"])
+    e = oracle.contact_reduce(g["geom_bodyid"], 0, 7, 10, g["ncon"], g["geom1"], g["geom2"], g["force6"], pz)
+    for k in ("grf_r", "grf_l", "min_z"):
+        assert np.array_equal(o[k], e[k]), k                          # same in-order chain: bit-exact
+    np.testing.assert_allclose(o["grf_r"], g["grf_r"], rtol=1e-14)
+
+
+@pytest.mark.parametrize("N,C", [(1, 16), (5, 7), (4097, 16), (300, 40)])
+def test_contacts_shapes(eng, oracle, N, C):
+    rng = np.random.default_rng(N + C)
+    gb = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)
+    eng.contact_configure(gb, 0, 7, 10)
+    ncon = np.minimum(rng.poisson(C / 3, N), C).astype(np.int32)
+    g1 = rng.choice([0, 0, 0, 8, 3], (N, C)).astype(np.int32)
+    g2 = rng.choice([8, 12, 8, 12, 0, 5], (N, C)).astype(np.int32)
+    f6 = rng.normal(0, 100, (N, C, 6))
+    pz = rng.uniform(-0.05, 0.05, (N, C))
+    o = eng.contact_reduce(dev(ncon), dev(g1), dev(g2), dev(f6), dev(pz))
+    e = oracle.contact_reduce(gb, 0, 7, 10, ncon, g1, g2, f6, pz)
+    for k in e:
+        assert np.array_equal(host(o[k]), e[k]), k
+
+
+# --------------------------------------------------------------------------------- K2
+def test_a3_golden_sequence(eng, golden, oracle):
+    g = golden("a3_task.npz")
+    spec = specs.A3Spec(mass=float(g["mass"]))
+    eng.a3_configure(spec, g["clock_lut"])
+    eng.contact_configure(g["geom_bodyid"], int(g["floor_body"]), int(g["rfoot_body"]), int(g["lfoot_body"]))
+    E, K = g["phase"].shape
+    st_h, _ = a3_fixture_arrays(g, 0)
+    st_o = {k: v.copy() for k, v in st_h.items()}
+    st_d = {k: dev(v) for k, v in st_h.items()}
+    for k in range(K):
+        _, inp = a3_fixture_arrays(g, k)
+        cr = eng.contact_reduce(dev(g["ncon"][:, k]), dev(g["geom1"][:, k]), dev(g["geom2"][:, k]),
+                                dev(g["force6"][:, k]), dev(g["cpos_z"][:, k]), want_idx=False)
+        d_in = {n: dev(v) for n, v in inp.items()}
+        d_in.update({n: cr[n] for n in ("grf_l", "grf_r", "min_z", "n_r", "n_l", "bad")})
+        o = eng.a3_step(d_in, st_d, obs_f64=True)
+        # integer task state vs the reference: bit-exact
+        assert np.array_equal(host(st_d["phase"]), g["phase"][:, k]), k
+        assert np.array_equal(host(st_d["t1"]), g["t1"][:, k]) and np.array_equal(host(st_d["t2"]), g["t2"][:, k])
+        assert np.array_equal(host(st_d["target_reached"]).astype(bool), g["target_reached"][:, k])
+        assert np.array_equal(host(st_d["reached_frames"]), g["reached_frames"][:, k])
+        assert np.array_equal(host(o["done"]).astype(bool), g["done"][:, k])
+        # floats vs the reference: fp64 math through device libm, 1e-11 relative
+        np.testing.assert_allclose(host(st_d["goal"]), g["goal"][:, k], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(host(o["obs"]), g["obs"][:, k], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(host(o["rew6"]), g["rew6"][:, k], rtol=2e-6, atol=1e-7)    # f32 outputs
+        np.testing.assert_allclose(host(o["reward"]), g["reward"][:, k], rtol=2e-6, atol=1e-7)
+        # and vs the oracle on the same inputs
+        cro = oracle.contact_reduce(g["geom_bodyid"], 0, 7, 10, g["ncon"][:, k], g["geom1"][:, k],
+                                    g["geom2"][:, k], g["force6"][:, k], g["cpos_z"][:, k])
+        inp.update({n: cro[n] for n in ("grf_l", "grf_r", "min_z", "n_r", "n_l", "bad")})
+        eo = oracle.a3_step(spec, g["clock_lut"], inp, st_o)
+        assert np.array_equal(host(o["done"]), eo["done"])
+        np.testing.assert_allclose(host(o["obs"]), eo["obs"], rtol=1e-13, atol=1e-14)
+
+
+def test_a3_many_envs_vs_oracle(eng, golden, oracle):
+    g = golden("a3_task.npz")
+    spec = specs.A3Spec(mass=41.5)
+    eng.a3_configure(spec, g["clock_lut"])
+    rng = np.random.default_rng(12)
+    N = 1500
+    E = g["phase"].shape[0]
+    pick = rng.integers(0, E, N)
+    st_h, _ = a3_fixture_arrays(g, 0)
+    st_h = {k: np.ascontiguousarray(v[pick]) for k, v in st_h.items()}
+    st_h["phase"] = rng.integers(0, 88, N).astype(np.int32)
+    seq = st_h["sequence"]
+    tgt = seq[np.arange(N), np.minimum(st_h["t1"], st_h["seq_len"] - 1), :3]
+    inp = dict(qpos=np.concatenate([rng.normal(0, 1, (N, 3)), rng.normal(0, 1, (N, 4)), rng.uniform(-1, 1, (N, 18))], 1),
+               qvel=rng.normal(0, 1, (N, 24)), act_len=rng.uniform(-1, 1, (N, 12)), act_vel=rng.normal(0, 2, (N, 12)),
+               lf_pos=tgt + rng.normal(0, 0.15, (N, 3)), rf_pos=tgt + rng.normal(0, 0.3, (N, 3)),
+               lf_vel=rng.normal(0, 0.2, (N, 3)), rf_vel=rng.normal(0, 0.2, (N, 3)),
+               root_pos=tgt + np.array([0, 0, 0.7]) + rng.normal(0, 0.2, (N, 3)),
+               root_quat=rng.normal(0, 1, (N, 4)), head_pos=tgt + np.array([0, 0, 1.2]) + rng.normal(0, 0.1, (N, 3)),
+               grf_l=rng.uniform(0, 400, N), grf_r=rng.uniform(0, 400, N), min_z=rng.uniform(-0.01, 0.03, N),
+               n_r=rng.integers(0, 3, N).astype(np.int32), n_l=rng.integers(0, 3, N).astype(np.int32),
+               bad=(rng.uniform(size=N) < 0.2).astype(np.uint8))
+    st_d = {k: dev(v) for k, v in st_h.items()}
+    st_o = {k: v.copy() for k, v in st_h.items()}
+    for _ in range(3):
+        o = eng.a3_step({k: dev(v) for k, v in inp.items()}, st_d, obs_f64=True)
+        eo = oracle.a3_step(spec, g["clock_lut"], inp, st_o)
+        for k in ("phase", "t1", "t2", "reached_frames", "target_reached"):
+            assert np.array_equal(host(st_d[k]), st_o[k]), k
+        assert np.array_equal(host(o["done"]), eo["done"])
+        np.testing.assert_allclose(host(st_d["goal"]), st_o["goal"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(host(o["obs"]), eo["obs"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(host(o["reward"]), eo["reward"], rtol=2e-6, atol=1e-7)
+        inp["lf_pos"] = inp["lf_pos"] + rng.normal(0, 0.02, (N, 3))
+
+
+def test_a3_pd(eng, golden, oracle):
+    g = golden("a3_task.npz")
+    spec = specs.A3Spec()
+    eng.a3_configure(spec, g["clock_lut"])
+    a32 = g["pd_action"].astype(np.float32)
+    tgt = eng.a3_pd_target(dev(a32))
+    assert np.array_equal(host(tgt), oracle.a3_pd_target(spec, a32))
+    for s in range(g["pd_q"].shape[1]):
+        tau = eng.a3_pd_torque(dev(spec.kp), dev(spec.kd), dev(g["pd_target"]), dev(g["pd_q"][:, s]),
+                               dev(g["pd_qd"][:, s]))
+        assert np.array_equal(host(tau), g["pd_tau"][:, s])           # bit-exact vs the reference
