@@ -162,11 +162,13 @@ __global__ __launch_bounds__(THREADS) void il_step_kernel(IlArgs p) {
           }
           return (float)s;  // PosReward
         };
+        // step-0 rows read the carried state BEFORE last-step rows may overwrite it
+        // (prev_in may alias prev_out when T == 1: then both are this very lane)
+        if (gr < p.N) p.reward[gr] = f(p.prev_in[gr]);
         if (gr + p.N < p.R)
           p.reward[gr + p.N] = f(x);  // reward(t+1) reads obs(t), utils/reward.py:73
         else
           p.prev_out[gr - (p.R - p.N)] = x;  // self._obs of the last step
-        if (gr < p.N) p.reward[gr] = f(p.prev_in[gr]);
       }
     }
     s_abs[r] = ab;

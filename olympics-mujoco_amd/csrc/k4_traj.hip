@@ -69,9 +69,10 @@ __global__ __launch_bounds__(THREADS) void traj_advance_kernel(int len, int N,
   const int n = blockIdx.x * THREADS + threadIdx.x;
   if (n >= N) return;
   if (active && !active[n]) { at_end[n] = 0; return; }
-  const int s = cur_step[n] + 1;
+  int s = cur_step[n];
+  if (s < len) s += 1;  // saturates at len (the reference's callers reset right after a None)
   cur_step[n] = s;
-  at_end[n] = (s == len) ? 1 : 0;
+  at_end[n] = (s >= len) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(THREADS) void traj_euler_kernel(int n_keys, int N, int n_qpos, double dt,

@@ -180,9 +180,12 @@ int oly_traj_next_cpu(int n_keys, int n_traj, int len, const double* table, int 
       continue;
     }
     int j = cur_traj[n];
-    int s = cur_step[n] + 1; /* self.subtraj_step_no += 1 */
+    int s = cur_step[n];
+    if (s < len) s += 1; /* self.subtraj_step_no += 1; saturates at len: the reference's
+                            callers reset right after a None (loco_env_base.py:534-537), so a
+                            call past the end never happens there (it would raise IndexError) */
     cur_step[n] = s;
-    if (s == len) { /* sample = None */
+    if (s >= len) { /* sample = None */
       at_end[n] = 1;
       continue;
     }
