@@ -17,19 +17,32 @@
 // every global access is a dense 16-B-per-lane stream: inputs are staged into LDS in their
 // global order, the per-row gather / permutation happens on LDS reads, and outputs leave
 // as float4 / double2 stores of the row-major output tile.
+#include <cstdlib>
+
 #include "oly_common.h"
 
 namespace {
 
 constexpr int THREADS = 256;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one 16-B lane access
 
 template <int NQ, int NV, int NGRF, int NACT, int NU, int NOBS>
 struct StaticDims {
   static constexpr int nq = NQ, nv = NV, n_grf = NGRF, n_act = NACT, nu = NU, n_obs = NOBS;
+  static constexpr bool is_static = true;
+  static constexpr int n_obs_ct = NOBS;
+  template <int ROWS, int TH>
+  static constexpr int max_chunks() {
+    return (ROWS * (NQ + NV + NGRF) / 2 + ROWS * NACT / 4 + TH - 1) / TH;
+  }
   __device__ explicit StaticDims(const IlDev*) {}
 };
 struct DynDims {
   int nq, nv, n_grf, n_act, nu, n_obs;
+  static constexpr bool is_static = false;
+  static constexpr int n_obs_ct = 1;
+  template <int ROWS, int TH>
+  static constexpr int max_chunks() { return 1; }
   __device__ explicit DynDims(const IlDev* m)
       : nq(m->nq), nv(m->nv), n_grf(m->n_grf), n_act(m->n_act), nu(m->nu), n_obs(m->n_obs) {}
 };
@@ -50,27 +63,39 @@ struct IlArgs {
   uint8_t* fall_code;
   void* ctrl;
   int fast;  // all base pointers 16-B aligned: dense 16-B staging / stores allowed
+  long tile0;    // first tile of this launch (generic kernel) / number of full tiles (tile kernel)
 };
 
 // LDS carve (all offsets in bytes, every region 16-B aligned):
-//   [ staged doubles: q | v | g ][ staged action floats ][ tables ][ row codes ]
+//   [ staged doubles: q | v | g ][ staged action floats ][ tables ]
 template <int ROWS, class D>
 struct Carve {
-  int q, v, g, a, tab_src, tab_csrc, tab_act, codes, total;
+  int q, v, g, a, tab_off, tab_str, tab_csrc, tab_act, total;
   __host__ __device__ Carve(int nq, int nv, int n_grf, int n_act, int nu, int n_obs) {
     auto al = [](int x) { return (x + 15) & ~15; };
     q = 0;
     v = q + ROWS * nq * 8;
     g = v + ROWS * nv * 8;
     a = al(g + ROWS * n_grf * 8);
-    tab_src = al(a + ROWS * n_act * 4);
-    tab_csrc = al(tab_src + n_obs * 2);
-    tab_act = al(tab_csrc + nu * 2);
-    codes = al(tab_act + 4 * n_act * 8);
-    total = al(codes + 2 * ROWS);
+    tab_off = al(a + ROWS * n_act * 4);
+    tab_str = al(tab_off + n_obs * 4);
+    tab_csrc = al(tab_str + n_obs * 4);
+    tab_act = al(tab_csrc + nu * 4);
+    total = al(tab_act + 4 * nu * 8);
   }
 };
 
+#ifndef OLY_K1_ABLATE
+#define OLY_K1_ABLATE 0  // diagnostic builds only: 1 = input stream only, 2 = no input loads
+#endif
+
+constexpr int FAST_FALL = 8;  // fall tests kept in registers (H1/Atlas/Talos have 4..7)
+
+// One workgroup per tile of ROWS rows.  Everything that does not depend on the staged data
+// (column tables, thresholds, per-lane source offsets) is fetched BEFORE the tile's loads are
+// waited for, so that after the barrier the tile is turned into outputs with one LDS round
+// trip per output vector; the long pole of a workgroup's life is then its input stream, and
+// several resident workgroups per CU keep that stream saturated.
 template <int ROWS, class D, bool OBS64, bool CTRL64>
 __global__ __launch_bounds__(THREADS) void il_step_kernel(IlArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -78,7 +103,8 @@ __global__ __launch_bounds__(THREADS) void il_step_kernel(IlArgs p) {
   const D d(md);
   const Carve<ROWS, D> cv(d.nq, d.nv, d.n_grf, d.n_act, d.nu, d.n_obs);
   const int tid = threadIdx.x;
-  const long row0 = (long)blockIdx.x * ROWS;
+  const int lane = tid & 63;
+  const long row0 = (p.tile0 + blockIdx.x) * ROWS;
   const int rows = (p.R - row0 < ROWS) ? (int)(p.R - row0) : ROWS;
   const bool full = (rows == ROWS) && p.fast;
 
@@ -86,32 +112,125 @@ __global__ __launch_bounds__(THREADS) void il_step_kernel(IlArgs p) {
   double* sv = reinterpret_cast<double*>(lds + cv.v);
   double* sg = reinterpret_cast<double*>(lds + cv.g);
   float* sa = reinterpret_cast<float*>(lds + cv.a);
-  short* t_src = reinterpret_cast<short*>(lds + cv.tab_src);
-  short* t_csrc = reinterpret_cast<short*>(lds + cv.tab_csrc);
-  double* t_act = reinterpret_cast<double*>(lds + cv.tab_act);  // mean|delta|lo|hi
-  unsigned char* s_abs = lds + cv.codes;
-  unsigned char* s_code = s_abs + ROWS;
+  int* t_off = reinterpret_cast<int*>(lds + cv.tab_off);  // column -> element offset of row 0
+  int* t_str = reinterpret_cast<int*>(lds + cv.tab_str);  // column -> row stride (elements)
+  int* t_cidx = reinterpret_cast<int*>(lds + cv.tab_csrc);      // actuator -> action slot | -1
+  double* t_act = reinterpret_cast<double*>(lds + cv.tab_act);  // per ACTUATOR: mean|delta|lo|hi
 
-  // ---- stage inputs (global order == LDS order)
-  if (full) {
-    const int cq = ROWS * d.nq / 2, cvv = ROWS * d.nv / 2, cg = ROWS * d.n_grf / 2;
-    const int ca = p.action ? ROWS * d.n_act / 4 : 0;
-    const uint4* gq = reinterpret_cast<const uint4*>(p.qpos + row0 * d.nq);
-    const uint4* gv = reinterpret_cast<const uint4*>(p.qvel + row0 * d.nv);
-    const uint4* gg = reinterpret_cast<const uint4*>(p.grf ? p.grf + row0 * d.n_grf : nullptr);
-    const uint4* ga = reinterpret_cast<const uint4*>(p.action ? p.action + row0 * d.n_act : nullptr);
-    uint4* lq = reinterpret_cast<uint4*>(sq);
-    uint4* lv = reinterpret_cast<uint4*>(sv);
-    uint4* lg = reinterpret_cast<uint4*>(sg);
-    uint4* la = reinterpret_cast<uint4*>(sa);
-#pragma unroll 4
-    for (int i = tid; i < cq; i += THREADS) lq[i] = gq[i];
-#pragma unroll 4
-    for (int i = tid; i < cvv; i += THREADS) lv[i] = gv[i];
-    if (p.grf)
-      for (int i = tid; i < cg; i += THREADS) lg[i] = gg[i];
-#pragma unroll 2
-    for (int i = tid; i < ca; i += THREADS) la[i] = ga[i];
+  // staged-row addressing: q | v | g are contiguous in LDS, so element `sidx` of the staged
+  // row [qpos | qvel | grf] of local row r lives at off(sidx) + r * stride(sidx)
+  auto col_off = [&](int sidx) -> int {
+    if (sidx < d.nq) return sidx;
+    if (sidx < d.nq + d.nv) return ROWS * d.nq + (sidx - d.nq);
+    return ROWS * (d.nq + d.nv) + (sidx - d.nq - d.nv);
+  };
+  auto col_str = [&](int sidx) -> int {
+    if (sidx < d.nq) return d.nq;
+    if (sidx < d.nq + d.nv) return d.nv;
+    return d.n_grf;
+  };
+  const int first_grf = d.n_obs - d.n_grf;
+
+  // ---- (1) issue the whole input tile: every 16-B load of the tile before any wait
+  const int cq = ROWS * d.nq / 2, cvv = ROWS * d.nv / 2, cg = ROWS * d.n_grf / 2;
+  const int ca = p.action ? ROWS * d.n_act / 4 : 0;
+  const int cd = cq + cvv + cg;
+  const int total = (OLY_K1_ABLATE & 2) ? 0 : cd + ca;
+  u32x4* ld = reinterpret_cast<u32x4*>(sq);
+  u32x4* la = reinterpret_cast<u32x4*>(sa);
+  constexpr int MAXC = D::template max_chunks<ROWS, THREADS>();
+  u32x4 regs[MAXC];
+  const bool reg_staged = D::is_static && full;
+  if (reg_staged) {
+    const u32x4* gq = reinterpret_cast<const u32x4*>(p.qpos + row0 * d.nq);
+    const u32x4* gv = reinterpret_cast<const u32x4*>(p.qvel + row0 * d.nv);
+    const u32x4* gg = reinterpret_cast<const u32x4*>(p.grf ? p.grf + row0 * d.n_grf : nullptr);
+    const u32x4* ga = reinterpret_cast<const u32x4*>(p.action ? p.action + row0 * d.n_act : nullptr);
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int g = tid + k * THREADS;
+      if (g < total) {
+        const u32x4* src = g < cq ? gq + g : (g < cq + cvv ? gv + (g - cq) : (g < cd ? gg + (g - cq - cvv) : ga + (g - cd)));
+        regs[k] = *src;
+      }
+    }
+  }
+
+  // ---- (2) while those are in flight: tables and per-lane constants
+  for (int i = tid; i < d.n_obs; i += THREADS) {
+    const int sidx = md->src[i];
+    t_off[i] = col_off(sidx);
+    t_str[i] = col_str(sidx);
+  }
+  for (int j = tid; j < d.nu; j += THREADS) {
+    const int k = md->ctrl_src[j];
+    t_cidx[j] = k;
+    const int kk = k < 0 ? 0 : k;
+    t_act[j] = md->act_mean[kk];
+    t_act[d.nu + j] = md->act_delta[kk];
+    t_act[2 * d.nu + j] = md->ctrl_lo[kk];
+    t_act[3 * d.nu + j] = md->ctrl_hi[kk];
+  }
+  // columns owned by this lane in the dense output sweep are loop-invariant when the sweep
+  // stride is a multiple of the row width (H1: 256 lanes x 4 floats = 32 rows x 32 columns)
+  constexpr int OW = OBS64 ? 2 : 4;  // observation values per lane store
+  const bool fixed_cols = D::is_static && ((THREADS * OW) % d.n_obs == 0);
+  int my_off[OW], my_str[OW];
+  if (fixed_cols) {
+    const int c0 = (tid * OW) % d.n_obs;
+#pragma unroll
+    for (int k = 0; k < OW; ++k) {
+      const int sidx = md->src[c0 + k];
+      my_off[k] = col_off(sidx);
+      my_str[k] = col_str(sidx);
+    }
+  }
+  // wave-uniform parameters of the per-row tests (scalar loads)
+  const int nf = md->n_fall;
+  int f_off[FAST_FALL], f_str[FAST_FALL];
+  double f_lo[FAST_FALL], f_hi[FAST_FALL];
+  bool f_grf[FAST_FALL];
+#pragma unroll
+  for (int k = 0; k < FAST_FALL; ++k) {
+    const int kk = k < nf ? k : 0;
+    const int sidx = md->fall_sidx[kk];
+    f_off[k] = col_off(sidx);
+    f_str[k] = col_str(sidx);
+    f_lo[k] = md->fall_lo[kk];
+    f_hi[k] = md->fall_hi[kk];
+    f_grf[k] = d.n_grf > 0 && md->fall_idx[kk] >= first_grf;
+  }
+  const int rt = md->reward_type;
+  const int rew_off = col_off(md->reward_sidx), rew_str = col_str(md->reward_sidx);
+  const bool rew_grf = d.n_grf > 0 && md->reward_idx >= first_grf;
+  const double tvel = md->target_velocity;
+  const int use_abs = md->use_absorbing;
+  const long gr = row0 + tid;  // global row of this lane in the per-row phase
+  double prev0 = 0.0;
+  if (tid < rows && rt != OLY_REWARD_NONE && gr < p.N) prev0 = p.prev_in[gr];
+
+  // ---- (3) land the tile in LDS (global order == LDS order)
+  if (reg_staged) {
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int g = tid + k * THREADS;
+      if (g < total) {
+        if (g < cd) ld[g] = regs[k];
+        else la[g - cd] = regs[k];
+      }
+    }
+  } else if (full) {
+    const u32x4* gq = reinterpret_cast<const u32x4*>(p.qpos + row0 * d.nq);
+    const u32x4* gv = reinterpret_cast<const u32x4*>(p.qvel + row0 * d.nv);
+    const u32x4* gg = reinterpret_cast<const u32x4*>(p.grf ? p.grf + row0 * d.n_grf : nullptr);
+    const u32x4* ga = reinterpret_cast<const u32x4*>(p.action ? p.action + row0 * d.n_act : nullptr);
+#pragma unroll 8
+    for (int g = tid; g < total; g += THREADS) {
+      const u32x4* src = g < cq ? gq + g : (g < cq + cvv ? gv + (g - cq) : (g < cd ? gg + (g - cq - cvv) : ga + (g - cd)));
+      const u32x4 x = *src;
+      if (g < cd) ld[g] = x;
+      else la[g - cd] = x;
+    }
   } else {
     for (int i = tid; i < rows * d.nq; i += THREADS) sq[i] = p.qpos[row0 * d.nq + i];
     for (int i = tid; i < rows * d.nv; i += THREADS) sv[i] = p.qvel[row0 * d.nv + i];
@@ -120,67 +239,119 @@ __global__ __launch_bounds__(THREADS) void il_step_kernel(IlArgs p) {
     if (p.action)
       for (int i = tid; i < rows * d.n_act; i += THREADS) sa[i] = p.action[row0 * d.n_act + i];
   }
-  // ---- per-column tables
-  for (int i = tid; i < d.n_obs; i += THREADS) t_src[i] = md->src[i];
-  for (int i = tid; i < d.nu; i += THREADS) t_csrc[i] = md->ctrl_src[i];
-  for (int i = tid; i < d.n_act; i += THREADS) {
-    t_act[i] = md->act_mean[i];
-    t_act[d.n_act + i] = md->act_delta[i];
-    t_act[2 * d.n_act + i] = md->ctrl_lo[i];
-    t_act[3 * d.n_act + i] = md->ctrl_hi[i];
-  }
   __syncthreads();
+  if (OLY_K1_ABLATE == 1) {  // diagnostic build: input stream only
+    if (sq[tid] == 1.2345e300) p.reward[0] = 1.f;
+    return;
+  }
 
-  // created-observation column c of local row r, in float64
-  auto obs_val = [&](int r, int c) -> double {
-    const int s = t_src[c];
-    if (s < d.nq) return sq[r * d.nq + s];
-    if (s < d.nq + d.nv) return sv[r * d.nv + (s - d.nq)];
-    return sg[r * d.n_grf + (s - d.nq - d.nv)] / 1000.0;
-  };
-
-  // ---- per-row scalars: fall tests, reward of the NEXT step, carried state
-  for (int r = tid; r < ROWS; r += THREADS) {
-    unsigned char code = 0, ab = 0;
+  // ---- (4) per-row scalars: fall tests, reward of the NEXT step, carried state, flags.
+  // ROWS is a multiple of 64 and <= THREADS: a wave is either all-in or all-out.
+  if (tid < ROWS && !(OLY_K1_ABLATE & 16)) {
+    const int r = tid;
+    unsigned code = 0, ab = 0;
     if (r < rows) {
-      const int nf = md->n_fall;
-      for (int k = 0; k < nf; ++k) {
-        const double v = obs_val(r, md->fall_idx[k]);
-        if (code == 0 && (v < md->fall_lo[k] || v > md->fall_hi[k])) code = (unsigned char)(k + 1);
+      double fv[FAST_FALL];
+#pragma unroll
+      for (int k = 0; k < FAST_FALL; ++k)
+        if (k < nf) fv[k] = sq[f_off[k] + r * f_str[k]];
+#pragma unroll
+      for (int k = 0; k < FAST_FALL; ++k)
+        if (k < nf) {
+          const double v = f_grf[k] ? fv[k] / 1000.0 : fv[k];
+          if (code == 0 && (v < f_lo[k] || v > f_hi[k])) code = (unsigned)(k + 1);
+        }
+      for (int k = FAST_FALL; k < nf; ++k) {  // robots with more tests than the fast set
+        const int sidx = md->fall_sidx[k];
+        double v = sq[col_off(sidx) + r * col_str(sidx)];
+        if (d.n_grf > 0 && md->fall_idx[k] >= first_grf) v = v / 1000.0;
+        if (code == 0 && (v < md->fall_lo[k] || v > md->fall_hi[k])) code = (unsigned)(k + 1);
       }
-      ab = (code != 0 && md->use_absorbing) ? 1 : 0;
-      const long gr = row0 + r;
-      const int rt = md->reward_type;
+      ab = (code != 0 && use_abs) ? 1u : 0u;
       if (rt == OLY_REWARD_NONE) {
         p.reward[gr] = 0.0f;
       } else {
-        const double x = obs_val(r, md->reward_idx);
+        double x = sq[rew_off + r * rew_str];
+        if (rew_grf) x = x / 1000.0;
         auto f = [&](double s) -> float {
           if (rt == OLY_REWARD_TARGET_VELOCITY) {
-            const double dv = s - md->target_velocity;
+            const double dv = s - tvel;
             return (float)exp(-(dv * dv));
           }
           return (float)s;  // PosReward
         };
-        // step-0 rows read the carried state BEFORE last-step rows may overwrite it
-        // (prev_in may alias prev_out when T == 1: then both are this very lane)
-        if (gr < p.N) p.reward[gr] = f(p.prev_in[gr]);
+        // step-0 rows use the carried state, read BEFORE any last-step row could overwrite it
+        // (prev_in may alias prev_out only when T == 1: then both are this very lane)
+        if (gr < p.N) p.reward[gr] = f(prev0);
         if (gr + p.N < p.R)
           p.reward[gr + p.N] = f(x);  // reward(t+1) reads obs(t), utils/reward.py:73
         else
           p.prev_out[gr - (p.R - p.N)] = x;  // self._obs of the last step
       }
     }
-    s_abs[r] = ab;
-    s_code[r] = code;
+    // flags: pack 4 rows per dword inside the wave (lane i < 16 gathers lanes 4i..4i+3)
+    if (full) {
+      unsigned a4 = 0, c4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int srcl = (lane & 15) * 4 + k;
+        a4 |= (unsigned)__shfl((int)ab, srcl, 64) << (8 * k);
+        c4 |= (unsigned)__shfl((int)code, srcl, 64) << (8 * k);
+      }
+      if (lane < 16) {
+        const long q4 = (row0 + (r - lane)) / 4 + lane;
+        reinterpret_cast<unsigned*>(p.absorbing)[q4] = a4;
+        if (p.fall_code) reinterpret_cast<unsigned*>(p.fall_code)[q4] = c4;
+      }
+    } else if (r < rows) {
+      p.absorbing[row0 + r] = (uint8_t)ab;
+      if (p.fall_code) p.fall_code[row0 + r] = (uint8_t)code;
+    }
   }
 
-  // ---- observation tile
+  // created-observation column c of local row r, in float64 (table-driven form)
+  auto obs_val = [&](int r, int c) -> double {
+    const double x = sq[t_off[c] + r * t_str[c]];
+    if (d.n_grf > 0 && c >= first_grf) return x / 1000.0;  // mean_grf / 1000.0
+    return x;
+  };
+
+  // ---- (5) observation tile
   if (full) {
-    if (OBS64) {
+    const int nvec = ROWS * d.n_obs / OW;
+    if (fixed_cols) {
+      const int c0 = (tid * OW) % d.n_obs;
+      const int rstep = THREADS * OW / d.n_obs;
+      constexpr int NIT = (ROWS * D::n_obs_ct / OW + THREADS - 1) / THREADS;
+      double v[NIT > 0 ? NIT : 1][OW];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int r = tid * OW / d.n_obs + it * rstep;
+#pragma unroll
+        for (int k = 0; k < OW; ++k) v[it][k] = (OLY_K1_ABLATE & 4) ? (double)(r + k) : sq[my_off[k] + r * my_str[k]];
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * THREADS;
+        if (i < nvec) {
+#pragma unroll
+          for (int k = 0; k < OW; ++k)
+            if (d.n_grf > 0 && c0 + k >= first_grf) v[it][k] = v[it][k] / 1000.0;
+          if (OBS64) {
+            double2 o;
+            o.x = v[it][0]; o.y = v[it][OW - 1];
+            reinterpret_cast<double2*>(static_cast<double*>(p.obs) + row0 * d.n_obs)[i] = o;
+          } else {
+            float4 o;
+            o.x = (float)v[it][0]; o.y = (float)v[it][1 % OW];
+            o.z = (float)v[it][2 % OW]; o.w = (float)v[it][3 % OW];
+            reinterpret_cast<float4*>(static_cast<float*>(p.obs) + row0 * d.n_obs)[i] = o;
+          }
+        }
+      }
+    } else if (OBS64) {
       double2* out = reinterpret_cast<double2*>(static_cast<double*>(p.obs) + row0 * d.n_obs);
-      const int n2 = ROWS * d.n_obs / 2;
-      for (int i = tid; i < n2; i += THREADS) {
+      for (int i = tid; i < nvec; i += THREADS) {
         int e = 2 * i, r = e / d.n_obs, c = e - r * d.n_obs;
         double2 o;
         o.x = obs_val(r, c);
@@ -190,8 +361,7 @@ __global__ __launch_bounds__(THREADS) void il_step_kernel(IlArgs p) {
       }
     } else {
       float4* out = reinterpret_cast<float4*>(static_cast<float*>(p.obs) + row0 * d.n_obs);
-      const int n4 = ROWS * d.n_obs / 4;
-      for (int i = tid; i < n4; i += THREADS) {
+      for (int i = tid; i < nvec; i += THREADS) {
         int e = 4 * i, r = e / d.n_obs, c = e - r * d.n_obs;
         float4 o;
         o.x = (float)obs_val(r, c);
@@ -215,16 +385,17 @@ __global__ __launch_bounds__(THREADS) void il_step_kernel(IlArgs p) {
     }
   }
 
-  // ---- control tile: un-normalise, clamp to ctrlrange, scatter to actuator order
+  // ---- (6) control tile: un-normalise, clamp to ctrlrange, in actuator order
   if (p.ctrl) {
     auto ctrl_val = [&](int r, int j) -> double {
-      const int k = t_csrc[j];
-      if (k < 0) return 0.0;
-      double u = (double)sa[r * d.n_act + k] * t_act[d.n_act + k] + t_act[k];
-      const double lo = t_act[2 * d.n_act + k], hi = t_act[3 * d.n_act + k];
+      if (OLY_K1_ABLATE & 8) return (double)(r - j);
+      const int k = t_cidx[j];
+      const double a = (double)sa[r * d.n_act + (k < 0 ? 0 : k)];
+      double u = a * t_act[d.nu + j] + t_act[j];
+      const double lo = t_act[2 * d.nu + j], hi = t_act[3 * d.nu + j];
       if (u < lo) u = lo;
       if (u > hi) u = hi;
-      return u;
+      return k < 0 ? 0.0 : u;
     };
     if (full && !CTRL64) {
       float4* out = reinterpret_cast<float4*>(static_cast<float*>(p.ctrl) + row0 * d.nu);
@@ -252,32 +423,253 @@ __global__ __launch_bounds__(THREADS) void il_step_kernel(IlArgs p) {
       }
     }
   }
+}
 
-  // ---- flags: 4 rows per dword
-  __syncthreads();
-  if (full) {
-    const unsigned* a4 = reinterpret_cast<const unsigned*>(s_abs);
-    const unsigned* c4 = reinterpret_cast<const unsigned*>(s_code);
-    for (int i = tid; i < ROWS / 4; i += THREADS) {
-      reinterpret_cast<unsigned*>(p.absorbing + row0)[i] = a4[i];
-      if (p.fall_code) reinterpret_cast<unsigned*>(p.fall_code + row0)[i] = c4[i];
+// ------------------------------------------------------------------------------------
+// Fast path: compile-time robot dimensions, full 16-B-aligned tiles only, PERSISTENT
+// workgroups.  Setup (tables, per-lane source offsets, thresholds) is paid once per
+// workgroup; per tile the body is: land prefetched registers in LDS -> barrier -> issue the
+// next tile's loads (in flight during the rest) -> per-row tests -> dense obs sweep -> dense
+// ctrl sweep -> barrier.  No tail handling, no table lookups in the sweeps.
+// ------------------------------------------------------------------------------------
+template <int ROWS, class D, bool OBS64, bool CTRL64>
+__global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
+  static_assert(D::is_static, "tile kernel needs compile-time dimensions");
+  static_assert(ROWS % 64 == 0 && ROWS <= THREADS, "ROWS: whole waves, at most one row per lane");
+  constexpr int NQ = D::nq, NV = D::nv, NA = D::n_act, NU = D::nu, NO = D::n_obs;
+  static_assert(D::n_grf == 0, "fast path: no foot-force columns");
+  constexpr int CQ = ROWS * NQ / 2, CV = ROWS * NV / 2, CA = ROWS * NA / 4;  // 16-B chunks
+  constexpr int KQ = (CQ + THREADS - 1) / THREADS, KV = (CV + THREADS - 1) / THREADS,
+                KA = (CA + THREADS - 1) / THREADS;
+  constexpr int OW = OBS64 ? 2 : 4;                 // obs values per lane store
+  static_assert((THREADS * OW) % NO == 0, "fast path: lane-invariant obs columns");
+  constexpr int NIT = (ROWS * NO / OW) / THREADS;   // obs stores per lane per tile
+  static_assert((ROWS * NO / OW) % THREADS == 0, "obs sweep must tile evenly");
+  constexpr int CW = CTRL64 ? 2 : 4;                // ctrl values per lane store
+  constexpr int NCV = ROWS * NU / CW;               // ctrl vectors per tile
+  constexpr int NCI = (NCV + THREADS - 1) / THREADS;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  double* sq = reinterpret_cast<double*>(lds);                                  // [ROWS][NQ]
+  double* sv = sq + ROWS * NQ;                                                  // [ROWS][NV]
+  float* sa = reinterpret_cast<float*>(lds + (size_t)ROWS * (NQ + NV) * 8);     // [ROWS][NA]
+  double* t_act = reinterpret_cast<double*>(lds + (size_t)ROWS * (NQ + NV) * 8 + (size_t)ROWS * NA * 4);
+  const IlDev* __restrict__ md = p.md;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool with_ctrl = p.ctrl != nullptr;
+
+  auto col_off = [&](int sidx) -> int { return sidx < NQ ? sidx : ROWS * NQ + (sidx - NQ); };
+  auto col_str = [&](int sidx) -> int { return sidx < NQ ? NQ : NV; };
+
+  // ---- once per workgroup
+  for (int j = tid; j < NU; j += THREADS) {   // per ACTUATOR: mean | delta | lo | hi
+    const int k = md->ctrl_src[j];
+    const int kk = k < 0 ? 0 : k;
+    t_act[j] = md->act_mean[kk];
+    t_act[NU + j] = md->act_delta[kk];
+    t_act[2 * NU + j] = md->ctrl_lo[kk];
+    t_act[3 * NU + j] = md->ctrl_hi[kk];
+  }
+  int my_off[OW], my_str[OW];                 // obs columns of this lane
+  {
+    const int c0 = (tid * OW) % NO;
+#pragma unroll
+    for (int k = 0; k < OW; ++k) {
+      const int sidx = md->src[c0 + k];
+      my_off[k] = col_off(sidx);
+      my_str[k] = col_str(sidx);
     }
-  } else {
-    for (int r = tid; r < rows; r += THREADS) {
-      p.absorbing[row0 + r] = s_abs[r];
-      if (p.fall_code) p.fall_code[row0 + r] = s_code[r];
+  }
+  const int my_r0 = tid * OW / NO;            // first row of this lane in the obs sweep
+  constexpr int RSTEP = THREADS * OW / NO;
+  int c_aidx[NCI][CW];                        // ctrl elements of this lane: LDS index of the
+  int c_j[NCI][CW];                           // action value (-1: actuator not driven), actuator
+#pragma unroll
+  for (int it = 0; it < NCI; ++it)
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+      const int e = (tid + it * THREADS) * CW + q;
+      const int r = e / NU, j = e - r * NU;
+      int k = -1;
+      if (e < ROWS * NU) k = md->ctrl_src[j];
+      c_j[it][q] = j;
+      c_aidx[it][q] = k < 0 ? -1 : r * NA + k;
     }
+  // per-row tests: wave-uniform thresholds; unused slots can never trigger
+  const int nf = md->n_fall;
+  int f_off[FAST_FALL], f_str[FAST_FALL];
+  double f_lo[FAST_FALL], f_hi[FAST_FALL];
+#pragma unroll
+  for (int k = 0; k < FAST_FALL; ++k) {
+    const int kk = k < nf ? k : 0;
+    const int sidx = md->fall_sidx[kk];
+    f_off[k] = col_off(sidx);
+    f_str[k] = col_str(sidx);
+    f_lo[k] = k < nf ? md->fall_lo[kk] : -__builtin_huge_val();
+    f_hi[k] = k < nf ? md->fall_hi[kk] : __builtin_huge_val();
+  }
+  const int rt = md->reward_type;
+  const int rew_off = col_off(md->reward_sidx), rew_str = col_str(md->reward_sidx);
+  const double tvel = md->target_velocity;
+  const int use_abs = md->use_absorbing;
+  auto rew_f = [&](double s) -> float {
+    if (rt == OLY_REWARD_TARGET_VELOCITY) {
+      const double dv = s - tvel;
+      return (float)exp(-(dv * dv));
+    }
+    return (float)s;  // PosReward
+  };
+
+  const long ntiles = p.tile0;  // number of full tiles
+  u32x4 rq[KQ], rv[KV], ra[KA];
+  auto issue_loads = [&](long t) {
+    const long r0 = t * ROWS;
+    const u32x4* gq = reinterpret_cast<const u32x4*>(p.qpos + r0 * NQ) + tid;
+    const u32x4* gv = reinterpret_cast<const u32x4*>(p.qvel + r0 * NV) + tid;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+      if (k * THREADS + THREADS <= CQ || tid + k * THREADS < CQ) rq[k] = gq[k * THREADS];
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+      if (k * THREADS + THREADS <= CV || tid + k * THREADS < CV) rv[k] = gv[k * THREADS];
+    if (with_ctrl) {
+      const u32x4* ga = reinterpret_cast<const u32x4*>(p.action + r0 * NA) + tid;
+#pragma unroll
+      for (int k = 0; k < KA; ++k)
+        if (k * THREADS + THREADS <= CA || tid + k * THREADS < CA) ra[k] = ga[k * THREADS];
+    }
+  };
+
+  long tile = blockIdx.x;
+  if (tile < ntiles) issue_loads(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long row0 = tile * ROWS;
+    // ---- land this tile (global order == LDS order)
+    {
+      u32x4* lq = reinterpret_cast<u32x4*>(sq) + tid;
+      u32x4* lv = reinterpret_cast<u32x4*>(sv) + tid;
+      u32x4* la = reinterpret_cast<u32x4*>(sa) + tid;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k)
+        if (k * THREADS + THREADS <= CQ || tid + k * THREADS < CQ) lq[k * THREADS] = rq[k];
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+        if (k * THREADS + THREADS <= CV || tid + k * THREADS < CV) lv[k * THREADS] = rv[k];
+      if (with_ctrl) {
+#pragma unroll
+        for (int k = 0; k < KA; ++k)
+          if (k * THREADS + THREADS <= CA || tid + k * THREADS < CA) la[k * THREADS] = ra[k];
+      }
+    }
+    __syncthreads();
+    // ---- the next tile's loads fly while this one is processed
+    const long next = tile + gridDim.x;
+    if (next < ntiles) issue_loads(next);
+
+    // ---- per-row scalars (waves 0 .. ROWS/64-1): fall tests, reward of the NEXT step, flags
+    if (tid < ROWS) {
+      const int r = tid;
+      const long gr = row0 + r;
+      double fv[FAST_FALL];
+#pragma unroll
+      for (int k = 0; k < FAST_FALL; ++k) fv[k] = sq[f_off[k] + r * f_str[k]];
+      const double x = sq[rew_off + r * rew_str];
+      unsigned code = 0;
+#pragma unroll
+      for (int k = FAST_FALL - 1; k >= 0; --k)
+        if (fv[k] < f_lo[k] || fv[k] > f_hi[k]) code = (unsigned)(k + 1);  // lowest k wins
+      const unsigned ab = (code != 0 && use_abs) ? 1u : 0u;
+      if (rt == OLY_REWARD_NONE) {
+        p.reward[gr] = 0.0f;
+      } else {
+        // step-0 rows read the carried state BEFORE the last-step row of the same env could
+        // overwrite it (prev_in may alias prev_out only when T == 1: same lane, this order)
+        if (gr < p.N) p.reward[gr] = rew_f(p.prev_in[gr]);
+        if (gr + p.N < p.R)
+          p.reward[gr + p.N] = rew_f(x);     // reward(t+1) reads obs(t), utils/reward.py:73
+        else
+          p.prev_out[gr - (p.R - p.N)] = x;  // self._obs of the last step
+      }
+      // flags: 4 rows per dword (lane i < 16 gathers lanes 4i .. 4i+3 of its wave)
+      unsigned a4 = 0, c4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int srcl = (lane & 15) * 4 + k;
+        a4 |= (unsigned)__shfl((int)ab, srcl, 64) << (8 * k);
+        c4 |= (unsigned)__shfl((int)code, srcl, 64) << (8 * k);
+      }
+      if (lane < 16) {
+        const long q4 = (row0 + (r - lane)) / 4 + lane;
+        reinterpret_cast<unsigned*>(p.absorbing)[q4] = a4;
+        if (p.fall_code) reinterpret_cast<unsigned*>(p.fall_code)[q4] = c4;
+      }
+    }
+
+    // ---- observation tile: NIT dense vector stores per lane, one LDS round trip
+    {
+      double v[NIT][OW];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int k = 0; k < OW; ++k) v[it][k] = sq[my_off[k] + (my_r0 + it * RSTEP) * my_str[k]];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (OBS64) {
+          double2 o;
+          o.x = v[it][0]; o.y = v[it][OW - 1];
+          reinterpret_cast<double2*>(static_cast<double*>(p.obs) + row0 * NO)[tid + it * THREADS] = o;
+        } else {
+          float4 o;
+          o.x = (float)v[it][0]; o.y = (float)v[it][1 % OW];
+          o.z = (float)v[it][2 % OW]; o.w = (float)v[it][3 % OW];
+          reinterpret_cast<float4*>(static_cast<float*>(p.obs) + row0 * NO)[tid + it * THREADS] = o;
+        }
+      }
+    }
+
+    // ---- control tile: un-normalise in fp64, clamp to ctrlrange, actuator order
+    if (with_ctrl) {
+#pragma unroll
+      for (int it = 0; it < NCI; ++it) {
+        const int i = tid + it * THREADS;
+        if (it * THREADS + THREADS <= NCV || i < NCV) {
+          double u[CW];
+#pragma unroll
+          for (int q = 0; q < CW; ++q) {
+            const int ai = c_aidx[it][q], j = c_j[it][q];
+            const double a = (double)sa[ai < 0 ? 0 : ai];
+            double x = a * t_act[NU + j] + t_act[j];
+            const double lo = t_act[2 * NU + j], hi = t_act[3 * NU + j];
+            if (x < lo) x = lo;
+            if (x > hi) x = hi;
+            u[q] = ai < 0 ? 0.0 : x;
+          }
+          if (CTRL64) {
+            double2 o;
+            o.x = u[0]; o.y = u[CW - 1];
+            reinterpret_cast<double2*>(static_cast<double*>(p.ctrl) + row0 * NU)[i] = o;
+          } else {
+            float4 o;
+            o.x = (float)u[0]; o.y = (float)u[1 % CW]; o.z = (float)u[2 % CW]; o.w = (float)u[3 % CW];
+            reinterpret_cast<float4*>(static_cast<float*>(p.ctrl) + row0 * NU)[i] = o;
+          }
+        }
+      }
+    }
+    __syncthreads();  // all LDS reads of this tile are done before the next one lands
   }
 }
 
 using H1Dims = StaticDims<17, 17, 0, 11, 11, 32>;
 
 template <int ROWS, class D>
-int launch(oly_ctx* ctx, const IlArgs& a, int out_flags, hipStream_t s) {
+int launch_generic(oly_ctx* ctx, IlArgs a, long tile0, int out_flags, hipStream_t s) {
   const IlDev& h = ctx->il_host;
   Carve<ROWS, D> cv(h.nq, h.nv, h.n_grf, h.n_act, h.nu, h.n_obs);
-  const long tiles = (a.R + ROWS - 1) / ROWS;
+  const long tiles = (a.R + ROWS - 1) / ROWS - tile0;
+  if (tiles <= 0) return OLY_OK;
   if (tiles > 0x7fffffffL) OLY_FAIL(ctx, OLY_EINVAL, "oly_il_step: too many rows");
+  a.tile0 = tile0;
   dim3 grid((unsigned)tiles), block(THREADS);
   const bool o64 = out_flags & OLY_OUT_OBS_F64, c64 = out_flags & OLY_OUT_CTRL_F64;
 #define OLY_K1(O, C_)                                                                       \
@@ -294,6 +686,41 @@ int launch(oly_ctx* ctx, const IlArgs& a, int out_flags, hipStream_t s) {
   else OLY_K1(false, false);
 #undef OLY_K1
   OLY_LAUNCH_CHECK(ctx, "il_step_kernel");
+  return OLY_OK;
+}
+
+// Full aligned tiles through the persistent tile kernel, the ragged remainder (< ROWS rows)
+// through the generic kernel.
+template <int ROWS, class D>
+int launch_fast(oly_ctx* ctx, IlArgs a, int out_flags, int wg_per_cu, hipStream_t s) {
+  const long nfull = a.R / ROWS;
+  if (nfull > 0) {
+    const int lds = ROWS * (D::nq + D::nv) * 8 + ROWS * D::n_act * 4 + 4 * D::nu * 8;
+    int per_cu = (160 * 1024) / lds;
+    if (per_cu > 8) per_cu = 8;
+    if (wg_per_cu > 0) per_cu = wg_per_cu;
+    long want = (long)ctx->num_cu * per_cu;
+    if (want > nfull) want = nfull;
+    IlArgs b = a;
+    b.tile0 = nfull;
+    dim3 grid((unsigned)want), block(THREADS);
+    const bool o64 = out_flags & OLY_OUT_OBS_F64, c64 = out_flags & OLY_OUT_CTRL_F64;
+#define OLY_K1T(O, C_)                                                                      \
+  do {                                                                                      \
+    auto k = il_tile_kernel<ROWS, D, O, C_>;                                                \
+    if (lds > 48 * 1024)                                                                    \
+      OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));   \
+    hipLaunchKernelGGL(k, grid, block, lds, s, b);                                          \
+  } while (0)
+    if (o64 && c64) OLY_K1T(true, true);
+    else if (o64) OLY_K1T(true, false);
+    else if (c64) OLY_K1T(false, true);
+    else OLY_K1T(false, false);
+#undef OLY_K1T
+    OLY_LAUNCH_CHECK(ctx, "il_tile_kernel");
+  }
+  if (nfull * ROWS < a.R) return launch_generic<ROWS, D>(ctx, a, nfull, out_flags, s);
   return OLY_OK;
 }
 
@@ -344,7 +771,9 @@ extern "C" int oly_il_configure(oly_ctx* ctx, const oly_il_model* m) {
     if (m->fall_idx[k] < 0 || m->fall_idx[k] >= n_obs)
       OLY_FAIL(ctx, OLY_ERANGE, "fall_idx[%d]=%d outside [0,%d)", k, m->fall_idx[k], n_obs);
     h.fall_idx[k] = m->fall_idx[k]; h.fall_lo[k] = m->fall_lo[k]; h.fall_hi[k] = m->fall_hi[k];
+    h.fall_sidx[k] = h.src[m->fall_idx[k]];
   }
+  h.reward_sidx = (h.reward_type != OLY_REWARD_NONE) ? h.src[h.reward_idx] : 0;
   for (int j = 0; j < m->nu; ++j) h.ctrl_src[j] = -1;
   for (int k = 0; k < m->n_act; ++k) {
     const int j = m->act_to_ctrl[k];
@@ -388,7 +817,14 @@ extern "C" int oly_il_step(oly_ctx* ctx, int T, int N, const double* qpos, const
   a.fast = al16(qpos) && al16(qvel) && al16(action) && al16(grf_mean) && al16(obs) && al16(ctrl) &&
            ((reinterpret_cast<uintptr_t>(absorbing) & 3) == 0) &&
            ((reinterpret_cast<uintptr_t>(fall_code) & 3) == 0);
+  a.tile0 = 0;
   const bool is_h1 = h.nq == 17 && h.nv == 17 && h.n_grf == 0 && h.n_act == 11 && h.nu == 11 && h.n_obs == 32;
-  if (is_h1) return launch<128, H1Dims>(ctx, a, out_flags, oly_s(stream));
-  return launch<64, DynDims>(ctx, a, out_flags, oly_s(stream));
+  if (is_h1 && a.fast && h.n_fall <= FAST_FALL) {
+    static const int rows_env = [] { const char* e = getenv("OLY_K1_ROWS"); return e ? atoi(e) : 0; }();
+    static const int wg_env = [] { const char* e = getenv("OLY_K1_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    if (rows_env == 128) return launch_fast<128, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
+    if (rows_env == 256) return launch_fast<256, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
+    return launch_fast<64, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
+  }
+  return launch_generic<64, DynDims>(ctx, a, 0, out_flags, oly_s(stream));
 }

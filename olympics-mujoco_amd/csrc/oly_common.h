@@ -15,12 +15,12 @@
 
 struct IlDev {
   int nq, nv, n_pos, n_vel, n_drop, n_grf, n_act, nu, n_obs, n_fall;
-  int reward_type, reward_idx, use_absorbing, pad0;
+  int reward_type, reward_idx, use_absorbing, reward_sidx;  // *_sidx: staged-row element
   double target_velocity;
   // created-observation column c reads staged row element src[c]; the staged row is
   // [qpos (nq) | qvel (nv) | grf (n_grf)] and grf columns are divided by 1000.
   short src[OLY_MAX_OBS];
-  int fall_idx[OLY_MAX_FALL];
+  int fall_idx[OLY_MAX_FALL], fall_sidx[OLY_MAX_FALL];
   double fall_lo[OLY_MAX_FALL], fall_hi[OLY_MAX_FALL];
   short ctrl_src[OLY_MAX_ACT];  // actuator j <- action slot, or -1
   double act_mean[OLY_MAX_ACT], act_delta[OLY_MAX_ACT], ctrl_lo[OLY_MAX_ACT], ctrl_hi[OLY_MAX_ACT];

@@ -9,7 +9,7 @@ import os
 from . import _abi
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libolympic_hip.so")
+LIB_PATH = os.environ.get("OLYMPIC_HIP_LIB") or os.path.join(_PKG_DIR, "lib", "libolympic_hip.so")
 
 
 class OlyError(RuntimeError):
