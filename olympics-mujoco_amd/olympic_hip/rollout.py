@@ -1,0 +1,124 @@
+"""Vectorised rollout post-processing for PPO and GAIL/VAIL on the GPU.
+
+Reference semantics (file:line under the reference tree):
+  PPOBuffer.store / finish_path       rl/algos/ppo.py:56-84     -> RolloutBuffer + oly_return_scan(RETURN)
+  PPO.sample loop                     rl/algos/ppo.py:150-198   -> collect()
+  advantage normalisation             rl/algos/ppo.py:335-336   -> oly_adv_stats/normalize (ddof 1, eps)
+  compute_gae + normalisation (GAIL)  gail_TRPO.py:126-128      -> oly_return_scan(GAE) (ddof 0, 1e-8)
+
+The reference runs n_proc single-env workers, each sampling episodes back to back; here N
+environments advance in lock step for T steps and the episode structure is carried by a
+flags tensor (ABSORBING = terminal, LAST = segment end).  Per-env semantics are identical.
+With several ranks the environments are sharded and the normalisation statistics are the
+only thing exchanged (dist.global_stats).
+"""
+import torch
+
+from . import _abi, dist as odist
+
+
+class RolloutBuffer:
+    """[T,N] device storage of one rollout block (what PPOBuffer keeps as python lists)."""
+
+    def __init__(self, T, N, obs_dim, act_dim, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.T, self.N = T, N
+        self.states = torch.empty((T, N, obs_dim), **f32)
+        self.actions = torch.empty((T, N, act_dim), **f32)
+        self.rewards = torch.empty((T, N), **f32)
+        self.values = torch.empty((T, N), **f32)
+        self.next_values = torch.zeros((T, N), **f32)
+        self.flags = torch.zeros((T, N), dtype=torch.uint8, device=device)
+        self.returns = torch.empty((T, N), **f32)
+        self.advantages = torch.empty((T, N), **f32)
+        self.ptr = 0
+
+    def store(self, state, action, reward, value):
+        t = self.ptr
+        self.states[t], self.actions[t], self.rewards[t], self.values[t] = state, action, reward, value
+        self.ptr += 1
+
+    def __len__(self):
+        return self.ptr * self.N
+
+    def episode_stats(self):
+        """ep_returns / ep_lens of the segments that END inside the block (logging only)."""
+        last = (self.flags & _abi.FLAG_LAST).bool()
+        last[-1] = True
+        r = self.rewards.double()
+        csum = torch.cumsum(r, dim=0)
+        ep_returns, ep_lens = [], []
+        lh = last.cpu()
+        ch = csum.cpu()
+        for n in range(self.N):
+            start, base = 0, 0.0
+            for t in torch.nonzero(lh[:, n]).flatten().tolist():
+                ep_returns.append(float(ch[t, n]) - base)
+                ep_lens.append(t + 1 - start)
+                start, base = t + 1, float(ch[t, n])
+        return ep_returns, ep_lens
+
+
+class PPORollout:
+    """finish_path + advantage normalisation for a whole [T,N] block on the device."""
+
+    def __init__(self, engine, gamma=0.99, lam=0.95, eps=1e-5):
+        self.eng, self.gamma, self.lam, self.eps = engine, gamma, lam, eps
+        self._stats = torch.empty(3, dtype=torch.float64, device=engine.device)
+
+    def finish(self, buf, normalize=True):
+        """returns, advantages (normalised in place when `normalize`)."""
+        self.eng.return_scan(_abi.SCAN_RETURN, self.gamma, self.lam, buf.rewards, buf.values,
+                             buf.next_values, buf.flags, buf.returns, buf.advantages)
+        if normalize:
+            self.normalize(buf.advantages, ddof=1, eps=self.eps)
+        return buf.returns, buf.advantages
+
+    def normalize(self, adv, ddof, eps):
+        self.eng.adv_stats(adv, self._stats)
+        total = odist.global_stats(self._stats)          # 24 B per rank over RCCL / xGMI
+        self.eng.adv_normalize(adv, total.contiguous(), ddof, eps)
+        return adv
+
+
+class GAERollout(PPORollout):
+    """compute_gae(V, x, xn, r, absorbing, last, gamma, lam) + GAIL's normalisation."""
+
+    def finish(self, buf, normalize=True):
+        self.eng.return_scan(_abi.SCAN_GAE, self.gamma, self.lam, buf.rewards, buf.values,
+                             buf.next_values, buf.flags, buf.returns, buf.advantages)
+        if normalize:
+            self.normalize(buf.advantages, ddof=0, eps=1e-8)
+        return buf.returns, buf.advantages
+
+
+@torch.no_grad()
+def collect(env, policy, critic, buf, max_traj_len, deterministic=False):
+    """PPO.sample for N environments in lock step (rl/algos/ppo.py:169-196).
+
+    env: VecLocoEnv-like (reset(env_mask)->obs, step(a)->(obs,r,done,info)); policy/critic:
+    torch modules mapping [N,obs] -> [N,act] / [N,1].  An episode segment ends when the env
+    reports done, when it reaches max_traj_len (bootstrapped with V(next state), :195-196) or
+    at the end of the block."""
+    T, N = buf.T, buf.N
+    dev = buf.rewards.device
+    state = env.reset().to(torch.float32)
+    traj_len = torch.zeros(N, dtype=torch.int32, device=dev)
+    buf.ptr = 0
+    buf.flags.zero_()
+    for t in range(T):
+        action = policy(state) if deterministic else policy(state)
+        value = critic(state).reshape(N)
+        next_state, reward, done, _ = env.step(action)
+        next_state = next_state.to(torch.float32)
+        buf.store(state, action, reward.to(torch.float32), value)
+        traj_len += 1
+        done = done.bool()
+        cut = done | (traj_len >= max_traj_len) | (t == T - 1)
+        buf.next_values[t] = critic(next_state).reshape(N)
+        buf.flags[t] = (cut.to(torch.uint8) * _abi.FLAG_LAST) | (done.to(torch.uint8) * _abi.FLAG_ABSORBING)
+        if bool(cut.any()) and t < T - 1:
+            next_state = torch.where(cut.unsqueeze(1), env.reset(env_mask=cut).to(torch.float32), next_state)
+            traj_len = torch.where(cut, torch.zeros_like(traj_len), traj_len)
+        state = next_state
+    return buf

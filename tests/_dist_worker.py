@@ -1,0 +1,39 @@
+"""Worker of test_adv_stats_allgather_two_ranks_gloo: CPU/gloo rehearsal of the N>1 path.
+The statistics kernel itself needs a GPU; here the local (count,sum,sumsq) triple is formed
+with torch on the CPU and everything downstream (shard_range, all-gather, combine,
+normalise) is the product's host logic."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "olympics-mujoco_amd"))
+from olympic_hip import dist as odist  # noqa: E402
+
+
+def main():
+    out = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    T, N = 50, 1001
+    adv = np.random.default_rng(0).normal(0.2, 1.7, (T, N)).astype(np.float32)
+    lo, hi = odist.shard_range(N)
+    mine = torch.as_tensor(adv[:, lo:hi]).double()
+    stats = torch.tensor([mine.numel(), mine.sum().item(), (mine * mine).sum().item()], dtype=torch.float64)
+    total = odist.global_stats(stats)
+    res = {"total": total.numpy()}
+    for ddof, eps, key in ((1, 1e-5, "ppo"), (0, 1e-8, "gail")):
+        mean, std = odist.mean_std_from_stats(total, ddof)
+        res[key] = ((mine - mean) / (std + eps)).float().numpy()
+    np.savez(os.path.join(out, f"rank{rank}.npz"), **res)
+    if rank == 0:
+        np.save(os.path.join(out, "full.npy"), adv.astype(np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

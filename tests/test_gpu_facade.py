@@ -1,0 +1,200 @@
+"""GPU tests of the host facade: the reference's env API (make/reset/step/
+play_trajectory_from_velocity/create_dataset), the vectorised PPO rollout post-processing and
+the VAIL discriminator reward, each against the oracle / golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from olympic_hip import _abi, specs
+from helpers import h1_rows_from_full, h1_synthetic_block, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+# ----------------------------------------------------------------- config 1: plumbing, N = 1
+def test_make_reset_step_single_env(oracle):
+    from olympic_hip.envs import LocoEnvBase
+    env = LocoEnvBase.make("UnitreeH1.walk.real", seed=3)
+    assert env.info.observation_space.shape == (32,) and env.info.action_space.shape == (11,)
+    assert env.info.gamma == 0.99 and env.info.horizon == 1000 and env.dt == 0.01
+    obs = env.reset()
+    assert obs.shape == (32,) and obs.dtype == np.float64
+    # the reset observation is the trajectory sample minus x,y (loco_env_base.py:603, 737)
+    smp = host(env.vec._sample)[0]
+    assert np.array_equal(obs, smp[2:34])
+    assert smp[0] == 0.0 and smp[1] == 0.0                       # x,y re-zeroed at the reset step
+    prev_x = obs[15]
+    o2, r, absorbing, info = env.step(np.zeros(11))
+    assert isinstance(r, float) and isinstance(absorbing, bool) and info == {}
+    # kinematic stand-in: state unchanged, reward reads the PREVIOUS obs (utils/reward.py:73)
+    assert np.array_equal(o2, obs)
+    assert abs(r - np.exp(-np.square(prev_x - 1.25))) <= 1.2e-7
+    assert env.get_obs_idx("dq_pelvis_tx") == [15] and len(env.get_kinematic_obs_mask()) == 32
+    ds = env.create_dataset()
+    n = env.vec.trajectories.trajectory_length * env.vec.trajectories.number_of_trajectories
+    assert ds["states"].shape == (n - 1, 32) and ds["last"].sum() == 2
+
+
+def test_play_trajectory_from_velocity_matches_host_replay(oracle):
+    """500 replay steps: device cursor + Euler integration + obs/has-fallen equal the
+    reference algorithm (loco_env_base.py:505-542) evaluated on the host with the oracle."""
+    from olympic_hip.envs import LocoEnvBase
+    env = LocoEnvBase.make("UnitreeH1.walk.real", seed=11)
+    sp = env.spec
+    obs_rec, fallen = env.play_trajectory_from_velocity(n_episodes=1, n_steps_per_episode=500)
+    assert obs_rec.shape == (500, 1, 32)
+    tr = env.vec.trajectories
+    table = tr.table
+    # host replay with the same reset indices (seed 11 -> first draw)
+    rng = np.random.default_rng(11)
+    L, J = tr.trajectory_length, tr.number_of_trajectories
+    exp = []
+    tn, st = rng.integers(0, J, 1), rng.integers(0, L, 1)
+    ct, cs, org, smp = oracle.traj_reset(table, tn, st)
+    cur = smp[:, :17].copy()
+    for _ in range(500):
+        smp = oracle.traj_euler(17, 0.01, cur, smp)
+        cur = smp[:, :17].copy()
+        cs, smp, at_end = oracle.traj_next(table, ct, cs, org, smp)
+        if at_end[0]:
+            tn, st = rng.integers(0, J, 1), rng.integers(0, L, 1)
+            ct, cs, org, smp = oracle.traj_reset(table, tn, st)
+            cur = smp[:, :17].copy()
+        exp.append(smp[0, 2:34].copy())
+    assert np.array_equal(host(obs_rec)[:, 0], np.array(exp))
+    assert not host(fallen).any()                                  # the synthetic gait never falls
+
+
+def test_vec_env_matches_oracle_over_an_episode(oracle):
+    """N = 4096 replayed synthetic physics, 20 steps: obs/reward/absorbing per step equal the
+    oracle's [T,N] block evaluation (config 2 per-step regime)."""
+    from olympic_hip.envs import ReplayPhysics, VecLocoEnv
+    sp = specs.unitree_h1("walk")
+    T, N = 20, 4096
+    qpos, qvel, act = h1_synthetic_block(sp, T, N, seed=77, fall_frac="wide")
+    phys = ReplayPhysics(sp, torch.as_tensor(qpos).cuda(), torch.as_tensor(qvel).cuda())
+    env = VecLocoEnv(sp, N, device=0, physics=phys, random_start=False)
+    prev0 = np.zeros(N)
+    ref = oracle.il_step(sp, qpos, qvel, act, prev0)
+    env._prev.zero_()
+    for t in range(T):
+        o, r, a, info = env.step(torch.as_tensor(act[t]).cuda())
+        assert np.array_equal(host(o), ref["obs"][t])
+        assert np.array_equal(host(a), ref["absorbing"][t].astype(bool))
+        assert ulp_diff(host(r), ref["reward"][t]).max() <= 1
+        assert np.array_equal(host(info["ctrl"]), ref["ctrl"][t])
+    assert int(env.episode_steps[0]) == T
+
+
+# ----------------------------------------------------------------- config 3: PPO post-processing
+def test_ppo_rollout_block(oracle):
+    from olympic_hip.engine import Engine
+    from olympic_hip.rollout import PPORollout, RolloutBuffer
+    eng = Engine(0)
+    T, N = 400, 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    buf = RolloutBuffer(T, N, 41, 12, eng.device)
+    buf.rewards.uniform_(-0.3, 1.0, generator=g)
+    buf.values.normal_(0, 1, generator=g)
+    buf.next_values.normal_(0, 1, generator=g)
+    ends = torch.rand((T, N), device="cuda", generator=g) < 1 / 300
+    dones = ends & (torch.rand((T, N), device="cuda", generator=g) < 0.7)
+    buf.flags.copy_((ends.to(torch.uint8) * _abi.FLAG_LAST) | (dones.to(torch.uint8) * _abi.FLAG_ABSORBING))
+    buf.ptr = T
+    pr = PPORollout(eng, gamma=0.99, lam=0.95, eps=1e-5)
+    ret, adv = pr.finish(buf, normalize=False)
+    e_ret, e_adv = oracle.return_scan(_abi.SCAN_RETURN, 0.99, 0.95, host(buf.rewards), host(buf.values),
+                                      host(buf.next_values), host(buf.flags))
+    assert np.array_equal(host(ret), e_ret) and np.array_equal(host(adv), e_adv)     # bit-exact
+    raw = adv.clone()
+    pr.normalize(adv, ddof=1, eps=1e-5)
+    ref = (raw - raw.mean()) / (raw.std() + 1e-5)            # the reference's torch expression
+    assert (adv - ref).abs().max().item() < 5e-5
+    assert abs(adv.mean().item()) < 1e-5 and abs(adv.std().item() - 1) < 1e-4
+    er, el = buf.episode_stats()
+    assert len(er) == len(el) == int((ends | (torch.arange(T, device="cuda") == T - 1).unsqueeze(1)).sum())
+    assert sum(el) == T * N
+
+
+def test_collect_with_torch_policy(oracle):
+    """PPO.sample in lock step: flags/next_values bookkeeping around resets and time limits."""
+    from olympic_hip.envs import VecLocoEnv
+    from olympic_hip.rollout import PPORollout, RolloutBuffer, collect
+    from olympic_hip.trajectory import Trajectory, synthetic_h1_trajectory_files
+    sp = specs.unitree_h1("walk")
+    files = synthetic_h1_trajectory_files(sp, n_traj=2, length=500)
+    low = np.concatenate([sp.joint_lo, -np.inf * np.ones(17)])
+    high = np.concatenate([sp.joint_hi, np.inf * np.ones(17)])
+    low[:6], high[:6] = -np.inf, np.inf
+    tr = Trajectory(keys=list(sp.obs_keys), low=low[2:], high=high[2:], joint_pos_idx=np.arange(17),
+                    traj_files=files, clip_trajectory_to_joint_ranges=True, warn=False)
+    N, T = 256, 24
+    env = VecLocoEnv(sp, N, device=0, trajectory=tr, seed=2)
+    torch.manual_seed(0)
+    policy = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.Tanh(), torch.nn.Linear(64, 11)).cuda()
+    critic = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.Tanh(), torch.nn.Linear(64, 1)).cuda()
+    buf = RolloutBuffer(T, N, 32, 11, env.device)
+    collect(env, policy, critic, buf, max_traj_len=10)
+    fl = host(buf.flags)
+    assert (fl[9] & _abi.FLAG_LAST).all() and (fl[19] & _abi.FLAG_LAST).all() and (fl[T - 1] & _abi.FLAG_LAST).all()
+    assert not (fl & _abi.FLAG_ABSORBING).any()                     # kinematic stand-in never falls
+    assert not (fl[[0, 5, 12]] & _abi.FLAG_LAST).any()
+    ret, adv = PPORollout(env.eng, 0.99, 0.95).finish(buf, normalize=False)
+    e_ret, _ = oracle.return_scan(_abi.SCAN_RETURN, 0.99, 0.95, host(buf.rewards), host(buf.values),
+                                  host(buf.next_values), fl)
+    assert np.array_equal(host(ret), e_ret)
+    # reward of the step right after a reset reads the RESET observation (self._obs)
+    x_reset = host(buf.states)[10, :, 15]
+    np.testing.assert_allclose(host(buf.rewards)[10], np.exp(-(x_reset.astype(np.float64) - 1.25) ** 2), rtol=3e-6)
+
+
+# ----------------------------------------------------------------- config 4: VAIL reward
+def test_vail_discriminator_reward_matches_reference(golden):
+    from olympic_hip.engine import Engine
+    from olympic_hip.gail import DiscriminatorReward, VariationalDiscriminator
+    g = golden("vail_disc.npz")
+    eng = Engine(0)
+    net = VariationalDiscriminator().load_reference_arrays(g).cuda()
+    dr = DiscriminatorReward(eng, net, state_mask=np.arange(32))
+    x, eps = torch.as_tensor(g["x"]).cuda(), torch.as_tensor(g["eps"]).cuda()
+    d, mu, logvar = dr.logits(x, eps)
+    np.testing.assert_allclose(host(dr.stand.mean), g["st_mean"], rtol=2e-5, atol=2e-6)   # ref sums in f32
+    np.testing.assert_allclose(host(dr.stand.std), g["st_std"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(host(mu), g["mu"], rtol=2e-4, atol=2e-5)                 # GEMM order
+    np.testing.assert_allclose(host(d), g["d"].reshape(-1), rtol=2e-3, atol=2e-3)
+    dr2 = DiscriminatorReward(eng, net, state_mask=np.arange(32))
+    r = host(dr2(x, eps))
+    ok = np.abs(g["d"].reshape(-1)) < 8
+    np.testing.assert_allclose(r[ok], g["reward"][ok], rtol=5e-3, atol=5e-3)
+    # the standardiser updates on EVERY forward, reward evaluation included (networks.py:68-70)
+    assert float(dr2.stand.colstats[0, 0]) == len(x)
+    dr2(x, eps)
+    assert float(dr2.stand.colstats[0, 0]) == 2 * len(x)
+
+
+def test_gail_gae_pipeline(oracle):
+    from olympic_hip.engine import Engine
+    from olympic_hip.rollout import GAERollout, RolloutBuffer
+    eng = Engine(0)
+    T, N = 250, 4096
+    g = torch.Generator(device="cuda").manual_seed(9)
+    buf = RolloutBuffer(T, N, 32, 11, eng.device)
+    buf.rewards.uniform_(0, 3, generator=g)
+    buf.values.normal_(0, 1, generator=g)
+    buf.next_values.normal_(0, 1, generator=g)
+    last = torch.rand((T, N), device="cuda", generator=g) < 1 / 100
+    ab = last & (torch.rand((T, N), device="cuda", generator=g) < 0.5)
+    buf.flags.copy_((last.to(torch.uint8) * _abi.FLAG_LAST) | (ab.to(torch.uint8) * _abi.FLAG_ABSORBING))
+    gr = GAERollout(eng, gamma=0.99, lam=0.97)
+    ret, adv = gr.finish(buf, normalize=False)
+    e_ret, e_adv = oracle.return_scan(_abi.SCAN_GAE, 0.99, 0.97, host(buf.rewards), host(buf.values),
+                                      host(buf.next_values), host(buf.flags))
+    assert np.array_equal(host(adv), e_adv) and np.array_equal(host(ret), e_ret)
+    raw = host(adv).astype(np.float64)
+    gr.normalize(adv, ddof=0, eps=1e-8)
+    ref = (raw - raw.mean()) / (raw.std() + 1e-8)                  # gail_TRPO.py:128 (numpy, biased)
+    np.testing.assert_allclose(host(adv), ref, rtol=2e-5, atol=2e-6)

@@ -1,0 +1,272 @@
+"""CPU tests of the host side: spec tables, trajectory preprocessing, wrappers, registry,
+the C ABI surface, the no-fallback rule and the multi-process statistics exchange."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from olympic_hip import _abi, specs
+from olympic_hip.trajectory import Trajectory
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_H1_XML = "/root/reference/olympic_mujoco/environments/data/unitree_h1/h1.xml"
+
+
+# ------------------------------------------------------------------------------ specs
+def test_h1_spec_matches_reference_tables(golden):
+    g = golden("h1_tables.npz")
+    sp = specs.unitree_h1("walk")
+    assert sp.obs_keys == list(g["spec_keys"])
+    assert sp.joint_names == list(g["joint_names"])
+    assert (sp.nq, sp.nv, sp.n_pos) == (int(g["nq"]), int(g["nv"]), int(g["n_pos"]))
+    assert np.array_equal(sp.qpos_adr, g["qpos_perm"]) and np.array_equal(sp.qvel_adr, g["qvel_perm"])
+    assert sp.action_names == list(g["action_names"])
+    assert np.array_equal(sp.act_to_ctrl, g["act_to_ctrl"])
+    assert np.array_equal(sp.joint_lo, g["joint_lo"]) and np.array_equal(sp.joint_hi, g["joint_hi"])
+    assert np.array_equal(sp.ctrl_lo, g["ctrl_lo"]) and np.array_equal(sp.ctrl_hi, g["ctrl_hi"])
+    assert sp.reward_idx == int(g["x_vel_idx"]) == 15
+    assert sp.n_obs == 32 and sp.n_act == 11
+    assert np.array_equal(sp.act_delta, np.full(11, 0.95)) and not sp.act_mean.any()
+    # SURVEY 8a tables
+    assert sp.qpos_adr.tolist() == [0, 1, 2, 3, 4, 5, 16, 13, 12, 11, 14, 15, 8, 7, 6, 9, 10]
+    assert sp.act_to_ctrl.tolist() == [10, 7, 6, 5, 8, 9, 2, 1, 0, 3, 4]
+
+
+def test_h1_fall_thresholds_are_the_reference_doubles():
+    sp = specs.unitree_h1("walk")
+    pi = np.pi
+    assert [t[1:] for t in sp.fall_tests] == [(-0.3, 0.1), (-pi / 4.5, pi / 12), (-pi / 12, pi / 8),
+                                             (-pi / 8, pi / 8)]
+    assert [sp.obs_idx(t[0]) for t in sp.fall_tests] == [0, 1, 2, 3]
+    assert specs.unitree_h1("run").target_velocity == 2.5
+    with pytest.raises(ValueError):
+        specs.unitree_h1("fly")
+    with pytest.raises(NotImplementedError):
+        specs.unitree_h1("walk", reward_type="bogus")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_H1_XML), reason="reference MJCF not present (GPU box)")
+def test_tables_rederived_from_mjcf():
+    from olympic_hip.mjcf_tables import tables_from_mjcf
+    arms = specs._H1_ARM_JOINTS
+    t = tables_from_mjcf(REF_H1_XML, removed_joints=arms, removed_motors=[a + "_actuator" for a in arms])
+    sp = specs.unitree_h1("walk")
+    assert [j[0] for j in t["joints"]] == sp.joint_names and t["nq"] == sp.nq
+    adr = {j[0]: j[1] for j in t["joints"]}
+    assert [adr[k[2:]] for k in sp.obs_keys[:sp.n_pos]] == sp.qpos_adr.tolist()
+    mid = {m[0]: i for i, m in enumerate(t["motors"])}
+    assert [mid[a] for a in sp.action_names] == sp.act_to_ctrl.tolist()
+    assert all(m[3:] == (-0.95, 0.95) for m in t["motors"])
+    full = tables_from_mjcf(REF_H1_XML)
+    assert [(j[0], j[3], j[4]) for j in full["joints"]] == specs._H1_JOINTS
+    assert [(m[1], m[2]) for m in full["motors"]] == specs._H1_MOTORS
+
+
+def test_a3_spec_constants(golden):
+    g = golden("a3_task.npz")
+    sp = specs.A3Spec()
+    assert sp.period == int(g["period"]) == 88 and sp.delay_frames == int(g["delay_frames"]) == 30
+    assert np.array_equal(sp.motor_offset, g["motor_offset"])
+    s = golden("symmetry.npz")
+    assert list(sp.mirrored_obs) == s["mirrored_obs"].tolist()
+    assert list(sp.mirrored_acts) == s["mirrored_acts"].tolist()
+    assert list(sp.clock_inds) == s["clock_inds"].tolist()
+
+
+# ------------------------------------------------------------------------------ trajectory
+def _traj_from_golden(g):
+    keys = list(g["keys"])
+    files = {k: g["raw"][i] for i, k in enumerate(keys)}
+    files["split_points"] = g["raw_split_points"]
+    return Trajectory(keys=keys, low=g["low"], high=g["high"], joint_pos_idx=np.arange(17), traj_files=files,
+                      traj_dt=float(g["traj_dt"]), control_dt=float(g["control_dt"]),
+                      clip_trajectory_to_joint_ranges=True, warn=False)
+
+
+def test_trajectory_preprocessing_matches_reference(golden):
+    g = golden("trajectory.npz")
+    tr = _traj_from_golden(g)
+    assert np.array_equal(tr.table, g["table"])              # clip + split + cubic resample: bit-exact
+    assert np.array_equal(tr.split_points, g["split_points"])
+    assert tr.trajectory_length == 50 and tr.number_of_trajectories == 2
+    for (sub, tno), exp in zip(g["resets"], g["reset_samples"]):
+        s = tr.reset_trajectory(int(sub), int(tno))
+        assert np.array_equal(np.array(s, dtype=np.float64).ravel(), exp)
+    sub, tno = g["rnd_reset"]
+    s = tr.reset_trajectory(int(sub), int(tno))
+    walk = [np.array(s, dtype=np.float64).ravel()]
+    while True:
+        s = tr.get_next_sample()
+        if s is None:
+            break
+        walk.append(np.concatenate(s))
+    assert np.array_equal(np.array(walk), g["walk"])
+    ds = tr.create_dataset(ignore_keys=["q_pelvis_tx", "q_pelvis_tz"])
+    for k in ("states", "next_states", "absorbing", "last"):
+        assert np.array_equal(ds[k], g["ds_" + k]), k
+
+
+def test_trajectory_argument_errors(golden):
+    g = golden("trajectory.npz")
+    keys = list(g["keys"])
+    with pytest.raises(AssertionError):
+        Trajectory(keys=keys, traj_path=None, traj_files=None)
+    files = {k: g["raw"][i] for i, k in enumerate(keys)}
+    files["split_points"] = np.array([0, 100, 500])          # unequal lengths
+    with pytest.raises(AssertionError):
+        Trajectory(keys=keys, traj_files=files, warn=False)
+    files["split_points"] = g["raw_split_points"]
+    files[keys[3]] = files[keys[3]][:-1]
+    with pytest.raises(AssertionError):
+        Trajectory(keys=keys, traj_files=files, warn=False)
+
+
+def test_synthetic_trajectory_is_in_range_and_not_fallen():
+    from olympic_hip.trajectory import synthetic_h1_trajectory_files
+    sp = specs.unitree_h1("walk")
+    files = synthetic_h1_trajectory_files(sp, n_traj=2, length=1000, seed=0)
+    for i, k in enumerate(sp.obs_keys[:sp.n_pos]):
+        if i >= 6:
+            assert files[k].min() >= sp.joint_lo[i] and files[k].max() <= sp.joint_hi[i]
+    for key, lo, hi in sp.fall_tests:
+        assert files[key].min() > lo and files[key].max() < hi
+
+
+# ------------------------------------------------------------------------------ wrappers
+def test_symmetry_wrappers(golden):
+    from olympic_hip.wrappers import SymmetricEnv, WrapEnv, _get_symmetry_matrix
+    g = golden("symmetry.npz")
+    assert np.array_equal(_get_symmetry_matrix(g["mirrored_obs"].tolist()), g["obs_matrix"])
+    assert np.array_equal(_get_symmetry_matrix(g["mirrored_acts"].tolist()), g["act_matrix"])
+
+    class Dummy:
+        base_obs_len = 41
+    env = SymmetricEnv(Dummy, mirrored_obs=g["mirrored_obs"].tolist(), mirrored_act=g["mirrored_acts"].tolist(),
+                       clock_inds=g["clock_inds"].tolist())
+    obs, act = torch.tensor(g["obs"]), torch.tensor(g["act"])
+    assert np.array_equal(env.mirror_observation(obs).numpy(), g["obs_mirror"])     # signed permutation: exact
+    assert np.array_equal(env.mirror_action(act).numpy(), g["act_mirror"])
+    np.testing.assert_allclose(env.mirror_clock_observation(obs).numpy(), g["obs_mirror_clock"], rtol=0, atol=6e-7)  # f32 sin(arcsin(x)+pi), numpy vs torch
+    with pytest.raises(AssertionError):
+        SymmetricEnv(Dummy, mirrored_obs=[0.1, 1], mirrored_act=None)
+
+    class One:
+        def step(self, a):
+            return np.zeros(3), 1.5, False, {}
+
+        def reset(self):
+            return np.ones(3)
+    w = WrapEnv(One)
+    s, r, d, i = w.step(np.zeros((1, 2)))
+    assert s.shape == (1, 3) and r.shape == (1,) and d.shape == (1,) and w.reset().shape == (1, 3)
+
+
+# ------------------------------------------------------------------------------ registry
+def test_registry_and_name_validation():
+    from olympic_hip.envs import LocoEnvBase, UnitreeH1, ValidTaskConf, check_validity_task_mode_dataset
+    names = LocoEnvBase.get_all_task_names()
+    assert "UnitreeH1.walk.real" in names and "UnitreeH1.carry.perfect" not in names
+    with pytest.raises(ValueError, match="does not exit"):
+        UnitreeH1.generate("jump", "real")
+    with pytest.raises(ValueError, match="Dataset type"):
+        UnitreeH1.generate("walk", "imaginary")
+    with pytest.raises(ValueError, match="not combineable"):
+        check_validity_task_mode_dataset("UnitreeH1", "carry", None, "perfect", *UnitreeH1.valid_task_confs.get_all())
+    with pytest.raises(KeyError):
+        LocoEnvBase.make("NoSuchRobot.walk")
+    c = ValidTaskConf(tasks=["a", "b"], data_types=["x"])
+    assert c.get_all_combinations() == [{"task": "a", "data_type": "x"}, {"task": "b", "data_type": "x"}]
+
+
+# ------------------------------------------------------------------------------ C ABI
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "olympic_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(oly_[a-z0-9_]+)\s*\(", txt))
+
+
+def test_abi_table_matches_header():
+    assert _header_functions() == set(_abi.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    from olympic_hip import _ffi
+    if not os.path.exists(_ffi.LIB_PATH):
+        pytest.fail(f"{_ffi.LIB_PATH} missing: run python __graft_entry__.py build")
+    L = _ffi.lib()                      # binds every symbol; AttributeError on a missing one
+    for name in _abi.SIGNATURES:
+        assert hasattr(L, name)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (oly_[a-z0-9_]+)", out))
+    assert set(_abi.SIGNATURES) <= exported
+    assert L.oly_strerror(_abi.OLY_EINVAL) == b"invalid argument"
+    assert b"gfx950" in L.oly_version()
+
+
+def test_struct_layouts_match_the_header():
+    """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
+    import tempfile
+    fields = {"oly_il_model": _abi.IlModel, "oly_a3_model": _abi.A3Model, "oly_a3_inputs": _abi.A3Inputs,
+              "oly_a3_state": _abi.A3State}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/olympic_hip.h"', "int main(){"]
+    for cname, cls in fields.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines.append("return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(src, "w").write("\n".join(lines))
+        subprocess.check_call(["gcc", "-o", exe, src])
+        out = dict(l.split() for l in subprocess.check_output([exe], text=True).splitlines())
+    for cname, cls in fields.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(out[f"{cname}.{f}"]) == getattr(cls, f).offset, (cname, f)
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product():
+    from olympic_hip._ffi import Context, OlyError
+    if not torch.cuda.is_available():
+        with pytest.raises(OlyError, match="no CPU fallback"):
+            Context(0)
+    pkg = os.path.join(ROOT, "olympics-mujoco_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oly_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+# ------------------------------------------------------------------------------ multi-process
+def test_shard_range():
+    from olympic_hip.dist import shard_range
+    parts = [shard_range(32768, r, 8) for r in range(8)]
+    assert parts[0] == (0, 4096) and parts[-1] == (28672, 32768)
+    parts = [shard_range(10, r, 4) for r in range(4)]
+    assert [b - a for a, b in parts] == [3, 3, 2, 2] and parts[-1][1] == 10
+
+
+def test_adv_stats_allgather_two_ranks_gloo(tmp_path):
+    """world_size 2 over gloo: each rank reduces its env shard to (count, sum, sumsq), ONE
+    all-gather, both ranks normalise with the same global statistics = the single-process
+    result (PPO ddof 1 / 1e-5 and GAIL ddof 0 / 1e-8)."""
+    script = os.path.join(ROOT, "tests", "_dist_worker.py")
+    port = 29500 + (os.getpid() % 2000)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(tmp_path)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["total"], r1["total"])                      # identical on every rank
+    adv = np.load(tmp_path / "full.npy")
+    for ddof, eps, key in ((1, 1e-5, "ppo"), (0, 1e-8, "gail")):
+        ref = (adv - adv.mean()) / (adv.std(ddof=ddof) + eps)
+        got = np.concatenate([r0[key], r1[key]], axis=1)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert r0["total"][0] == adv.size
