@@ -151,7 +151,7 @@ def main():
         achieved = bpr * rows / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_k1.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (T, N) == (400, 4096) and not args.fall_code:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -167,15 +167,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 in / f32 out",
+            "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "UnitreeH1.walk config-2: fused K1+K5 over one [T,N] block per step",
                        "T": T, "envs_per_gpu": N, "env_steps_per_step": rows * world,
                        "launch_regime": "[T,N] block per launch", "fallen_fraction": fallen,
+                       "io": "qpos/qvel f64 + action f32 in; obs/reward/ctrl f32 + absorbing u8 out",
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "il_step_kernel<128,H1>", "kernel_ms": kern_ms,
+                         "kernel": "il_tile_kernel<128,H1>", "kernel_ms": kern_ms,
                          "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
         }
         if world == 1 and not args.no_cpu_baseline:
