@@ -78,16 +78,26 @@ def main():
     ap.add_argument("--N", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fall-code", action="store_true", help="also write the fall-code byte")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to "
+                         "rehearse the multi-rank path on a one-GPU box)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         dist = None
     if world != args.gpus and rank == 0:
@@ -120,8 +130,12 @@ def main():
         eng.il_step(qpos, qvel, act, prev[i & 1], prev[(i + 1) & 1], out=out, want_fall_code=args.fall_code)
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
@@ -140,7 +154,7 @@ def main():
     kern_ms = timer.elapsed_ms() / max(args.steps, 1)
 
     if dist is not None:
-        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        w = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     rows = T * N
@@ -183,7 +197,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

@@ -12,7 +12,35 @@
 
 namespace {
 
-constexpr int CHUNK = 8;
+constexpr int CHUNK = 16;
+
+struct Chunk {
+  float r[CHUNK], v[CHUNK], nv[CHUNK];
+  uint8_t f[CHUNK];
+};
+
+template <int MODE>
+__device__ __forceinline__ void load_chunk(Chunk& c, int t_hi, int T, int N, int n,
+                                           const float* __restrict__ rew, const float* __restrict__ val,
+                                           const float* __restrict__ next_val,
+                                           const uint8_t* __restrict__ flags) {
+#pragma unroll
+  for (int k = 0; k < CHUNK; ++k) {
+    const int t = t_hi - k;
+    if (t >= 0) {
+      const size_t e = (size_t)t * N + n;
+      c.r[k] = rew[e];
+      c.v[k] = val[e];
+      uint8_t f = flags[e];
+      if (t == T - 1) f |= OLY_FLAG_LAST;  // the block end always cuts the segment
+      c.f[k] = f;
+      if (MODE == OLY_SCAN_GAE)
+        c.nv[k] = next_val[e];
+      else
+        c.nv[k] = ((f & OLY_FLAG_LAST) && !(f & OLY_FLAG_ABSORBING)) ? next_val[e] : 0.f;
+    }
+  }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(64) void scan_kernel(int T, int N, double gamma, double lam,
@@ -27,53 +55,42 @@ __global__ __launch_bounds__(64) void scan_kernel(int T, int N, double gamma, do
   const float gl32 = (float)(gamma * lam);
   double R = 0.0;      // RETURN mode carry (float64, as numpy promotes it)
   float a_next = 0.f;  // GAE mode carry (float32 arrays in the reference)
+  // two register chunks: the loads of chunk i+1 are in flight while chunk i runs its
+  // dependent fp chain (software pipelining; the recurrence itself cannot be re-associated)
+  Chunk cur, nxt;
+  load_chunk<MODE>(cur, T - 1, T, N, n, rew, val, next_val, flags);
   for (int t_hi = T - 1; t_hi >= 0; t_hi -= CHUNK) {
-    float r[CHUNK], v[CHUNK], nv[CHUNK];
-    uint8_t f[CHUNK];
-#pragma unroll
-    for (int k = 0; k < CHUNK; ++k) {
-      const int t = t_hi - k;
-      if (t >= 0) {
-        const size_t e = (size_t)t * N + n;
-        r[k] = rew[e];
-        v[k] = val[e];
-        f[k] = flags[e];
-        if (t == T - 1) f[k] |= OLY_FLAG_LAST;  // the block end always cuts the segment
-        if (MODE == OLY_SCAN_GAE)
-          nv[k] = next_val[e];
-        else
-          nv[k] = ((f[k] & OLY_FLAG_LAST) && !(f[k] & OLY_FLAG_ABSORBING)) ? next_val[e] : 0.f;
-      }
-    }
+    if (t_hi - CHUNK >= 0) load_chunk<MODE>(nxt, t_hi - CHUNK, T, N, n, rew, val, next_val, flags);
 #pragma unroll
     for (int k = 0; k < CHUNK; ++k) {
       const int t = t_hi - k;
       if (t >= 0) {
         const size_t e = (size_t)t * N + n;
         if (MODE == OLY_SCAN_RETURN) {
-          if (f[k] & OLY_FLAG_LAST) {
-            const float p = g32 * nv[k];  // python float * float32 array: float32 product
-            R = (double)p + (double)r[k];
+          if (cur.f[k] & OLY_FLAG_LAST) {
+            const float p = g32 * cur.nv[k];  // python float * float32 array: float32 product
+            R = (double)p + (double)cur.r[k];
           } else {
-            R = gamma * R + (double)r[k];
+            R = gamma * R + (double)cur.r[k];
           }
           const float rt = (float)R;
           ret[e] = rt;
-          adv[e] = rt - v[k];
+          adv[e] = rt - cur.v[k];
         } else {
           float a;
-          if (f[k] & OLY_FLAG_LAST) {
-            a = r[k] - v[k];
-            if (!(f[k] & OLY_FLAG_ABSORBING)) a += g32 * nv[k];
+          if (cur.f[k] & OLY_FLAG_LAST) {
+            a = cur.r[k] - cur.v[k];
+            if (!(cur.f[k] & OLY_FLAG_ABSORBING)) a += g32 * cur.nv[k];
           } else {
-            a = r[k] + g32 * nv[k] - v[k] + gl32 * a_next;
+            a = cur.r[k] + g32 * cur.nv[k] - cur.v[k] + gl32 * a_next;
           }
           adv[e] = a;
-          ret[e] = a + v[k];
+          ret[e] = a + cur.v[k];
           a_next = a;
         }
       }
     }
+    cur = nxt;
   }
 }
 

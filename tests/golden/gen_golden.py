@@ -532,6 +532,8 @@ def gen_a3_task():
 
     E, K, C = 16, 100, 16          # envs, steps per env, contact slots
     rec = dict(
+        reset_lfoot=np.zeros((E, 3)), reset_rfoot=np.zeros((E, 3)), reset_root_quat=np.zeros((E, 4)),
+        iter_count=np.zeros(E, np.int64),
         mode=np.zeros(E, np.int32), phase0=np.zeros(E, np.int32), seq_len=np.zeros(E, np.int32),
         sequence=np.zeros((E, 20, 4)), t1_0=np.zeros(E, np.int32), t2_0=np.zeros(E, np.int32),
         root_pos=np.zeros((E, K, 3)), root_quat=np.zeros((E, K, 4)), head_pos=np.zeros((E, K, 3)),
@@ -565,6 +567,10 @@ def gen_a3_task():
         }
         np.random.seed(1000 + e)
         task.reset(iter_count=5000 + 400 * e)
+        rec["reset_lfoot"][e] = client.state["xpos_left_foot"]
+        rec["reset_rfoot"][e] = client.state["xpos_right_foot"]
+        rec["reset_root_quat"][e] = client.state["xquat_torso"]
+        rec["iter_count"][e] = 5000 + 400 * e
         rec["mode"][e] = task.mode.value
         rec["phase0"][e] = task._phase
         rec["seq_len"][e] = len(task.sequence)

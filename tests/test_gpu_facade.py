@@ -198,3 +198,35 @@ def test_gail_gae_pipeline(oracle):
     gr.normalize(adv, ddof=0, eps=1e-8)
     ref = (raw - raw.mean()) / (raw.std() + 1e-8)                  # gail_TRPO.py:128 (numpy, biased)
     np.testing.assert_allclose(host(adv), ref, rtol=2e-5, atol=2e-6)
+
+
+# ----------------------------------------------------------------- config 3: A3 vec env
+def test_vec_a3_env_replays_golden_sequence(golden):
+    """Host reset (reference RNG draws) + pd_target -> contact_reduce -> a3_step per step, fed
+    with the recorded physics readback, reproduces the reference's WalkingTask/get_obs."""
+    from olympic_hip.a3 import ReplayA3Physics, VecA3Env
+    from olympic_hip.engine import Engine
+    g = golden("a3_task.npz")
+    E, K = g["phase"].shape
+    sp = specs.A3Spec(mass=float(g["mass"]))
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    blocks = {n: dev(np.swapaxes(g[n], 0, 1)) for n in
+              ("qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel", "rf_vel", "root_pos",
+               "root_quat", "head_pos", "ncon", "geom1", "geom2", "force6", "cpos_z")}
+    env = VecA3Env(sp, E, Engine(0), ReplayA3Physics(blocks), g["geom_bodyid"], int(g["floor_body"]),
+                   int(g["rfoot_body"]), int(g["lfoot_body"]), obs_f64=True)
+    assert np.array_equal(env.lut, g["clock_lut"])
+    for e in range(E):                                   # per-env seeds, as the fixture was generated
+        np.random.seed(1000 + e)
+        env.iteration_count = int(g["iter_count"][e])
+        env.reset_task([e], g["reset_lfoot"][e:e + 1], g["reset_rfoot"][e:e + 1], g["reset_root_quat"][e:e + 1])
+    assert np.array_equal(host(env.state["mode"]), g["mode"]) and np.array_equal(host(env.state["phase"]), g["phase0"])
+    act = torch.zeros((E, 12), device="cuda")
+    for k in range(K):
+        obs, rew, done, rew6 = env.step(act)
+        assert np.array_equal(host(env.state["phase"]), g["phase"][:, k])
+        assert np.array_equal(host(env.state["t1"]), g["t1"][:, k]) and np.array_equal(host(env.state["t2"]), g["t2"][:, k])
+        assert np.array_equal(host(done), g["done"][:, k])
+        np.testing.assert_allclose(host(obs), g["obs"][:, k], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(host(rew), g["reward"][:, k], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(host(rew6), g["rew6"][:, k], rtol=2e-6, atol=1e-7)

@@ -270,3 +270,26 @@ def test_adv_stats_allgather_two_ranks_gloo(tmp_path):
         got = np.concatenate([r0[key], r1[key]], axis=1)
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
     assert r0["total"][0] == adv.size
+
+
+# ------------------------------------------------------------------------------ A3 host side
+def test_clock_lut_matches_create_phase_reward(golden):
+    from olympic_hip.a3 import clock_lut
+    g = golden("a3_task.npz")
+    lut = clock_lut(0.75, 0.35, 0.1, "grounded", 40.0)
+    assert lut.shape == (4, 88)
+    assert np.array_equal(lut, g["clock_lut"])           # same knots, same scipy PCHIP: bit-exact
+
+
+def test_walking_task_reset_matches_reference(golden):
+    """Same numpy global-stream draws as WalkingTask.reset (walking_task.py:321-397)."""
+    from olympic_hip.a3 import WalkingTaskReset, yaw_of_quat
+    g = golden("a3_task.npz")
+    reset = WalkingTaskReset(specs.A3Spec())
+    for e in range(len(g["mode"])):
+        np.random.seed(1000 + e)                          # the seed gen_golden.py used per env
+        r = reset(g["reset_lfoot"][e], g["reset_rfoot"][e], yaw_of_quat(g["reset_root_quat"][e]),
+                  int(g["iter_count"][e]))
+        assert r["mode"] == g["mode"][e] and r["phase"] == g["phase0"][e]
+        assert r["seq_len"] == g["seq_len"][e] and (r["t1"], r["t2"]) == (g["t1_0"][e], g["t2_0"][e])
+        np.testing.assert_allclose(r["sequence"], g["sequence"][e, :r["seq_len"]], rtol=1e-13, atol=1e-14)

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the secondary kernels (K2, K3, K4, K6, K7, K8) at BASELINE sizes,
+HIP events on the launch stream, algorithmic bytes per launch / time -> GB/s.
+Prints one JSON object.  The headline kernel (K1) is measured by bench.py."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "olympics-mujoco_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from olympic_hip import _abi, specs  # noqa: E402
+from olympic_hip._ffi import HipTimer  # noqa: E402
+from olympic_hip.engine import Engine  # noqa: E402
+
+
+def timeit(eng, fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    t = HipTimer()
+    s = eng.ctx.stream()
+    t.start(s)
+    for _ in range(reps):
+        fn()
+    t.stop(s)
+    return t.elapsed_ms() / reps
+
+
+def main():
+    eng = Engine(0)
+    dev = eng.device
+    g = torch.Generator(device="cuda").manual_seed(0)
+    out = {}
+    T, N = 400, 4096
+
+    def rnd(shape, dt=torch.float32):
+        return torch.empty(shape, dtype=dt, device=dev).normal_(0, 1, generator=g)
+
+    # K6
+    r, v, nv = rnd((T, N)), rnd((T, N)), rnd((T, N))
+    fl = ((torch.rand((T, N), device=dev, generator=g) < 1 / 300).to(torch.uint8) * 3)
+    ret, adv = torch.empty_like(r), torch.empty_like(r)
+    for mode, name, bpe in ((_abi.SCAN_RETURN, "K6_return", 17), (_abi.SCAN_GAE, "K6_gae", 21)):
+        ms = timeit(eng, lambda: eng.return_scan(mode, 0.99, 0.97, r, v, nv, fl, ret, adv))
+        out[name] = dict(ms=ms, GBps=bpe * T * N / ms / 1e6, bytes_per_elem=bpe, elems=T * N)
+    # K7
+    st = torch.empty(3, dtype=torch.float64, device=dev)
+    ms = timeit(eng, lambda: eng.adv_stats(adv, st))
+    out["K7_stats"] = dict(ms=ms, GBps=4 * T * N / ms / 1e6)
+    ms = timeit(eng, lambda: eng.adv_normalize(adv, st, 1, 1e-5))
+    out["K7_normalize"] = dict(ms=ms, GBps=8 * T * N / ms / 1e6)
+    x = rnd((T * N // 8, 32))
+    ms = timeit(eng, lambda: eng.col_stats(x))
+    out["K7_col_stats_[204800,32]"] = dict(ms=ms, GBps=x.numel() * 4 / ms / 1e6)
+    # K8
+    B = 4096 * 100
+    d = rnd((B,))
+    rw = torch.empty_like(d)
+    ms = timeit(eng, lambda: eng.disc_reward(d, rw))
+    out["K8_reward"] = dict(ms=ms, GBps=8 * B / ms / 1e6)
+    xs = rnd((B, 32))
+    mean, std = torch.zeros(32, dtype=torch.float64, device=dev), torch.ones(32, dtype=torch.float64, device=dev)
+    o = torch.empty_like(xs)
+    ms = timeit(eng, lambda: eng.disc_standardize(xs, None, mean, std, o))
+    out["K8_standardize_[409600,32]"] = dict(ms=ms, GBps=8 * xs.numel() / ms / 1e6)
+    # K3
+    gb = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)
+    eng.contact_configure(gb, 0, 7, 10)
+    Nc, C = 4096 * 16, 16
+    ncon = torch.randint(0, 9, (Nc,), device=dev, generator=g, dtype=torch.int32)
+    g1 = torch.zeros((Nc, C), dtype=torch.int32, device=dev)
+    g2 = torch.randint(0, 13, (Nc, C), device=dev, generator=g, dtype=torch.int32)
+    f6 = rnd((Nc, C, 6), torch.float64)
+    pz = rnd((Nc, C), torch.float64)
+    ms = timeit(eng, lambda: eng.contact_reduce(ncon, g1, g2, f6, pz, want_idx=False))
+    out["K3_contacts_[65536,16]"] = dict(ms=ms, GBps=(4 + C * 64 + 60) * Nc / ms / 1e6, env_per_s=Nc / ms * 1e3)
+    # K2
+    sp = specs.A3Spec(mass=41.5)
+    lut = np.zeros((4, sp.period))
+    eng.a3_configure(sp, lut)
+    Na = 4096 * 16
+    inp = dict(qpos=rnd((Na, 25), torch.float64), qvel=rnd((Na, 24), torch.float64),
+               act_len=rnd((Na, 12), torch.float64), act_vel=rnd((Na, 12), torch.float64),
+               lf_pos=rnd((Na, 3), torch.float64), rf_pos=rnd((Na, 3), torch.float64),
+               lf_vel=rnd((Na, 3), torch.float64), rf_vel=rnd((Na, 3), torch.float64),
+               root_pos=rnd((Na, 3), torch.float64), root_quat=rnd((Na, 4), torch.float64),
+               head_pos=rnd((Na, 3), torch.float64), grf_l=rnd((Na,), torch.float64).abs() * 100,
+               grf_r=rnd((Na,), torch.float64).abs() * 100, min_z=rnd((Na,), torch.float64) * 0.01,
+               n_r=torch.ones(Na, dtype=torch.int32, device=dev), n_l=torch.ones(Na, dtype=torch.int32, device=dev),
+               bad=torch.zeros(Na, dtype=torch.uint8, device=dev))
+    st2 = dict(phase=torch.zeros(Na, dtype=torch.int32, device=dev), t1=torch.zeros(Na, dtype=torch.int32, device=dev),
+               t2=torch.ones(Na, dtype=torch.int32, device=dev), reached_frames=torch.zeros(Na, dtype=torch.int32, device=dev),
+               target_reached=torch.zeros(Na, dtype=torch.uint8, device=dev),
+               mode=torch.full((Na,), 2, dtype=torch.int32, device=dev),
+               seq_len=torch.full((Na,), 20, dtype=torch.int32, device=dev),
+               sequence=rnd((Na, 20, 4), torch.float64), goal=torch.zeros((Na, 8), dtype=torch.float64, device=dev))
+    o2 = dict(obs=torch.empty((Na, 41), dtype=torch.float32, device=dev),
+              rew6=torch.empty((Na, 6), dtype=torch.float32, device=dev),
+              reward=torch.empty(Na, dtype=torch.float32, device=dev), done=torch.empty(Na, dtype=torch.uint8, device=dev))
+    ms = timeit(eng, lambda: eng.a3_step(inp, st2, out=o2))
+    out["K2_a3_step_[65536]"] = dict(ms=ms, GBps=(930 + 257) * Na / ms / 1e6, env_per_s=Na / ms * 1e3)
+    # K1 single-step regime (T = 1): launch-latency-bound, reported as latency
+    h1 = specs.unitree_h1("walk")
+    eng.il_configure(h1)
+    q1, v1 = rnd((1, N, 17), torch.float64), rnd((1, N, 17), torch.float64)
+    a1 = rnd((1, N, 11))
+    pv = torch.zeros(N, dtype=torch.float64, device=dev)
+    o1 = dict(obs=torch.empty((1, N, 32), dtype=torch.float32, device=dev), reward=torch.empty((1, N), dtype=torch.float32, device=dev),
+              absorbing=torch.empty((1, N), dtype=torch.uint8, device=dev), ctrl=torch.empty((1, N, 11), dtype=torch.float32, device=dev))
+    ms = timeit(eng, lambda: eng.il_step(q1, v1, a1, pv, out=o1, want_fall_code=False), reps=200, warm=20)
+    out["K1_single_step_T1_N4096"] = dict(us_per_launch=ms * 1e3, env_steps_per_s=N / ms * 1e3,
+                                          note="launch-bound regime, 2 MB per launch")
+    call, _ = eng.il_step_prepare(q1, v1, a1, pv, out=o1, want_fall_code=False)
+    stream = eng.ctx.stream()
+    ms = timeit(eng, lambda: call(stream), reps=500, warm=50)
+    out["K1_single_step_T1_N4096_prepared"] = dict(us_per_launch=ms * 1e3, env_steps_per_s=N / ms * 1e3,
+                                                   note="same launch through the prepared-call path")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
