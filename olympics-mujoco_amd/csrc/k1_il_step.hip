@@ -757,6 +757,7 @@ extern "C" int oly_il_configure(oly_ctx* ctx, const oly_il_model* m) {
       !m->act_delta || !m->ctrl_lo || !m->ctrl_hi)) || (m->n_fall && (!m->fall_idx || !m->fall_lo ||
       !m->fall_hi)))
     OLY_FAIL(ctx, OLY_EINVAL, "oly_il_configure: NULL table");
+  ctx->il_ok = false;  // a failed re-configure must not leave a half-written model usable
   IlDev& h = ctx->il_host;
   memset(&h, 0, sizeof(h));
   h.nq = m->nq; h.nv = m->nv; h.n_pos = m->n_pos; h.n_vel = m->n_vel; h.n_drop = m->n_drop;

@@ -265,6 +265,7 @@ extern "C" int oly_a3_configure(oly_ctx* ctx, const oly_a3_model* m) {
   if (m->nu <= 0 || m->nu > 16 || m->nq < 7 || m->nv < 6 || m->period <= 0 || m->period > OLY_MAX_PERIOD ||
       !m->clock_lut || !m->motor_offset || !m->gear)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_configure: bad model (nu=%d period=%d)", m->nu, m->period);
+  ctx->a3_ok = false;
   A3Dev& h = ctx->a3_host;
   memset(&h, 0, sizeof(h));
   h.nq = m->nq; h.nv = m->nv; h.nu = m->nu; h.period = m->period; h.delay_frames = m->delay_frames;

@@ -435,3 +435,97 @@ def test_a3_pd(eng, golden, oracle):
         tau = eng.a3_pd_torque(dev(spec.kp), dev(spec.kd), dev(g["pd_target"]), dev(g["pd_q"][:, s]),
                                dev(g["pd_qd"][:, s]))
         assert np.array_equal(host(tau), g["pd_tau"][:, s])           # bit-exact vs the reference
+
+
+# --------------------------------------------------------------------------------- edges
+def test_foot_force_columns_generic_kernel(eng, oracle):
+    """use_foot_forces=True appends mean_grf/1000 (loco_env_base.py:749-758): n_grf = 6 columns
+    run through the table-driven kernel."""
+    spec = specs.unitree_h1("walk")
+    spec.n_grf = 6
+    assert spec.n_obs == 38
+    rng = np.random.default_rng(21)
+    T, N = 3, 200
+    qpos, qvel, act = h1_synthetic_block(spec, T, N, seed=5, fall_frac="wide")
+    grf = rng.normal(0, 400, (T, N, 6))
+    prev = rng.normal(1.25, 0.3, N)
+    eng.il_configure(spec)
+    o = eng.il_step(dev(qpos), dev(qvel), dev(act), dev(prev), grf_mean=dev(grf), obs_f64=True)
+    torch.cuda.synchronize()
+    ref = oracle.il_step(spec, qpos, qvel, act, prev, grf_mean=grf, obs_f64=True)
+    assert np.array_equal(host(o["obs"]), ref["obs"])
+    assert np.array_equal(host(o["obs"])[..., 32:], grf / 1000.0)
+    assert np.array_equal(host(o["absorbing"]), ref["absorbing"])
+    assert np.array_equal(host(o["ctrl"]), ref["ctrl"])
+    from olympic_hip._ffi import OlyError
+    with pytest.raises(OlyError):
+        eng.il_step(dev(qpos), dev(qvel), dev(act), dev(prev))           # grf_mean missing
+
+
+def test_empty_inputs(eng):
+    spec = specs.unitree_h1("walk")
+    eng.il_configure(spec)
+    z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device="cuda")
+    o = eng.il_step(z(0, 5, 17), z(0, 5, 17), z(0, 5, 11, dt=torch.float32), z(5), prev_out=z(5))
+    assert o["obs"].shape == (0, 5, 32)
+    o = eng.il_step(z(1, 0, 17), z(1, 0, 17), None, z(0))
+    assert o["reward"].numel() == 0
+    ret, adv = eng.return_scan(_abi.SCAN_GAE, 0.99, 0.97, z(0, 4, dt=torch.float32), z(0, 4, dt=torch.float32),
+                               z(0, 4, dt=torch.float32), z(0, 4, dt=torch.uint8))
+    assert ret.numel() == 0
+    st = eng.adv_stats(z(0, dt=torch.float32))
+    assert host(st).tolist() == [0.0, 0.0, 0.0]
+    assert eng.disc_reward(z(0, dt=torch.float32)).numel() == 0
+    cs = eng.col_stats(z(0, 32, dt=torch.float32))
+    assert not host(cs).any()
+
+
+def test_error_codes_before_configure_and_bad_models():
+    from olympic_hip._ffi import OlyError
+    from olympic_hip.engine import Engine
+    e = Engine(0)
+    z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device="cuda")
+    with pytest.raises(OlyError, match="il_step before il_configure"):
+        e.il_step(z(1, 4, 17), z(1, 4, 17), None, z(4))
+    with pytest.raises(OlyError, match="before traj_upload"):
+        e.traj_reset(z(4, dt=torch.int32), z(4, dt=torch.int32))
+    with pytest.raises(OlyError, match="before contact_configure"):
+        e.contact_reduce(z(4, dt=torch.int32), z(4, 16, dt=torch.int32), z(4, 16, dt=torch.int32), z(4, 16, 6), z(4, 16))
+    with pytest.raises(OlyError, match="before a3_configure"):
+        e.a3_step({}, {"phase": z(4, dt=torch.int32)})
+    # the C layer itself reports OLY_ENOTCONF / OLY_ERANGE / OLY_EINVAL with a message
+    import ctypes as C
+    from olympic_hip import _ffi
+    L = _ffi.lib()
+    rc = L.oly_il_step(e.ctx.handle, 1, 4, None, None, None, None, None, None, None, None, None, None, None, 0, None)
+    assert rc == _abi.OLY_ENOTCONF and b"before oly_il_configure" in L.oly_last_error(e.ctx.handle)
+    bad = specs.unitree_h1("walk")
+    bad.act_to_ctrl = bad.act_to_ctrl.copy()
+    bad.act_to_ctrl[0] = 99
+    rc = L.oly_il_configure(e.ctx.handle, C.byref(bad.to_c()))
+    assert rc == _abi.OLY_ERANGE and b"act_to_ctrl" in L.oly_last_error(e.ctx.handle)
+    bad2 = specs.unitree_h1("walk")
+    bad2.qpos_adr = bad2.qpos_adr.copy()
+    bad2.qpos_adr[5] = 17
+    assert L.oly_il_configure(e.ctx.handle, C.byref(bad2.to_c())) == _abi.OLY_ERANGE
+    e.il_configure(specs.unitree_h1("walk"))
+    rc = L.oly_il_step(e.ctx.handle, 1, 4, None, None, None, None, None, None, None, None, None, None, None, 0, None)
+    assert rc == _abi.OLY_EINVAL
+    assert L.oly_return_scan(e.ctx.handle, 7, 1, 1, C.c_double(0.9), C.c_double(0.9), None, None, None, None, None,
+                             None, None) == _abi.OLY_EINVAL
+
+
+def test_unaligned_buffers_take_the_generic_path(eng, oracle):
+    """Views that are not 16-B aligned must still be correct (slow path)."""
+    spec = specs.unitree_h1("walk")
+    eng.il_configure(spec)
+    T, N = 2, 300
+    qpos, qvel, act = h1_synthetic_block(spec, T, N, seed=8, fall_frac="wide")
+    prev = np.zeros(N)
+    big = torch.zeros(T * N * 17 + 1, dtype=torch.float64, device="cuda")
+    qp = big[1:].view(T, N, 17)                       # 8-B aligned only
+    qp.copy_(torch.as_tensor(qpos))
+    assert qp.data_ptr() % 16 == 8 and qp.is_contiguous()
+    o = eng.il_step(qp, dev(qvel), dev(act), dev(prev))
+    ref = oracle.il_step(spec, qpos, qvel, act, prev)
+    _cmp_il({k: (None if v is None else host(v)) for k, v in o.items()}, ref, False)
