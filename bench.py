@@ -72,8 +72,8 @@ def cpu_baseline(spec, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--T", type=int, default=400)
     ap.add_argument("--N", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

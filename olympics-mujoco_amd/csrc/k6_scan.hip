@@ -8,6 +8,8 @@
 // a CHUNK of steps are issued before the dependent fp chain so that the wave keeps CHUNK x 4
 // loads in flight.  One wave per workgroup: with N = 4096 that is 64 workgroups on 64
 // different CUs, each with its own memory pipeline.  Bound: HBM/latency, 17-21 B per element.
+#include <cstdlib>
+
 #include "oly_common.h"
 
 namespace {
@@ -43,14 +45,16 @@ __device__ __forceinline__ void load_chunk(Chunk& c, int t_hi, int T, int N, int
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void scan_kernel(int T, int N, double gamma, double lam,
+__global__ __launch_bounds__(64) void scan_kernel(int T, int N, int epw, double gamma, double lam,
                                                   const float* __restrict__ rew,
                                                   const float* __restrict__ val,
                                                   const float* __restrict__ next_val,
                                                   const uint8_t* __restrict__ flags,
                                                   float* __restrict__ ret, float* __restrict__ adv) {
-  const int n = blockIdx.x * 64 + threadIdx.x;
-  if (n >= N) return;
+  // epw = environments per wave: a lone wave issues ~1 instruction per 4 cycles whatever its
+  // lane count, so with few environments the chains are spread over MORE (narrower) waves
+  const int n = blockIdx.x * epw + threadIdx.x;
+  if (threadIdx.x >= epw || n >= N) return;
   const float g32 = (float)gamma;
   const float gl32 = (float)(gamma * lam);
   double R = 0.0;      // RETURN mode carry (float64, as numpy promotes it)
@@ -94,7 +98,236 @@ __global__ __launch_bounds__(64) void scan_kernel(int T, int N, double gamma, do
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Tiled variant (default): a workgroup of 4 waves owns 64 environments.  ALL waves prefetch the
+// next TT-step tile of rew/val/next_val/flags (4 x 32 loads in flight per workgroup instead of
+// one wave's chunk) while wave 0 runs the sequential recurrence over the current tile out of
+// LDS.  Same arithmetic, same order: results are bit-identical to scan_kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int TT = 32;          // time steps per tile
+constexpr int SCAN_THREADS = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(int T, int N, double gamma, double lam,
+                                                                 const float* __restrict__ rew,
+                                                                 const float* __restrict__ val,
+                                                                 const float* __restrict__ next_val,
+                                                                 const uint8_t* __restrict__ flags,
+                                                                 float* __restrict__ ret,
+                                                                 float* __restrict__ adv) {
+  __shared__ float s_r[TT][64], s_v[TT][64], s_nv[TT][64];
+  __shared__ uint8_t s_f[TT][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const bool env_ok = n < N;
+  constexpr int RPW = TT / 4;  // rows per wave per tile
+  float pr[RPW], pv[RPW], pnv[RPW];
+  uint8_t pf[RPW];
+  const int ntiles = (T + TT - 1) / TT;
+
+  auto prefetch = [&](int k) {
+    const int t_top = T - 1 - k * TT;  // highest step of the tile; row tt <-> t = t_top - tt
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int t = t_top - (w + 4 * j);
+      if (t >= 0 && env_ok) {
+        const size_t e = (size_t)t * N + n;
+        pr[j] = rew[e];
+        pv[j] = val[e];
+        uint8_t f = flags[e];
+        if (t == T - 1) f |= OLY_FLAG_LAST;
+        pf[j] = f;
+        if (MODE == OLY_SCAN_GAE)
+          pnv[j] = next_val[e];
+        else
+          pnv[j] = ((f & OLY_FLAG_LAST) && !(f & OLY_FLAG_ABSORBING)) ? next_val[e] : 0.f;
+      }
+    }
+  };
+
+  const float g32 = (float)gamma;
+  const float gl32 = (float)(gamma * lam);
+  double R = 0.0;
+  float a_next = 0.f;
+  prefetch(0);
+  for (int k = 0; k < ntiles; ++k) {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int tt = w + 4 * j;
+      s_r[tt][lane] = pr[j];
+      s_v[tt][lane] = pv[j];
+      s_nv[tt][lane] = pnv[j];
+      s_f[tt][lane] = pf[j];
+    }
+    __syncthreads();
+    if (k + 1 < ntiles) prefetch(k + 1);
+    if (w == 0 && env_ok) {
+      const int t_top = T - 1 - k * TT;
+#pragma unroll 8
+      for (int tt = 0; tt < TT; ++tt) {
+        const int t = t_top - tt;
+        if (t < 0) break;
+        const size_t e = (size_t)t * N + n;
+        const float r = s_r[tt][lane], v = s_v[tt][lane], nv = s_nv[tt][lane];
+        const uint8_t f = s_f[tt][lane];
+        if (MODE == OLY_SCAN_RETURN) {
+          if (f & OLY_FLAG_LAST) {
+            const float p = g32 * nv;
+            R = (double)p + (double)r;
+          } else {
+            R = gamma * R + (double)r;
+          }
+          const float rt = (float)R;
+          ret[e] = rt;
+          adv[e] = rt - v;
+        } else {
+          float a;
+          if (f & OLY_FLAG_LAST) {
+            a = r - v;
+            if (!(f & OLY_FLAG_ABSORBING)) a += g32 * nv;
+          } else {
+            a = r + g32 * nv - v + gl32 * a_next;
+          }
+          adv[e] = a;
+          ret[e] = a + v;
+          a_next = a;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Wide variant (default when N % 4 == 0 and the arrays are 16-B aligned): same tiling, but
+// every global access is 16 B per lane (4 environments of one step) and the outputs go
+// through LDS so that wave 0 only does the recurrence: per tile a lane issues 8 loads and 4
+// stores instead of 32 and (on wave 0) 64.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_wide_kernel(int T, int N, double gamma, double lam,
+                                                                 const float* __restrict__ rew,
+                                                                 const float* __restrict__ val,
+                                                                 const float* __restrict__ next_val,
+                                                                 const uint8_t* __restrict__ flags,
+                                                                 float* __restrict__ ret,
+                                                                 float* __restrict__ adv) {
+  __shared__ __attribute__((aligned(16))) float s_r[TT][64], s_v[TT][64], s_nv[TT][64];
+  __shared__ __attribute__((aligned(16))) float s_ret[TT][64], s_adv[TT][64];
+  __shared__ __attribute__((aligned(16))) uint8_t s_f[TT][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.x * 64;
+  const int c4 = tid & 15;        // which group of 4 environments inside the 64
+  const int rr = tid >> 4;        // row within a 16-row slab
+  const bool col_ok = n0 + 4 * c4 < N;   // N % 4 == 0: a float4 is all-in or all-out
+  const bool env_ok = n0 + lane < N;
+  constexpr int SL = TT / 16;     // slabs per tile
+  float4 pr[SL], pv[SL], pnv[SL];
+  uchar4 pf[SL];
+  const int ntiles = (T + TT - 1) / TT;
+
+  auto prefetch = [&](int k) {
+    const int t_top = T - 1 - k * TT;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const int t = t_top - (rr + 16 * j);
+      if (t >= 0 && col_ok) {
+        const size_t e = (size_t)t * N + n0 + 4 * c4;
+        pr[j] = *reinterpret_cast<const float4*>(rew + e);
+        pv[j] = *reinterpret_cast<const float4*>(val + e);
+        pnv[j] = *reinterpret_cast<const float4*>(next_val + e);
+        pf[j] = *reinterpret_cast<const uchar4*>(flags + e);
+      }
+    }
+  };
+
+  const float g32 = (float)gamma;
+  const float gl32 = (float)(gamma * lam);
+  double R = 0.0;
+  float a_next = 0.f;
+  prefetch(0);
+  for (int k = 0; k < ntiles; ++k) {
+    const int t_top = T - 1 - k * TT;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const int tt = rr + 16 * j;
+      *reinterpret_cast<float4*>(&s_r[tt][4 * c4]) = pr[j];
+      *reinterpret_cast<float4*>(&s_v[tt][4 * c4]) = pv[j];
+      *reinterpret_cast<float4*>(&s_nv[tt][4 * c4]) = pnv[j];
+      *reinterpret_cast<uchar4*>(&s_f[tt][4 * c4]) = pf[j];
+    }
+    __syncthreads();
+    if (k + 1 < ntiles) prefetch(k + 1);
+    if (w == 0 && env_ok) {
+      // batches of SB steps: all LDS reads of a batch first (one round trip), then the
+      // dependent fp chain in registers, then the LDS writes.  Rows with t < 0 (last tile
+      // only, and last in time order) compute on garbage that is never stored or carried.
+      constexpr int SB = 8;
+      for (int tb = 0; tb < TT; tb += SB) {
+        float r8[SB], v8[SB], nv8[SB], o_ret[SB], o_adv[SB];
+        uint8_t f8[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+          r8[q] = s_r[tb + q][lane];
+          v8[q] = s_v[tb + q][lane];
+          nv8[q] = s_nv[tb + q][lane];
+          f8[q] = s_f[tb + q][lane];
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+          uint8_t f = f8[q];
+          if (t_top - (tb + q) == T - 1) f |= OLY_FLAG_LAST;
+          if (MODE == OLY_SCAN_RETURN) {
+            if (f & OLY_FLAG_LAST) {
+              const float nv = (f & OLY_FLAG_ABSORBING) ? 0.f : nv8[q];
+              const float p = g32 * nv;
+              R = (double)p + (double)r8[q];
+            } else {
+              R = gamma * R + (double)r8[q];
+            }
+            const float rt = (float)R;
+            o_ret[q] = rt;
+            o_adv[q] = rt - v8[q];
+          } else {
+            float a;
+            if (f & OLY_FLAG_LAST) {
+              a = r8[q] - v8[q];
+              if (!(f & OLY_FLAG_ABSORBING)) a += g32 * nv8[q];
+            } else {
+              a = r8[q] + g32 * nv8[q] - v8[q] + gl32 * a_next;
+            }
+            o_adv[q] = a;
+            o_ret[q] = a + v8[q];
+            a_next = a;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+          s_ret[tb + q][lane] = o_ret[q];
+          s_adv[tb + q][lane] = o_adv[q];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const int tt = rr + 16 * j;
+      const int t = t_top - tt;
+      if (t >= 0 && col_ok) {
+        const size_t e = (size_t)t * N + n0 + 4 * c4;
+        *reinterpret_cast<float4*>(ret + e) = *reinterpret_cast<const float4*>(&s_ret[tt][4 * c4]);
+        *reinterpret_cast<float4*>(adv + e) = *reinterpret_cast<const float4*>(&s_adv[tt][4 * c4]);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+static bool wide_ok(const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
+  auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
+  return al(a, 15) && al(b, 15) && al(c, 15) && al(d, 3) && al(e, 15) && al(f, 15);
+}
 
 extern "C" int oly_return_scan(oly_ctx* ctx, int mode, int T, int N, double gamma, double lam,
                                const float* rew, const float* val, const float* next_val,
@@ -104,15 +337,37 @@ extern "C" int oly_return_scan(oly_ctx* ctx, int mode, int T, int N, double gamm
   if (T == 0 || N == 0) return OLY_OK;
   if (!rew || !val || !next_val || !flags || !ret || !adv)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: NULL pointer");
-  dim3 grid((N + 63) / 64), block(64);
-  if (mode == OLY_SCAN_RETURN)
-    hipLaunchKernelGGL(scan_kernel<OLY_SCAN_RETURN>, grid, block, 0, oly_s(stream), T, N, gamma, lam,
-                       rew, val, next_val, flags, ret, adv);
-  else if (mode == OLY_SCAN_GAE)
-    hipLaunchKernelGGL(scan_kernel<OLY_SCAN_GAE>, grid, block, 0, oly_s(stream), T, N, gamma, lam, rew,
-                       val, next_val, flags, ret, adv);
-  else
+  static const int variant = [] { const char* e = getenv("OLY_K6_VARIANT"); return e ? atoi(e) : 1; }();  // 0 chunk, 1 auto (wide if possible), 3 tile
+  dim3 grid((N + 63) / 64);
+  if (mode != OLY_SCAN_RETURN && mode != OLY_SCAN_GAE)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: unknown mode %d", mode);
+  if (variant == 0) {  // single-wave register-chunk kernel
+    static const int epw_env = [] { const char* e = getenv("OLY_K6_EPW"); return e ? atoi(e) : 0; }();
+    int epw = 64;
+    while (epw > 8 && (long)((N + epw - 1) / epw) < 4L * ctx->num_cu) epw >>= 1;  // >= 4 waves per CU if possible
+    if (epw_env > 0) epw = epw_env;
+    dim3 g0((N + epw - 1) / epw);
+    if (mode == OLY_SCAN_RETURN)
+      hipLaunchKernelGGL(scan_kernel<OLY_SCAN_RETURN>, g0, dim3(64), 0, oly_s(stream), T, N, epw, gamma, lam,
+                         rew, val, next_val, flags, ret, adv);
+    else
+      hipLaunchKernelGGL(scan_kernel<OLY_SCAN_GAE>, g0, dim3(64), 0, oly_s(stream), T, N, epw, gamma, lam, rew,
+                         val, next_val, flags, ret, adv);
+  } else if (variant == 2 || (variant == 1 && N % 4 == 0 && wide_ok(rew, val, next_val, flags, ret, adv))) {
+    if (mode == OLY_SCAN_RETURN)
+      hipLaunchKernelGGL(scan_wide_kernel<OLY_SCAN_RETURN>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
+                         gamma, lam, rew, val, next_val, flags, ret, adv);
+    else
+      hipLaunchKernelGGL(scan_wide_kernel<OLY_SCAN_GAE>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
+                         gamma, lam, rew, val, next_val, flags, ret, adv);
+  } else {
+    if (mode == OLY_SCAN_RETURN)
+      hipLaunchKernelGGL(scan_tile_kernel<OLY_SCAN_RETURN>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
+                         gamma, lam, rew, val, next_val, flags, ret, adv);
+    else
+      hipLaunchKernelGGL(scan_tile_kernel<OLY_SCAN_GAE>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
+                         gamma, lam, rew, val, next_val, flags, ret, adv);
+  }
   OLY_LAUNCH_CHECK(ctx, "scan_kernel");
   return OLY_OK;
 }

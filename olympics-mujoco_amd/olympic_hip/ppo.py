@@ -1,0 +1,215 @@
+"""PPO (clip objective) with the reference's agent interface on top of the vectorised engine.
+
+Reference: rl/algos/ppo.py
+  PPO.__init__ args / log files        :94-132
+  PPO.sample / sample_parallel         :150-230  -> sample_vec (N envs in lock step, no ray)
+  PPO.update_policy                    :232-282  (clip loss, value loss, entropy, mirror loss)
+  PPO.train                            :284-477  (anneal / minibatch epochs / CSV logs / eval)
+  PPOBuffer.finish_path + adv-norm     :68-84, :335-336 -> HIP kernels via rollout.PPORollout
+
+Where the reference fans n_proc single-env workers out over ray, here `env_fn()` returns ONE
+vectorised env and `num_procs` maps to its num_envs; the optimiser side is unchanged PyTorch
+(MFMA GEMMs).  Actor / critic modules are the reference's own (anything with
+`forward(state, deterministic, anneal)`, `distribution(obs)` and a critic `forward(obs)`).
+"""
+import os
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+from torch.utils.data.sampler import BatchSampler, SubsetRandomSampler
+
+from . import _abi
+from .rollout import PPORollout, RolloutBuffer
+
+
+class MLPGaussianActor(torch.nn.Module):
+    """Shape-compatible stand-in for rl.policies.actor.Gaussian_FF_Actor (relu MLP, fixed
+    std): used by tests and examples when the reference's policy classes are not importable."""
+
+    def __init__(self, state_dim, action_dim, layers=(256, 256), fixed_std=None):
+        super().__init__()
+        dims = [state_dim] + list(layers)
+        self.actor_layers = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(layers))])
+        self.means = torch.nn.Linear(layers[-1], action_dim)
+        self.fixed_std = fixed_std if fixed_std is not None else torch.exp(torch.tensor(-1.5))
+        self.obs_mean, self.obs_std = 0.0, 1.0
+
+    def _mean(self, state):
+        x = (state - self.obs_mean) / self.obs_std
+        for lin in self.actor_layers:
+            x = torch.relu(lin(x))
+        return self.means(x)
+
+    def forward(self, state, deterministic=True, anneal=1.0):
+        mu = self._mean(state)
+        if deterministic:
+            return mu
+        return torch.distributions.Normal(mu, self.fixed_std * anneal).sample()
+
+    def distribution(self, inputs):
+        return torch.distributions.Normal(self._mean(inputs), self.fixed_std)
+
+
+class MLPCritic(torch.nn.Module):
+    """Stand-in for rl.policies.critic.FF_V."""
+
+    def __init__(self, state_dim, layers=(256, 256)):
+        super().__init__()
+        dims = [state_dim] + list(layers)
+        self.critic_layers = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(layers))])
+        self.network_out = torch.nn.Linear(layers[-1], 1)
+
+    def forward(self, inputs):
+        x = inputs
+        for lin in self.critic_layers:
+            x = torch.relu(lin(x))
+        return self.network_out(x)
+
+
+class PPO:
+    def __init__(self, args, save_path):
+        self.gamma, self.lam = args["gamma"], args["lam"]
+        self.lr, self.eps = args["lr"], args["eps"]
+        self.ent_coeff, self.clip = args["entropy_coeff"], args["clip"]
+        self.minibatch_size, self.epochs = args["minibatch_size"], args["epochs"]
+        self.max_traj_len, self.use_gae = args["max_traj_len"], args["use_gae"]
+        self.n_proc = args["num_procs"]
+        self.grad_clip, self.mirror_coeff = args["max_grad_norm"], args["mirror_coeff"]
+        self.eval_freq = args["eval_freq"]
+        self.recurrent = False
+        self.batch_size = self.n_proc * self.max_traj_len
+        self.vf_coeff = 0.5
+        self.target_kl = None
+        self.total_steps, self.highest_reward, self.iteration_count = 0, -1, 0
+        self.save_path = save_path
+        os.makedirs(save_path, exist_ok=True)
+        self.eval_fn = os.path.join(save_path, "eval.txt")
+        with open(self.eval_fn, "w") as out:
+            out.write("test_ep_returns,test_ep_lens\n")
+        self.train_fn = os.path.join(save_path, "train.txt")
+        with open(self.train_fn, "w") as out:
+            out.write("ep_returns,ep_lens\n")
+
+    def save(self, policy, critic, suffix=""):
+        os.makedirs(self.save_path, exist_ok=True)
+        torch.save(policy, os.path.join(self.save_path, "actor" + suffix + ".pt"))
+        torch.save(critic, os.path.join(self.save_path, "critic" + suffix + ".pt"))
+
+    # ------------------------------------------------------------------ rollout
+    @torch.no_grad()
+    def sample_vec(self, env, policy, critic, T, max_traj_len, deterministic=False, anneal=1.0):
+        """N envs x T steps; episode cuts as in PPO.sample (:169-196)."""
+        N, dev = env.num_envs, env.device
+        obs_dim = int(np.prod(env.observation_space.shape)) if hasattr(env, "observation_space") else env.spec.n_obs
+        act_dim = int(np.prod(env.action_space.shape)) if hasattr(env, "action_space") else env.spec.n_act
+        buf = RolloutBuffer(T, N, obs_dim, act_dim, dev)
+        state = env.reset().to(torch.float32)
+        traj_len = torch.zeros(N, dtype=torch.int32, device=dev)
+        for t in range(T):
+            action = policy(state, deterministic=deterministic, anneal=anneal)
+            value = critic(state).reshape(N)
+            next_state, reward, done, _ = env.step(action)
+            next_state = next_state.to(torch.float32)
+            buf.store(state, action, reward.to(torch.float32), value)
+            traj_len += 1
+            done = done.bool()
+            cut = done | (traj_len >= max_traj_len) | (t == T - 1)
+            buf.next_values[t] = critic(next_state).reshape(N)
+            buf.flags[t] = (cut.to(torch.uint8) * _abi.FLAG_LAST) | (done.to(torch.uint8) * _abi.FLAG_ABSORBING)
+            if t < T - 1 and bool(cut.any()):
+                fresh = env.reset(env_mask=cut).to(torch.float32)
+                next_state = torch.where(cut.unsqueeze(1), fresh, next_state)
+                traj_len = torch.where(cut, torch.zeros_like(traj_len), traj_len)
+            state = next_state
+        return buf
+
+    # ------------------------------------------------------------------ losses
+    def update_policy(self, obs_batch, action_batch, return_batch, advantage_batch, mask,
+                      mirror_observation=None, mirror_action=None):
+        policy, critic, old_policy = self.policy, self.critic, self.old_policy
+        values = critic(obs_batch)
+        pdf = policy.distribution(obs_batch)
+        log_probs = pdf.log_prob(action_batch).sum(-1, keepdim=True)
+        with torch.no_grad():
+            old_log_probs = old_policy.distribution(obs_batch).log_prob(action_batch).sum(-1, keepdim=True)
+        ratio = (log_probs - old_log_probs).exp()
+        cpi_loss = ratio * advantage_batch * mask
+        clip_loss = ratio.clamp(1.0 - self.clip, 1.0 + self.clip) * advantage_batch * mask
+        actor_loss = -torch.min(cpi_loss, clip_loss).mean()
+        clip_fraction = torch.mean((torch.abs(ratio - 1) > self.clip).float()).item()
+        critic_loss = self.vf_coeff * F.mse_loss(return_batch, values)
+        entropy_penalty = -(pdf.entropy() * mask).mean()
+        if mirror_observation is not None and mirror_action is not None:
+            deterministic_actions = policy(obs_batch)
+            mirror_actions = mirror_action(policy(mirror_observation(obs_batch)))
+            mirror_loss = (deterministic_actions - mirror_actions).pow(2).mean()
+        else:
+            mirror_loss = torch.zeros(1, device=obs_batch.device)
+        with torch.no_grad():
+            log_ratio = log_probs - old_log_probs
+            approx_kl_div = torch.mean((ratio - 1) - log_ratio)
+        return actor_loss, entropy_penalty, critic_loss, approx_kl_div, mirror_loss, clip_fraction
+
+    # ------------------------------------------------------------------ training loop
+    def train(self, env_fn, policy, critic, n_itr, anneal_rate=1.0, verbose=True):
+        self.old_policy = deepcopy(policy)
+        self.policy, self.critic = policy, critic
+        self.actor_optimizer = optim.Adam(policy.parameters(), lr=self.lr, eps=self.eps)
+        self.critic_optimizer = optim.Adam(critic.parameters(), lr=self.lr, eps=self.eps)
+        env = env_fn()
+        post = PPORollout(env.eng, gamma=self.gamma, lam=self.lam, eps=self.eps)
+        obs_mirr = getattr(env, "mirror_clock_observation", None) if hasattr(env, "mirror_observation") else None
+        act_mirr = getattr(env, "mirror_action", None)
+        T = max(1, self.batch_size // env.num_envs)
+        curr_anneal, start = 1.0, time.time()
+        history = []
+        for itr in range(n_itr):
+            self.iteration_count = itr
+            if hasattr(env, "iteration_count"):
+                env.iteration_count = itr
+            t0 = time.time()
+            if self.highest_reward > (2 / 3) * self.max_traj_len and curr_anneal > 0.5:
+                curr_anneal *= anneal_rate
+            buf = self.sample_vec(env, self.policy, self.critic, T, self.max_traj_len, anneal=curr_anneal)
+            returns, advantages = post.finish(buf, normalize=True)       # finish_path + (adv-mean)/(std+eps)
+            sample_s = time.time() - t0
+            n = buf.T * buf.N
+            observations = buf.states.reshape(n, -1)
+            actions = buf.actions.reshape(n, -1)
+            returns, advantages = returns.reshape(n, 1), advantages.reshape(n, 1)
+            self.total_steps += n
+            self.old_policy.load_state_dict(policy.state_dict())
+            minibatch = self.minibatch_size or n
+            t1 = time.time()
+            stats = []
+            for _ in range(self.epochs):
+                for idx in BatchSampler(SubsetRandomSampler(range(n)), minibatch, drop_last=True):
+                    idx = torch.as_tensor(idx, device=observations.device)
+                    a_l, ent, c_l, kl, m_l, clipf = self.update_policy(
+                        observations[idx], actions[idx], returns[idx], advantages[idx], 1, obs_mirr, act_mirr)
+                    self.actor_optimizer.zero_grad()
+                    (a_l + self.mirror_coeff * m_l + self.ent_coeff * ent).backward()
+                    torch.nn.utils.clip_grad_norm_(policy.parameters(), self.grad_clip)
+                    self.actor_optimizer.step()
+                    self.critic_optimizer.zero_grad()
+                    c_l.backward()
+                    torch.nn.utils.clip_grad_norm_(critic.parameters(), self.grad_clip)
+                    self.critic_optimizer.step()
+                    stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), clipf))
+            ep_ret, ep_len = buf.episode_stats()
+            mean_ret = float(np.mean(ep_ret)) if ep_ret else 0.0
+            self.highest_reward = max(self.highest_reward, mean_ret)
+            with open(self.train_fn, "a") as out:
+                out.write("{},{}\n".format(mean_ret, float(np.mean(ep_len)) if ep_len else 0.0))
+            rec = dict(itr=itr, ep_return=mean_ret, ep_len=float(np.mean(ep_len)) if ep_len else 0.0,
+                       sample_s=sample_s, optim_s=time.time() - t1,
+                       fps=self.total_steps / (time.time() - start), losses=np.mean(stats, axis=0).tolist())
+            history.append(rec)
+            if verbose:
+                print("itr {itr}: return {ep_return:.3f} len {ep_len:.1f} sampling {sample_s:.2f}s "
+                      "optimizer {optim_s:.2f}s fps {fps:.0f}".format(**rec))
+        return history

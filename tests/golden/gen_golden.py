@@ -33,6 +33,8 @@ fixtures do.  Fixture -> reference function map (file:line in /root/reference):
                   get_{r,l}foot_grf (:275-297), check_* (:381-413)
   symmetry.npz    _get_symmetry_matrix (rl/envs/wrappers.py:75),
                   SymmetricEnv.mirror_* (:51-72), A3 tables (StickFigureA3.py:118-129)
+  ppo_update.npz  PPO.update_policy (rl/algos/ppo.py:232-282) with Gaussian_FF_Actor / FF_V
+                  (rl/policies/actor.py:142, critic.py:37) and the A3 mirror functions
   vail_disc.npz   Standardizer/FullyConnectedNetwork/VariationalNet forward
                   (imitation_lib/utils/networks.py), GAIL.make_discrim_reward
                   (imitation_lib/imitation/gail_TRPO.py:320), GailDiscriminatorLoss
@@ -786,8 +788,52 @@ def gen_vail():
          dec_b=sd["decoder_net._linears.0.bias"])
 
 
+# -------------------------------------------------------------- G10 PPO update_policy
+def gen_ppo_update():
+    import importlib
+    base = importlib.import_module("rl.policies.base")
+    sys.modules["rl.policies"].base = base
+    actor_m = importlib.import_module("rl.policies.actor")
+    critic_m = importlib.import_module("rl.policies.critic")
+    torch.manual_seed(3)
+    rng = np.random.default_rng(4)
+    policy = actor_m.Gaussian_FF_Actor(41, 12, fixed_std=torch.exp(torch.tensor(-1.5)), bounded=False)
+    critic = critic_m.FF_V(41)
+    old_policy = actor_m.Gaussian_FF_Actor(41, 12, fixed_std=torch.exp(torch.tensor(-1.5)), bounded=False)
+    old_policy.load_state_dict(policy.state_dict())
+    with torch.no_grad():                       # make old != new so that ratio != 1
+        for prm in policy.parameters():
+            prm.add_(0.02 * torch.randn_like(prm))
+    B = 64
+    obs = torch.tensor(rng.normal(0, 1, (B, 41)), dtype=torch.float32)
+    obs[:, 31:33] = torch.tensor(rng.uniform(-1, 1, (B, 2)), dtype=torch.float32)
+    act = torch.tensor(rng.normal(0, 0.3, (B, 12)), dtype=torch.float32)
+    ret = torch.tensor(rng.normal(1, 1, (B, 1)), dtype=torch.float32)
+    adv = torch.tensor(rng.normal(0, 1, (B, 1)), dtype=torch.float32)
+    base_mir_obs = [0.1, -1, 2, -3, -4, 5, -6, 13, -14, -15, 16, -17, 18, 7, -8, -9, 10, -11, 12,
+                    25, -26, -27, 28, -29, 30, 19, -20, -21, 22, -23, 24]
+    mirrored_obs = base_mir_obs + [len(base_mir_obs) + i for i in range(10)]
+    mirrored_acts = [6, -7, -8, 9, -10, 11, 0.1, -1, -2, 3, -4, 5]
+    sym = ns.wrappers.SymmetricEnv(lambda: types.SimpleNamespace(base_obs_len=41), mirrored_obs=mirrored_obs,
+                                   mirrored_act=mirrored_acts, clock_inds=[31, 32])
+    fake = types.SimpleNamespace(policy=policy, critic=critic, old_policy=old_policy, clip=0.2, vf_coeff=0.5)
+    out = ns.ppo.PPO.update_policy(fake, obs, act, ret, adv, 1, mirror_observation=sym.mirror_clock_observation,
+                                   mirror_action=sym.mirror_action)
+    names = ("actor_loss", "entropy_penalty", "critic_loss", "approx_kl_div", "mirror_loss", "clip_fraction")
+    vals = {n: np.float64(float(v)) for n, v in zip(names, out)}
+    out2 = ns.ppo.PPO.update_policy(fake, obs, act, ret, adv, 1)
+    vals["mirror_loss_none"] = np.float64(float(out2[4]))
+    arrs = {}
+    for tag, mod in (("pi", policy), ("old", old_policy), ("vf", critic)):
+        for k, v in mod.state_dict().items():
+            arrs[f"{tag}.{k}"] = v.numpy()
+    save("ppo_update.npz", obs=obs.numpy(), act=act.numpy(), ret=ret.numpy(), adv=adv.numpy(), clip=0.2,
+         fixed_std=float(torch.exp(torch.tensor(-1.5))), mirrored_obs=np.array(mirrored_obs),
+         mirrored_acts=np.array(mirrored_acts), **vals, **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail"]
+    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd"]
     tab = gen_h1_tables() if any(w in which for w in ("tables", "h1", "traj")) else None
     if "h1" in which:
         gen_h1_step(tab)
@@ -805,3 +851,5 @@ if __name__ == "__main__":
         gen_symmetry()
     if "vail" in which:
         gen_vail()
+    if "ppoupd" in which:
+        gen_ppo_update()

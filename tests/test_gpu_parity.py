@@ -529,3 +529,51 @@ def test_unaligned_buffers_take_the_generic_path(eng, oracle):
     o = eng.il_step(qp, dev(qvel), dev(act), dev(prev))
     ref = oracle.il_step(spec, qpos, qvel, act, prev)
     _cmp_il({k: (None if v is None else host(v)) for k, v in o.items()}, ref, False)
+
+
+def _random_il_spec(rng, h1_shape=False):
+    """A made-up table-driven robot: random gather permutation, thresholds, ranges."""
+    from olympic_hip.specs import ILRobotSpec
+    if h1_shape:
+        nq = nv = n_pos = n_vel = 17
+        n_act = nu = 11
+    else:
+        nq, nv = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+        n_pos, n_vel = int(rng.integers(3, nq + 1)), int(rng.integers(1, nv + 1))
+        nu = int(rng.integers(1, 20))
+        n_act = int(rng.integers(1, nu + 1))
+    n_fall = int(rng.integers(0, 11)) if not h1_shape else int(rng.integers(0, 9))
+    keys = [f"q_j{i}" for i in range(n_pos)] + [f"dq_j{i}" for i in range(n_vel)]
+    n_obs = n_pos + n_vel - 2
+    fall_keys = [keys[2 + int(i)] for i in rng.integers(0, n_obs, n_fall)]
+    lo = rng.uniform(-1.0, -0.1, n_fall)
+    hi = rng.uniform(0.1, 1.0, n_fall)
+    sp = ILRobotSpec(
+        name="rand", obs_keys=keys, joint_names=[f"j{i}" for i in range(nq)], nq=nq, nv=nv, n_pos=n_pos,
+        n_vel=n_vel, qpos_adr=rng.permutation(nq)[:n_pos].astype(np.int32),
+        qvel_adr=rng.permutation(nv)[:n_vel].astype(np.int32), joint_lo=-np.ones(n_pos), joint_hi=np.ones(n_pos),
+        action_names=[f"a{i}" for i in range(n_act)], nu=nu,
+        act_to_ctrl=rng.permutation(nu)[:n_act].astype(np.int32), ctrl_lo=rng.uniform(-2, -0.5, n_act),
+        ctrl_hi=rng.uniform(0.5, 2, n_act), fall_tests=list(zip(fall_keys, lo.tolist(), hi.tolist())),
+        fall_names=[f"c{i}" for i in range(n_fall)], target_velocity=float(rng.uniform(0.5, 3)))
+    sp.__class__ = type("RandSpec", (ILRobotSpec,), {"reward_idx": property(lambda self: self._ridx)})
+    sp._ridx = int(rng.integers(0, n_obs))
+    return sp
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_table_driven_robots(eng, oracle, seed):
+    """The IL kernel is table-driven (Atlas/Talos are data): random robots vs the oracle,
+    alternating between H1-shaped tables (fast tile kernel) and arbitrary shapes (generic)."""
+    rng = np.random.default_rng(100 + seed)
+    sp = _random_il_spec(rng, h1_shape=(seed % 2 == 0))
+    T, N = int(rng.integers(1, 5)), int(rng.integers(1, 700))
+    qpos = rng.uniform(-1.2, 1.2, (T, N, sp.nq))
+    qvel = rng.normal(0, 1.5, (T, N, sp.nv))
+    act = rng.uniform(-1.5, 1.5, (T, N, sp.n_act)).astype(np.float32)
+    prev = rng.normal(1, 1, N)
+    for f64 in (False, True):
+        o = _run_il(eng, sp, qpos, qvel, act, prev, obs_f64=f64, ctrl_f64=f64)
+        ref = oracle.il_step(sp, qpos, qvel, act, prev, obs_f64=f64, ctrl_f64=f64)
+        _cmp_il(o, ref, f64)
+    assert (np.asarray(ref["fall_code"]) > 0).any() or len(sp.fall_tests) == 0

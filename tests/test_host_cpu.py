@@ -293,3 +293,38 @@ def test_walking_task_reset_matches_reference(golden):
         assert r["mode"] == g["mode"][e] and r["phase"] == g["phase0"][e]
         assert r["seq_len"] == g["seq_len"][e] and (r["t1"], r["t2"]) == (g["t1_0"][e], g["t2_0"][e])
         np.testing.assert_allclose(r["sequence"], g["sequence"][e, :r["seq_len"]], rtol=1e-13, atol=1e-14)
+
+
+# ------------------------------------------------------------------------------ PPO losses
+def test_ppo_update_policy_matches_reference(golden, tmp_path):
+    """PPO.update_policy (rl/algos/ppo.py:232-282) on the reference's own actor/critic weights."""
+    from olympic_hip.ppo import PPO, MLPCritic, MLPGaussianActor
+    from olympic_hip.wrappers import SymmetricEnv
+    g = golden("ppo_update.npz")
+
+    def load(mod, tag):
+        sd = {k[len(tag) + 1:]: torch.tensor(g[k]) for k in g.files if k.startswith(tag + ".")}
+        mod.load_state_dict(sd)
+        return mod
+    std = torch.tensor(float(g["fixed_std"]))
+    pi = load(MLPGaussianActor(41, 12, fixed_std=std), "pi")
+    old = load(MLPGaussianActor(41, 12, fixed_std=std), "old")
+    vf = load(MLPCritic(41), "vf")
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=float(g["clip"]), minibatch_size=64,
+                epochs=3, max_traj_len=400, use_gae=False, num_procs=4, max_grad_norm=0.05, mirror_coeff=0.4,
+                eval_freq=100)
+    ppo = PPO(args, str(tmp_path))
+    assert open(ppo.train_fn).read() == "ep_returns,ep_lens\n" and ppo.batch_size == 1600
+    ppo.policy, ppo.critic, ppo.old_policy = pi, vf, old
+
+    class Dummy:
+        base_obs_len = 41
+    sym = SymmetricEnv(Dummy, mirrored_obs=g["mirrored_obs"].tolist(), mirrored_act=g["mirrored_acts"].tolist(),
+                       clock_inds=[31, 32])
+    t = lambda k: torch.tensor(g[k])
+    out = ppo.update_policy(t("obs"), t("act"), t("ret"), t("adv"), 1, sym.mirror_clock_observation, sym.mirror_action)
+    names = ("actor_loss", "entropy_penalty", "critic_loss", "approx_kl_div", "mirror_loss", "clip_fraction")
+    for n, v in zip(names, out):
+        np.testing.assert_allclose(float(v), float(g[n]), rtol=2e-5, atol=2e-7, err_msg=n)
+    out2 = ppo.update_policy(t("obs"), t("act"), t("ret"), t("adv"), 1)
+    assert float(out2[4]) == float(g["mirror_loss_none"]) == 0.0
