@@ -35,7 +35,8 @@ class MLPGaussianActor(torch.nn.Module):
         dims = [state_dim] + list(layers)
         self.actor_layers = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(layers))])
         self.means = torch.nn.Linear(layers[-1], action_dim)
-        self.fixed_std = fixed_std if fixed_std is not None else torch.exp(torch.tensor(-1.5))
+        std = fixed_std if fixed_std is not None else torch.exp(torch.tensor(-1.5))
+        self.register_buffer("fixed_std", torch.as_tensor(std, dtype=torch.float32), persistent=False)
         self.obs_mean, self.obs_std = 0.0, 1.0
 
     def _mean(self, state):

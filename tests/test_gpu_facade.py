@@ -254,6 +254,7 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path):
                   geom1=torch.zeros((K, N, 16), dtype=torch.int32, device="cuda"),
                   geom2=torch.randint(8, 13, (K, N, 16), device="cuda", generator=gen, dtype=torch.int32),
                   force6=100 * rnd(K, N, 16, 6), cpos_z=0.01 * rnd(K, N, 16))
+    blocks["root_quat"] = blocks["root_quat"] / blocks["root_quat"].norm(dim=-1, keepdim=True)   # xquat is unit
     blocks = {k: v.contiguous() for k, v in blocks.items()}
 
     class Env(VecA3Env):

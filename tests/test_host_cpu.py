@@ -325,6 +325,7 @@ def test_ppo_update_policy_matches_reference(golden, tmp_path):
     out = ppo.update_policy(t("obs"), t("act"), t("ret"), t("adv"), 1, sym.mirror_clock_observation, sym.mirror_action)
     names = ("actor_loss", "entropy_penalty", "critic_loss", "approx_kl_div", "mirror_loss", "clip_fraction")
     for n, v in zip(names, out):
+        v = v.detach() if torch.is_tensor(v) else v
         np.testing.assert_allclose(float(v), float(g[n]), rtol=2e-5, atol=2e-7, err_msg=n)
     out2 = ppo.update_policy(t("obs"), t("act"), t("ret"), t("adv"), 1)
     assert float(out2[4]) == float(g["mirror_loss_none"]) == 0.0
