@@ -675,6 +675,30 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
   }
 }
 
+// K5 alone: un-normalise, clamp, actuator order, for N rows (elementwise over N*nu outputs).
+template <bool CTRL64>
+__global__ __launch_bounds__(THREADS) void il_ctrl_kernel(const IlDev* __restrict__ md, long total,
+                                                          const float* __restrict__ action,
+                                                          void* __restrict__ ctrl) {
+  const int nu = md->nu, n_act = md->n_act;
+  const long stride = (long)gridDim.x * THREADS;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += stride) {
+    const long r = e / nu;
+    const int j = (int)(e - r * nu);
+    const int k = md->ctrl_src[j];
+    double u = 0.0;
+    if (k >= 0) {
+      u = (double)action[r * n_act + k] * md->act_delta[k] + md->act_mean[k];
+      if (u < md->ctrl_lo[k]) u = md->ctrl_lo[k];
+      if (u > md->ctrl_hi[k]) u = md->ctrl_hi[k];
+    }
+    if (CTRL64)
+      static_cast<double*>(ctrl)[e] = u;
+    else
+      static_cast<float*>(ctrl)[e] = (float)u;
+  }
+}
+
 using H1Dims = StaticDims<17, 17, 0, 11, 11, 32>;
 
 template <int ROWS, class D>
@@ -843,4 +867,23 @@ extern "C" int oly_il_step(oly_ctx* ctx, int T, int N, const double* qpos, const
     return launch_fast<128, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
   }
   return launch_generic<64, DynDims>(ctx, a, 0, out_flags, oly_s(stream));
+}
+
+extern "C" int oly_il_ctrl(oly_ctx* ctx, int N, const float* action, void* ctrl, int out_flags,
+                           oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->il_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_il_ctrl before oly_il_configure");
+  if (N < 0 || (N > 0 && (!action || !ctrl))) OLY_FAIL(ctx, OLY_EINVAL, "oly_il_ctrl: bad argument");
+  if (N == 0) return OLY_OK;
+  const long total = (long)N * ctx->il_host.nu;
+  long nb = (total + THREADS - 1) / THREADS;
+  if (nb > 4096) nb = 4096;
+  if (out_flags & OLY_OUT_CTRL_F64)
+    hipLaunchKernelGGL(il_ctrl_kernel<true>, dim3((unsigned)nb), dim3(THREADS), 0, oly_s(stream), ctx->il_dev,
+                       total, action, ctrl);
+  else
+    hipLaunchKernelGGL(il_ctrl_kernel<false>, dim3((unsigned)nb), dim3(THREADS), 0, oly_s(stream), ctx->il_dev,
+                       total, action, ctrl);
+  OLY_LAUNCH_CHECK(ctx, "il_ctrl_kernel");
+  return OLY_OK;
 }

@@ -17,6 +17,7 @@ FLAG_ABSORBING, FLAG_LAST = 1, 2
 i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)
 vp = C.c_void_p
+PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp)
 
 
 class IlModel(C.Structure):
@@ -65,6 +66,14 @@ SIGNATURES = {
     "oly_il_obs_dim": (C.c_int, [vp]),
     "oly_il_step": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                               C.c_int, vp]),
+    "oly_il_ctrl": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
+    "oly_batcher_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_double, vp, vp]),
+    "oly_batcher_destroy": (None, [vp]),
+    "oly_batcher_qpos": (C.POINTER(C.c_double), [vp]),
+    "oly_batcher_qvel": (C.POINTER(C.c_double), [vp]),
+    "oly_batcher_prev": (vp, [vp]),
+    "oly_batcher_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
+    "oly_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "oly_traj_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "oly_traj_reset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "oly_traj_next": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),

@@ -98,3 +98,41 @@ class DiscriminatorReward:
                               device=x.device, generator=generator)
         d, _, _ = self.logits(x, eps)
         return self.eng.disc_reward(d)
+
+
+class GAILAdvantage:
+    """The reward / advantage half of GAIL.fit (gail_TRPO.py:105-129) on the device:
+
+        r_disc = make_discrim_reward(x, u, xn)
+        r      = r * env_reward_frac + r_disc * (1 - env_reward_frac)
+        v_target, adv = compute_gae(V, x, xn, r, absorbing, last, gamma, lam)
+        adv    = (adv - mean(adv)) / (std(adv) + 1e-8)            (numpy, biased std)
+
+    x / xn are [T,N,obs] rollout blocks (the reference's flat dataset is the N = 1 case)."""
+
+    def __init__(self, engine, disc_reward, critic, gamma=0.99, lam=0.97, env_reward_frac=0.0):
+        from .rollout import GAERollout
+        assert 0.0 <= env_reward_frac <= 1.0, "Environment reward must be between [0,1]"
+        self.eng, self.disc, self.critic = engine, disc_reward, critic
+        self.frac = env_reward_frac
+        self.post = GAERollout(engine, gamma=gamma, lam=lam)
+
+    @torch.no_grad()
+    def __call__(self, x, xn, r_env, absorbing, last, eps=None):
+        from . import _abi
+        from .rollout import RolloutBuffer
+        T, N, D = x.shape
+        flat = x.reshape(T * N, D).contiguous()
+        if self.frac < 1.0:
+            r_disc = self.disc(flat, eps).reshape(T, N)
+            r = r_env * self.frac + r_disc * (1 - self.frac)
+        else:
+            r = r_env
+        buf = RolloutBuffer(T, N, D, 1, x.device)
+        buf.rewards.copy_(r)
+        buf.values.copy_(self.critic(flat).reshape(T, N))
+        buf.next_values.copy_(self.critic(xn.reshape(T * N, D)).reshape(T, N))
+        buf.flags.copy_((last.to(torch.uint8) * _abi.FLAG_LAST) | (absorbing.to(torch.uint8) * _abi.FLAG_ABSORBING))
+        buf.ptr = T
+        v_target, adv = self.post.finish(buf, normalize=True)
+        return r, v_target, adv

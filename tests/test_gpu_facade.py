@@ -284,3 +284,89 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path):
     assert ppo.total_steps == 2 * 16 * N
     lines = open(ppo.train_fn).read().strip().splitlines()
     assert lines[0] == "ep_returns,ep_lens" and len(lines) == 3
+
+
+def test_gail_fit_reward_and_advantage_pipeline(golden, oracle):
+    """Config 4 at N = 4096: discriminator reward -> GAE(0.97) -> biased-std normalisation."""
+    from olympic_hip.engine import Engine
+    from olympic_hip.gail import DiscriminatorReward, GAILAdvantage, VariationalDiscriminator
+    g = golden("vail_disc.npz")
+    eng = Engine(0)
+    net = VariationalDiscriminator().load_reference_arrays(g).cuda()
+    torch.manual_seed(0)
+    critic = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 1)).cuda()
+    T, N = 8, 4096
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.empty((T, N, 32), device="cuda").normal_(0, 1, generator=gen)
+    xn = torch.empty((T, N, 32), device="cuda").normal_(0, 1, generator=gen)
+    eps = torch.empty((T * N, 128), device="cuda").normal_(0, 1, generator=gen)
+    last = torch.rand((T, N), device="cuda", generator=gen) < 0.1
+    absorbing = last & (torch.rand((T, N), device="cuda", generator=gen) < 0.5)
+    r_env = torch.zeros((T, N), device="cuda")
+    pipe = GAILAdvantage(eng, DiscriminatorReward(eng, net, state_mask=np.arange(32)), critic, 0.99, 0.97)
+    r, v_target, adv = pipe(x, xn, r_env, absorbing, last, eps)
+    assert torch.isfinite(r).all() and (r >= 0).all()              # -log(1 - p + 1e-8) >= -log(1+1e-8)
+    v = critic(x.reshape(-1, 32)).reshape(T, N)
+    vn = critic(xn.reshape(-1, 32)).reshape(T, N)
+    flags = (last.to(torch.uint8) * _abi.FLAG_LAST) | (absorbing.to(torch.uint8) * _abi.FLAG_ABSORBING)
+    e_ret, e_adv = oracle.return_scan(_abi.SCAN_GAE, 0.99, 0.97, host(r), host(v.detach()), host(vn.detach()), host(flags))
+    assert np.array_equal(host(v_target), e_ret)                   # v_target = adv + v, pre-normalisation
+    ref = (e_adv.astype(np.float64) - e_adv.mean(dtype=np.float64)) / (e_adv.astype(np.float64).std() + 1e-8)
+    np.testing.assert_allclose(host(adv), ref, rtol=2e-5, atol=2e-6)
+
+
+# ----------------------------------------------------------------- next row f1: host batcher
+def test_host_batcher_kinematic_and_callback(oracle):
+    from olympic_hip.batcher import HostBatcher
+    from olympic_hip.engine import Engine
+    sp = specs.unitree_h1("walk")
+    eng = Engine(0).il_configure(sp)
+    N = 777
+    qpos, qvel, act = h1_synthetic_block(sp, 3, N, seed=31, fall_frac="wide")
+    b = HostBatcher(eng, N, n_threads=4, dt=0.01, obs_f64=True)
+    b.qpos[:], b.qvel[:] = qpos[0], qvel[0]
+    prev = np.linspace(0.5, 2.0, N)
+    b.set_prev(prev)
+    q, v = qpos[0].copy(), qvel[0].copy()
+    for t in range(3):
+        obs, rew, ab = b.step(torch.as_tensor(act[t]).cuda())
+        torch.cuda.synchronize()
+        q = q + 0.01 * v                                       # built-in kinematic stand-in
+        assert np.array_equal(b.qpos, q)
+        ref = oracle.il_step(sp, q[None], v[None], None, prev, obs_f64=True)
+        assert np.array_equal(host(obs), ref["obs"][0]) and np.array_equal(host(ab), ref["absorbing"][0])
+        assert ulp_diff(host(rew), ref["reward"][0]).max() <= 1
+        prev = ref["prev"]
+    tm = b.last_timing()
+    assert tm["physics_s"] >= 0 and tm["ctrl_d2h_s"] > 0
+    b.close()
+    # a Python physics callback sees the un-normalised, clamped, actuator-ordered controls in fp64
+    seen = {}
+
+    def phys(env, ctrl, qp, qv):
+        seen[env] = ctrl.copy()
+        qp[2] = -1.0                                           # pelvis height out of range: fallen
+    b2 = HostBatcher(eng, 5, n_threads=2, physics=phys)
+    a = torch.as_tensor(act[0][:5]).cuda()
+    obs, rew, ab = b2.step(a)
+    torch.cuda.synchronize()
+    exp = np.zeros((5, 11))
+    exp[:, sp.act_to_ctrl] = np.clip(act[0][:5].astype(np.float64) * 0.95, -0.95, 0.95)
+    assert sorted(seen) == [0, 1, 2, 3, 4] and all(np.array_equal(seen[e], exp[e]) for e in range(5))
+    assert host(ab).all() and (host(b2.fall_code) == 1).all()
+    b2.close()
+
+
+def test_il_ctrl_matches_il_step(oracle):
+    from olympic_hip.engine import Engine
+    import ctypes as C
+    from olympic_hip import _ffi
+    sp = specs.unitree_h1("walk")
+    eng = Engine(0).il_configure(sp)
+    N = 1000
+    qpos, qvel, act = h1_synthetic_block(sp, 1, N, seed=2)
+    a = torch.as_tensor(act[0] * 1.4).cuda().contiguous()
+    out = torch.empty((N, 11), dtype=torch.float64, device="cuda")
+    eng.ctx.call("oly_il_ctrl", N, _ffi.ptr(a), _ffi.ptr(out), _abi.OUT_CTRL_F64, eng._s())
+    ref = oracle.il_step(sp, qpos, qvel, host(a)[None], np.zeros(N), ctrl_f64=True)
+    assert np.array_equal(host(out), ref["ctrl"][0])
