@@ -9,6 +9,7 @@
 // loads in flight.  One wave per workgroup: with N = 4096 that is 64 workgroups on 64
 // different CUs, each with its own memory pipeline.  Bound: HBM/latency, 17-21 B per element.
 #include <cstdlib>
+#include <type_traits>
 
 #include "oly_common.h"
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(64) void scan_kernel(int T, int N, int epw, double 
 // one wave's chunk) while wave 0 runs the sequential recurrence over the current tile out of
 // LDS.  Same arithmetic, same order: results are bit-identical to scan_kernel.
 // ---------------------------------------------------------------------------------------
-constexpr int TT = 32;          // time steps per tile
+constexpr int TT = 64;          // time steps per tile
 constexpr int SCAN_THREADS = 256;
 
 template <int MODE>
@@ -324,6 +325,145 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_wide_kernel(int T, int N, d
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------
+// Lean variant (default when the wide layout applies): the serial wave runs ONLY the
+// recurrence.  The lanes that load a tile turn it, while it is still in their registers, into
+// the per-step constant of the recurrence,
+//   RETURN:  R_t = sel ? b : gamma * R_{t+1} + b      b = f64(r)            (sel = segment end:
+//                                                      b = f64(g32 * nv_eff) + f64(r))
+//   GAE:     a_t = sel ? c : c + gl32 * a_{t+1}       c = (r + g32*nv) - v  (sel: c = (r - v) [+ g32*nv])
+// which are exactly the reference's operations in the reference's order; wave 0 reads (b|c, sel),
+// does one multiply-add pair per step and writes the carry; all lanes then derive ret / adv
+// (RETURN: ret = f32(R), adv = ret - v; GAE: adv = a, ret = a + v) during the store sweep.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_lean_kernel(int T, int N, double gamma, double lam,
+                                                                 const float* __restrict__ rew,
+                                                                 const float* __restrict__ val,
+                                                                 const float* __restrict__ next_val,
+                                                                 const uint8_t* __restrict__ flags,
+                                                                 float* __restrict__ ret,
+                                                                 float* __restrict__ adv) {
+  using carry_t = typename std::conditional<MODE == OLY_SCAN_RETURN, double, float>::type;
+  __shared__ __attribute__((aligned(16))) carry_t s_b[TT][64];   // recurrence constant, then the carry
+  __shared__ __attribute__((aligned(16))) float s_v[TT][64];
+  __shared__ __attribute__((aligned(16))) uint8_t s_sel[TT][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.x * 64;
+  const int c4 = tid & 15, rr = tid >> 4;
+  const bool col_ok = n0 + 4 * c4 < N;
+  const bool env_ok = n0 + lane < N;
+  constexpr int SL = TT / 16;
+  float4 pr[SL], pv[SL], pnv[SL];
+  uchar4 pf[SL];
+  const int ntiles = (T + TT - 1) / TT;
+  const float g32 = (float)gamma;
+  const float gl32 = (float)(gamma * lam);
+
+  auto prefetch = [&](int k) {
+    const int t_top = T - 1 - k * TT;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const int t = t_top - (rr + 16 * j);
+      if (t >= 0 && col_ok) {
+        const size_t e = (size_t)t * N + n0 + 4 * c4;
+        pr[j] = *reinterpret_cast<const float4*>(rew + e);
+        pv[j] = *reinterpret_cast<const float4*>(val + e);
+        pnv[j] = *reinterpret_cast<const float4*>(next_val + e);
+        pf[j] = *reinterpret_cast<const uchar4*>(flags + e);
+      }
+    }
+  };
+  auto konst = [&](float r, float v, float nv, uint8_t f, bool top) -> carry_t {
+    const bool last = (f & OLY_FLAG_LAST) || top, ab = f & OLY_FLAG_ABSORBING;
+    if (MODE == OLY_SCAN_RETURN) {
+      if (last) {
+        const float p = g32 * (ab ? 0.f : nv);
+        return (carry_t)((double)p + (double)r);
+      }
+      return (carry_t)(double)r;
+    }
+    if (last) {
+      float a = r - v;
+      if (!ab) a += g32 * nv;
+      return (carry_t)a;
+    }
+    return (carry_t)(r + g32 * nv - v);
+  };
+
+  carry_t carry = 0;
+  prefetch(0);
+  for (int k = 0; k < ntiles; ++k) {
+    const int t_top = T - 1 - k * TT;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const int tt = rr + 16 * j;
+      const bool top = (t_top - tt) == T - 1;
+      const float rv[4] = {pr[j].x, pr[j].y, pr[j].z, pr[j].w};
+      const float vv[4] = {pv[j].x, pv[j].y, pv[j].z, pv[j].w};
+      const float nn[4] = {pnv[j].x, pnv[j].y, pnv[j].z, pnv[j].w};
+      const uint8_t ff[4] = {pf[j].x, pf[j].y, pf[j].z, pf[j].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s_b[tt][4 * c4 + q] = konst(rv[q], vv[q], nn[q], ff[q], top);
+        s_sel[tt][4 * c4 + q] = (uint8_t)(((ff[q] & OLY_FLAG_LAST) || top) ? 1 : 0);
+      }
+      *reinterpret_cast<float4*>(&s_v[tt][4 * c4]) = pv[j];
+    }
+    __syncthreads();
+    if (k + 1 < ntiles) prefetch(k + 1);
+    if (w == 0 && env_ok) {
+      constexpr int SB = 16;
+      for (int tb = 0; tb < TT; tb += SB) {
+        carry_t b8[SB];
+        uint8_t s8[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+          b8[q] = s_b[tb + q][lane];
+          s8[q] = s_sel[tb + q][lane];
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+          carry_t nxt;
+          if (MODE == OLY_SCAN_RETURN)
+            nxt = (carry_t)(gamma * (double)carry + (double)b8[q]);
+          else
+            nxt = (carry_t)((float)b8[q] + gl32 * (float)carry);
+          carry = s8[q] ? b8[q] : nxt;
+          b8[q] = carry;
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) s_b[tb + q][lane] = b8[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const int tt = rr + 16 * j;
+      const int t = t_top - tt;
+      if (t >= 0 && col_ok) {
+        const size_t e = (size_t)t * N + n0 + 4 * c4;
+        const float4 v4 = *reinterpret_cast<const float4*>(&s_v[tt][4 * c4]);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        float ro[4], ao[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const carry_t c = s_b[tt][4 * c4 + q];
+          if (MODE == OLY_SCAN_RETURN) {
+            ro[q] = (float)c;
+            ao[q] = ro[q] - vv[q];
+          } else {
+            ao[q] = (float)c;
+            ro[q] = ao[q] + vv[q];
+          }
+        }
+        *reinterpret_cast<float4*>(ret + e) = make_float4(ro[0], ro[1], ro[2], ro[3]);
+        *reinterpret_cast<float4*>(adv + e) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+      }
+    }
+  }
+}
+
 static bool wide_ok(const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
   auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
   return al(a, 15) && al(b, 15) && al(c, 15) && al(d, 3) && al(e, 15) && al(f, 15);
@@ -337,7 +477,7 @@ extern "C" int oly_return_scan(oly_ctx* ctx, int mode, int T, int N, double gamm
   if (T == 0 || N == 0) return OLY_OK;
   if (!rew || !val || !next_val || !flags || !ret || !adv)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: NULL pointer");
-  static const int variant = [] { const char* e = getenv("OLY_K6_VARIANT"); return e ? atoi(e) : 1; }();  // 0 chunk, 1 auto (wide if possible), 3 tile
+  static const int variant = [] { const char* e = getenv("OLY_K6_VARIANT"); return e ? atoi(e) : 1; }();  // 0 chunk, 1 auto (lean if possible, else tile), 2 wide, 3 tile
   dim3 grid((N + 63) / 64);
   if (mode != OLY_SCAN_RETURN && mode != OLY_SCAN_GAE)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: unknown mode %d", mode);
@@ -353,7 +493,14 @@ extern "C" int oly_return_scan(oly_ctx* ctx, int mode, int T, int N, double gamm
     else
       hipLaunchKernelGGL(scan_kernel<OLY_SCAN_GAE>, g0, dim3(64), 0, oly_s(stream), T, N, epw, gamma, lam, rew,
                          val, next_val, flags, ret, adv);
-  } else if (variant == 2 || (variant == 1 && N % 4 == 0 && wide_ok(rew, val, next_val, flags, ret, adv))) {
+  } else if (variant == 1 && N % 4 == 0 && wide_ok(rew, val, next_val, flags, ret, adv)) {
+    if (mode == OLY_SCAN_RETURN)
+      hipLaunchKernelGGL(scan_lean_kernel<OLY_SCAN_RETURN>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
+                         gamma, lam, rew, val, next_val, flags, ret, adv);
+    else
+      hipLaunchKernelGGL(scan_lean_kernel<OLY_SCAN_GAE>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
+                         gamma, lam, rew, val, next_val, flags, ret, adv);
+  } else if (variant == 2 && N % 4 == 0 && wide_ok(rew, val, next_val, flags, ret, adv)) {
     if (mode == OLY_SCAN_RETURN)
       hipLaunchKernelGGL(scan_wide_kernel<OLY_SCAN_RETURN>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
                          gamma, lam, rew, val, next_val, flags, ret, adv);
