@@ -360,14 +360,18 @@ class UnitreeH1(LocoEnvBase):
 
     valid_task_confs = ValidTaskConf(tasks=["walk", "run", "carry"], data_types=["real", "perfect"],
                                      non_combinable=[("carry", None, "perfect")])
+    _spec_fn = staticmethod(_specs.unitree_h1)
+    _default_back = False
 
-    def __init__(self, task="walk", disable_arms=True, disable_back_joint=False, use_foot_forces=False,
+    def __init__(self, task="walk", disable_arms=True, disable_back_joint=None, use_foot_forces=False,
                  use_absorbing_states=True, random_start=True, init_step_no=None, reward_type="target_velocity",
                  num_envs=1, device=0, traj_params=None, physics=None, seed=None, **unused):
         if use_foot_forces:
             raise NotImplementedError("use_foot_forces=True needs the host contact batcher (next-row f1)")
-        self.spec = _specs.unitree_h1(task, disable_arms=disable_arms, disable_back_joint=disable_back_joint,
-                                      use_absorbing_states=use_absorbing_states, reward_type=reward_type)
+        if disable_back_joint is None:
+            disable_back_joint = self._default_back
+        self.spec = self._spec_fn(task, disable_arms=disable_arms, disable_back_joint=disable_back_joint,
+                                  use_absorbing_states=use_absorbing_states, reward_type=reward_type)
         traj = None
         if traj_params:
             traj = self.load_trajectory(traj_params)
@@ -384,19 +388,21 @@ class UnitreeH1(LocoEnvBase):
         return Trajectory(keys=list(sp.obs_keys), low=low[2:], high=high[2:], joint_pos_idx=np.arange(sp.n_pos),
                           warn=warn, **traj_params)
 
-    @staticmethod
-    def generate(task="walk", dataset_type="real", traj_path=None, **kwargs):
-        check_validity_task_mode_dataset("UnitreeH1", task, None, dataset_type, *UnitreeH1.valid_task_confs.get_all())
+    @classmethod
+    def generate(cls, task="walk", dataset_type="real", traj_path=None, **kwargs):
+        check_validity_task_mode_dataset(cls.__name__, task, None, dataset_type, *cls.valid_task_confs.get_all())
         traj_dt = 1 / 500 if dataset_type == "real" else 1 / 100       # base_humanoid_robot.py:164,188
         if traj_path is not None:
             tp = dict(traj_path=traj_path, traj_dt=traj_dt, control_dt=0.01, clip_trajectory_to_joint_ranges=True)
         else:
             # the reference's datasets are not distributed with it (README: external download);
             # fall back to the seeded synthetic trajectory of the same wire format
-            sp = _specs.unitree_h1(task, **{k: kwargs[k] for k in ("disable_arms", "disable_back_joint") if k in kwargs})
+            sk = {k: kwargs[k] for k in ("disable_arms", "disable_back_joint") if kwargs.get(k) is not None}
+            sk.setdefault("disable_back_joint", cls._default_back)
+            sp = cls._spec_fn(task, **sk)
             files = synthetic_h1_trajectory_files(sp, traj_dt=traj_dt)
             tp = dict(traj_files=files, traj_dt=traj_dt, control_dt=0.01, clip_trajectory_to_joint_ranges=True)
-        return UnitreeH1(task=task, traj_params=tp, **kwargs)
+        return cls(task=task, traj_params=tp, **kwargs)
 
     # ----- reference single-env API (N = 1 view)
     def _one(self):
@@ -446,4 +452,20 @@ class UnitreeH1(LocoEnvBase):
         pass
 
 
+class Atlas(UnitreeH1):
+    """Atlas (reference: real_humanoid_robots/atlas.py; back joints disabled by default :26)."""
+    valid_task_confs = ValidTaskConf(tasks=["walk"], data_types=["real", "perfect"])
+    _spec_fn = staticmethod(_specs.atlas)
+    _default_back = True
+
+
+class Talos(UnitreeH1):
+    """Talos (reference: real_humanoid_robots/talos.py)."""
+    valid_task_confs = ValidTaskConf(tasks=["walk"], data_types=["real", "perfect"])
+    _spec_fn = staticmethod(_specs.talos)
+    _default_back = False
+
+
 UnitreeH1.register()
+Atlas.register()
+Talos.register()

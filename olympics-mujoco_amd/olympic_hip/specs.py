@@ -208,6 +208,58 @@ def unitree_h1(task: str = "walk", disable_arms: bool = True, disable_back_joint
                          use_absorbing_states=use_absorbing_states)
 
 
+# ------------------------------------------------------------------------- Atlas / Talos
+def _il_robot(name, removed, fall, names, task, reward_type, use_absorbing_states):
+    from .robot_data import ROBOTS
+    if task not in ("walk",):
+        raise ValueError(f"Task \"{task}\" does not exit in the environment {name}.")
+    rt = {"target_velocity": _abi.REWARD_TARGET_VELOCITY, "x_pos": _abi.REWARD_X_POS, None: _abi.REWARD_NONE}
+    if reward_type not in rt:
+        raise NotImplementedError("The specified reward has not been implemented: %s" % reward_type)
+    d = ROBOTS[name]
+    return build_il_spec(name, d["obs_joints"], removed, d["actions"], d["joints"], d["motors"], d["ctrlrange"],
+                         fall, names, reward_type=rt[reward_type], target_velocity=1.25,
+                         use_absorbing_states=use_absorbing_states)
+
+
+_PELVIS_NAMES = ["pelvis_y_condition", "pelvis_tilt_condition", "pelvis_list_condition", "pelvis_rotation_condition"]
+
+
+def _pelvis_tests(rot):
+    pi = np.pi
+    return [("q_pelvis_ty", -0.3, 0.1), ("q_pelvis_tilt", -pi / 4.5, pi / 12), ("q_pelvis_list", -pi / 12, pi / 8),
+            ("q_pelvis_rotation", -rot, rot)]
+
+
+def atlas(task="walk", disable_arms=True, disable_back_joint=True, use_absorbing_states=True,
+          reward_type="target_velocity") -> ILRobotSpec:
+    """Atlas tables (real_humanoid_robots/atlas.py: spec lists, removal :86-112, _has_fallen :118-170)."""
+    from .robot_data import ROBOTS
+    pi = np.pi
+    removed = (ROBOTS["Atlas"]["arm_joints"] if disable_arms else []) + \
+              (ROBOTS["Atlas"]["back_joints"] if disable_back_joint else [])
+    fall, names = _pelvis_tests(pi / 10), list(_PELVIS_NAMES)
+    if not disable_back_joint:
+        fall += [("q_back_bky", -pi / 4, pi / 10), ("q_back_bkx", -pi / 10, pi / 10),
+                 ("q_back_bkz", -pi / 4.5, pi / 4.5)]
+        names += ["back_extension_condition", "back_bending_condition", "back_rotation_condition"]
+    return _il_robot("Atlas", removed, fall, names, task, reward_type, use_absorbing_states)
+
+
+def talos(task="walk", disable_arms=True, disable_back_joint=False, use_absorbing_states=True,
+          reward_type="target_velocity") -> ILRobotSpec:
+    """Talos tables (real_humanoid_robots/talos.py: removal :86-112, _has_fallen :114-160)."""
+    from .robot_data import ROBOTS
+    pi = np.pi
+    removed = (ROBOTS["Talos"]["arm_joints"] if disable_arms else []) + \
+              (ROBOTS["Talos"]["back_joints"] if disable_back_joint else [])
+    fall, names = _pelvis_tests(pi / 10), list(_PELVIS_NAMES)
+    if not disable_back_joint:
+        fall += [("q_back_bky", -pi / 4, pi / 10), ("q_back_bkz", -pi / 10, pi / 10)]
+        names += ["back_extension_condition", "back_rotation_condition"]
+    return _il_robot("Talos", removed, fall, names, task, reward_type, use_absorbing_states)
+
+
 # ------------------------------------------------------------------------ StickFigureA3
 
 @dataclass

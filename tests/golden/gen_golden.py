@@ -35,6 +35,8 @@ fixtures do.  Fixture -> reference function map (file:line in /root/reference):
                   SymmetricEnv.mirror_* (:51-72), A3 tables (StickFigureA3.py:118-129)
   ppo_update.npz  PPO.update_policy (rl/algos/ppo.py:232-282) with Gaussian_FF_Actor / FF_V
                   (rl/policies/actor.py:142, critic.py:37) and the A3 mirror functions
+  atlas_tables.npz, talos_tables.npz  spec lists / removal / _has_fallen of atlas.py, talos.py
+                  and the joint/actuator order of their MJCF data files
   vail_disc.npz   Standardizer/FullyConnectedNetwork/VariationalNet forward
                   (imitation_lib/utils/networks.py), GAIL.make_discrim_reward
                   (imitation_lib/imitation/gail_TRPO.py:320), GailDiscriminatorLoss
@@ -832,8 +834,48 @@ def gen_ppo_update():
          mirrored_acts=np.array(mirrored_acts), **vals, **arrs)
 
 
+# -------------------------------------------------------- G11 Atlas / Talos (table-driven robots)
+def gen_il_robot(cls_name, mod, xml, defaults):
+    import importlib
+    m = importlib.import_module(f"olympic_mujoco.environments.real_humanoid_robots.{mod}")
+    cls = getattr(m, cls_name)
+    rng = np.random.default_rng(abs(hash(cls_name)) % 1000)
+    out = {}
+    for tag, (arms, back) in (("default", defaults), ("all_joints", (False, False))):
+        env = cls.__new__(cls)
+        env._disable_arms, env._disable_back_joint = arms, back
+        env._algorithm_type = AlgorithmType.IMITATION_LEARNING
+        env._use_foot_forces, env._use_absorbing_states = False, True
+        jr, mr, _ = env._get_xml_modifications()
+        spec = [e for e in cls._get_observation_specification()
+                if e[0] not in ["q_" + j for j in jr] + ["dq_" + j for j in jr]]
+        act = [a for a in cls._get_action_specification() if a not in mr]
+        env.obs_helper = stubs.FakeObservationHelper(spec)
+        joints, motors, nq, nv = walk_mjcf(f"{REF}/olympic_mujoco/environments/data/{xml}", jr, mr)
+        qadr = {j[0]: j[1] for j in joints}
+        mname = [mm[0] for mm in motors]
+        n_pos = sum(1 for e in spec if e[2] == OT.JOINT_POS)
+        M = 512
+        obs = rng.uniform(-0.9, 0.9, (M, len(spec) - 2))
+        obs[:, 0] = rng.uniform(-0.4, 0.2, M)
+        fallen = np.zeros(M, bool)
+        code = np.zeros(M, np.int32)
+        import inspect
+        src = inspect.getsource(cls._has_fallen)
+        # condition names in the order of the reference's if/elif message chain
+        names = [ln.split('"')[1].split(" violated")[0] for ln in src.splitlines() if "error_msg +=" in ln]
+        for i in range(M):
+            f, msg = env._has_fallen(obs[i], return_err_msg=True)
+            fallen[i] = f
+            code[i] = 0 if not msg else names.index(msg.split(" violated")[0]) + 1
+        out[tag] = dict(keys=np.array([e[0] for e in spec]), qpos_perm=np.array([qadr[e[1]] for e in spec[:n_pos]]),
+                        act_to_ctrl=np.array([mname.index(a) for a in act]), nq=nq, n_pos=n_pos,
+                        obs=obs, fallen=fallen, code=code, cond_names=np.array(names))
+    save(f"{cls_name.lower()}_tables.npz", **{f"{t}.{k}": v for t, d in out.items() for k, v in d.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd"]
+    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd", "robots"]
     tab = gen_h1_tables() if any(w in which for w in ("tables", "h1", "traj")) else None
     if "h1" in which:
         gen_h1_step(tab)
@@ -853,3 +895,6 @@ if __name__ == "__main__":
         gen_vail()
     if "ppoupd" in which:
         gen_ppo_update()
+    if "robots" in which:
+        gen_il_robot("Atlas", "atlas", "atlas/atlas.xml", (True, True))
+        gen_il_robot("Talos", "talos", "talos/talos.xml", (True, False))

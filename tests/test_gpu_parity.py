@@ -577,3 +577,30 @@ def test_random_table_driven_robots(eng, oracle, seed):
         ref = oracle.il_step(sp, qpos, qvel, act, prev, obs_f64=f64, ctrl_f64=f64)
         _cmp_il(o, ref, f64)
     assert (np.asarray(ref["fall_code"]) > 0).any() or len(sp.fall_tests) == 0
+
+
+@pytest.mark.parametrize("robot", ["atlas", "talos"])
+def test_atlas_talos_on_gpu(eng, golden, oracle, robot):
+    g = golden(f"{robot}_tables.npz")
+    for tag, kw in (("default", {}), ("all_joints", dict(disable_arms=False, disable_back_joint=False))):
+        sp = getattr(specs, robot)("walk", **kw)
+        obs = g[f"{tag}.obs"]
+        full = np.concatenate([np.zeros((len(obs), 2)), obs], axis=1)
+        qpos, qvel = h1_rows_from_full(sp, full)
+        rng = np.random.default_rng(3)
+        act = rng.uniform(-1.2, 1.2, (1, len(obs), sp.n_act)).astype(np.float32)
+        prev = rng.normal(1.25, 0.4, len(obs))
+        o = _run_il(eng, sp, qpos[None], qvel[None], act, prev, obs_f64=True)
+        ref = oracle.il_step(sp, qpos[None], qvel[None], act, prev, obs_f64=True)
+        _cmp_il(o, ref, True)
+        assert np.array_equal(o["fall_code"][0], g[f"{tag}.code"])          # vs the reference class
+        assert np.array_equal(o["absorbing"][0].astype(bool), g[f"{tag}.fallen"])
+
+
+def test_make_atlas_env_steps(eng):
+    from olympic_hip.envs import LocoEnvBase
+    env = LocoEnvBase.make("Atlas.walk.real", seed=1)
+    obs = env.reset()
+    assert obs.shape == (env.spec.n_obs,) == (30,)
+    o2, r, ab, _ = env.step(np.zeros(env.spec.n_act))
+    assert o2.shape == (30,) and 0.0 < r <= 1.0 and ab is False

@@ -329,3 +329,36 @@ def test_ppo_update_policy_matches_reference(golden, tmp_path):
         np.testing.assert_allclose(float(v), float(g[n]), rtol=2e-5, atol=2e-7, err_msg=n)
     out2 = ppo.update_policy(t("obs"), t("act"), t("ret"), t("adv"), 1)
     assert float(out2[4]) == float(g["mirror_loss_none"]) == 0.0
+
+
+# ------------------------------------------------------------------------------ Atlas / Talos
+@pytest.mark.parametrize("robot", ["atlas", "talos"])
+def test_atlas_talos_tables_and_has_fallen(golden, oracle, robot):
+    """The IL kernel is table-driven: Atlas and Talos are data.  Tables and _has_fallen (first
+    violated condition of the elif chain) against the reference classes."""
+    g = golden(f"{robot}_tables.npz")
+    fn = getattr(specs, robot)
+    for tag, kw in (("default", {}), ("all_joints", dict(disable_arms=False, disable_back_joint=False))):
+        sp = fn("walk", **kw)
+        assert sp.obs_keys == list(g[f"{tag}.keys"])
+        assert (sp.nq, sp.n_pos) == (int(g[f"{tag}.nq"]), int(g[f"{tag}.n_pos"]))
+        assert np.array_equal(sp.qpos_adr, g[f"{tag}.qpos_perm"])
+        assert np.array_equal(sp.act_to_ctrl, g[f"{tag}.act_to_ctrl"])
+        assert sp.fall_names == list(g[f"{tag}.cond_names"])[:len(sp.fall_names)]
+        obs = g[f"{tag}.obs"]
+        full = np.concatenate([np.zeros((len(obs), 2)), obs], axis=1)
+        from olympic_hip.synthetic import h1_rows_from_full
+        qpos, qvel = h1_rows_from_full(sp, full)
+        o = oracle.il_step(sp, qpos[None], qvel[None], None, np.zeros(len(obs)), obs_f64=True)
+        assert np.array_equal(o["obs"][0], obs)
+        assert np.array_equal(o["absorbing"][0].astype(bool), g[f"{tag}.fallen"])
+        assert np.array_equal(o["fall_code"][0], g[f"{tag}.code"])
+
+
+def test_atlas_talos_registered():
+    from olympic_hip.envs import Atlas, LocoEnvBase, Talos
+    names = LocoEnvBase.get_all_task_names()
+    assert "Atlas.walk.real" in names and "Talos.walk.perfect" in names
+    with pytest.raises(ValueError):
+        Atlas.generate("run", "real")
+    assert Talos._default_back is False and Atlas._default_back is True
