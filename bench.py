@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--N", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fall-code", action="store_true", help="also write the fall-code byte")
+    ap.add_argument("--robot", default="h1", choices=["h1", "atlas", "talos", "h1_arms"],
+                    help="h1 is the BASELINE config; the others exercise the same kernel on other tables")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to "
                          "rehearse the multi-rank path on a one-GPU box)")
@@ -110,7 +112,9 @@ def main():
     from olympic_hip.engine import Engine
     from olympic_hip.synthetic import h1_synthetic_block
 
-    spec = specs.unitree_h1("walk")
+    spec = {"h1": lambda: specs.unitree_h1("walk"), "atlas": lambda: specs.atlas("walk"),
+            "talos": lambda: specs.talos("walk"),
+            "h1_arms": lambda: specs.unitree_h1("walk", disable_arms=False)}[args.robot]()
     eng = Engine(local_rank).il_configure(spec)
     T, N = args.T, args.N
     qpos_h, qvel_h, act_h = h1_synthetic_block(spec, T, N, seed=1234 + 17 * rank)
@@ -165,7 +169,7 @@ def main():
         achieved = bpr * rows / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_k1.json")
-        if os.path.exists(tpath) and (T, N) == (400, 4096) and not args.fall_code:
+        if os.path.exists(tpath) and (T, N) == (400, 4096) and not args.fall_code and args.robot == "h1":
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -183,14 +187,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "UnitreeH1.walk config-2: fused K1+K5 over one [T,N] block per step",
+            "config": {"workload": ("UnitreeH1.walk config-2" if args.robot == "h1" else args.robot + ".walk") +
+                                   ": fused K1+K5 over one [T,N] block per step",
                        "T": T, "envs_per_gpu": N, "env_steps_per_step": rows * world,
                        "launch_regime": "[T,N] block per launch", "fallen_fraction": fallen,
                        "io": "qpos/qvel f64 + action f32 in; obs/reward/ctrl f32 + absorbing u8 out",
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "il_tile_kernel<128,H1>", "kernel_ms": kern_ms,
+                         "kernel": "il_tile_kernel<128,%s>" % args.robot if args.robot != "h1_arms" else
+                                   "il_step_kernel<64,DynDims>", "kernel_ms": kern_ms,
                          "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
         }
         if world == 1 and not args.no_cpu_baseline:

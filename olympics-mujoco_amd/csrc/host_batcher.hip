@@ -135,6 +135,12 @@ extern "C" double* oly_batcher_qpos(oly_batcher* b) { return b ? b->h_qpos : nul
 extern "C" double* oly_batcher_qvel(oly_batcher* b) { return b ? b->h_qvel : nullptr; }
 extern "C" double* oly_batcher_prev(oly_batcher* b) { return b ? b->d_prev : nullptr; }
 
+extern "C" int oly_batcher_set_prev(oly_batcher* b, const double* prev_dev, oly_stream stream) {
+  if (!b || !prev_dev) return OLY_EINVAL;
+  OLY_HIP(b->ctx, hipMemcpyAsync(b->d_prev, prev_dev, sizeof(double) * b->N, hipMemcpyDeviceToDevice, oly_s(stream)));
+  return OLY_OK;
+}
+
 extern "C" int oly_batcher_last_timing(const oly_batcher* b, double out3[3]) {
   if (!b || !out3) return OLY_EINVAL;
   for (int i = 0; i < 3; ++i) out3[i] = b->timing[i];

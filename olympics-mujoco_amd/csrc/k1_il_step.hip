@@ -457,9 +457,9 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
   constexpr int KQ = (CQ + THREADS - 1) / THREADS, KV = (CV + THREADS - 1) / THREADS,
                 KA = (CA + THREADS - 1) / THREADS;
   constexpr int OW = OBS64 ? 2 : 4;                 // obs values per lane store
-  static_assert((THREADS * OW) % NO == 0, "fast path: lane-invariant obs columns");
-  constexpr int NIT = (ROWS * NO / OW) / THREADS;   // obs stores per lane per tile
-  static_assert((ROWS * NO / OW) % THREADS == 0, "obs sweep must tile evenly");
+  static_assert((ROWS * NO) % OW == 0, "observation tile must split into whole lane vectors");
+  constexpr int NOV = ROWS * NO / OW;               // obs vectors per tile
+  constexpr int NIT = (NOV + THREADS - 1) / THREADS; // obs stores per lane per tile
   constexpr int CW = CTRL64 ? 2 : 4;                // ctrl values per lane store
   constexpr int NCV = ROWS * NU / CW;               // ctrl vectors per tile
   constexpr int NCI = (NCV + THREADS - 1) / THREADS;
@@ -485,18 +485,22 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
     t_act[2 * NU + j] = md->ctrl_lo[kk];
     t_act[3 * NU + j] = md->ctrl_hi[kk];
   }
-  int my_off[OW], my_str[OW];                 // obs columns of this lane
-  {
-    const int c0 = (tid * OW) % NO;
+  // The tile-local position of every value a lane stores is the same for every tile, so the
+  // LDS element it reads (column permutation + row stride) is computed ONCE: e_off[it][k].
+  int e_off[NIT][OW];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
 #pragma unroll
     for (int k = 0; k < OW; ++k) {
-      const int sidx = md->src[c0 + k];
-      my_off[k] = col_off(sidx);
-      my_str[k] = col_str(sidx);
+      const int e = (tid + it * THREADS) * OW + k;
+      int off = 0;
+      if (e < ROWS * NO) {
+        const int r = e / NO, c = e - r * NO;
+        const int sidx = md->src[c];
+        off = col_off(sidx) + r * col_str(sidx);
+      }
+      e_off[it][k] = off;
     }
-  }
-  const int my_r0 = tid * OW / NO;            // first row of this lane in the obs sweep
-  constexpr int RSTEP = THREADS * OW / NO;
   int c_aidx[NCI][CW];                        // ctrl elements of this lane: LDS index of the
   int c_j[NCI][CW];                           // action value (-1: actuator not driven), actuator
 #pragma unroll
@@ -626,18 +630,21 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
 #pragma unroll
-        for (int k = 0; k < OW; ++k) v[it][k] = sq[my_off[k] + (my_r0 + it * RSTEP) * my_str[k]];
+        for (int k = 0; k < OW; ++k) v[it][k] = sq[e_off[it][k]];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        if (OBS64) {
-          f64x2 o;
-          o.x = v[it][0]; o.y = v[it][OW - 1];
-          st16(reinterpret_cast<f64x2*>(static_cast<double*>(p.obs) + row0 * NO) + tid + it * THREADS, o);
-        } else {
-          f32x4 o;
-          o.x = (float)v[it][0]; o.y = (float)v[it][1 % OW];
-          o.z = (float)v[it][2 % OW]; o.w = (float)v[it][3 % OW];
-          st16(reinterpret_cast<f32x4*>(static_cast<float*>(p.obs) + row0 * NO) + tid + it * THREADS, o);
+        const int i = tid + it * THREADS;
+        if (it * THREADS + THREADS <= NOV || i < NOV) {
+          if (OBS64) {
+            f64x2 o;
+            o.x = v[it][0]; o.y = v[it][OW - 1];
+            st16(reinterpret_cast<f64x2*>(static_cast<double*>(p.obs) + row0 * NO) + i, o);
+          } else {
+            f32x4 o;
+            o.x = (float)v[it][0]; o.y = (float)v[it][1 % OW];
+            o.z = (float)v[it][2 % OW]; o.w = (float)v[it][3 % OW];
+            st16(reinterpret_cast<f32x4*>(static_cast<float*>(p.obs) + row0 * NO) + i, o);
+          }
         }
       }
     }
@@ -699,7 +706,9 @@ __global__ __launch_bounds__(THREADS) void il_ctrl_kernel(const IlDev* __restric
   }
 }
 
-using H1Dims = StaticDims<17, 17, 0, 11, 11, 32>;
+using H1Dims = StaticDims<17, 17, 0, 11, 11, 32>;      // UnitreeH1, arms removed
+using AtlasDims = StaticDims<16, 16, 0, 10, 10, 30>;   // Atlas, arms + back removed (default)
+using TalosDims = StaticDims<18, 18, 0, 12, 12, 34>;   // Talos, arms removed (default)
 
 template <int ROWS, class D>
 int launch_generic(oly_ctx* ctx, IlArgs a, long tile0, int out_flags, hipStream_t s) {
@@ -858,8 +867,16 @@ extern "C" int oly_il_step(oly_ctx* ctx, int T, int N, const double* qpos, const
            ((reinterpret_cast<uintptr_t>(absorbing) & 3) == 0) &&
            ((reinterpret_cast<uintptr_t>(fall_code) & 3) == 0);
   a.tile0 = 0;
-  const bool is_h1 = h.nq == 17 && h.nv == 17 && h.n_grf == 0 && h.n_act == 11 && h.nu == 11 && h.n_obs == 32;
-  if (is_h1 && a.fast && h.n_fall <= FAST_FALL) {
+  auto shape = [&](int nq, int na, int no) {
+    return h.nq == nq && h.nv == nq && h.n_grf == 0 && h.n_act == na && h.nu == na && h.n_obs == no &&
+           h.n_pos == nq && h.n_vel == nq && h.n_drop == 2;
+  };
+  const bool fast_ok = a.fast && h.n_fall <= FAST_FALL;
+  static const int wg_env2 = [] { const char* e = getenv("OLY_K1_WG_PER_CU"); return e ? atoi(e) : 0; }();
+  if (fast_ok && shape(16, 10, 30)) return launch_fast<128, AtlasDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
+  if (fast_ok && shape(18, 12, 34)) return launch_fast<128, TalosDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
+  const bool is_h1 = shape(17, 11, 32);
+  if (is_h1 && fast_ok) {
     static const int rows_env = [] { const char* e = getenv("OLY_K1_ROWS"); return e ? atoi(e) : 0; }();
     static const int wg_env = [] { const char* e = getenv("OLY_K1_WG_PER_CU"); return e ? atoi(e) : 0; }();
     if (rows_env == 64) return launch_fast<64, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));

@@ -72,6 +72,7 @@ SIGNATURES = {
     "oly_batcher_qpos": (C.POINTER(C.c_double), [vp]),
     "oly_batcher_qvel": (C.POINTER(C.c_double), [vp]),
     "oly_batcher_prev": (vp, [vp]),
+    "oly_batcher_set_prev": (C.c_int, [vp, vp, vp]),
     "oly_batcher_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "oly_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "oly_traj_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -49,12 +49,9 @@ class HostBatcher:
         t = torch.as_tensor(prev, dtype=torch.float64, device=self.eng.device).contiguous()
         if t.shape != (self.N,):
             raise OlyError(f"prev: shape {tuple(t.shape)}, expected ({self.N},)")
-        dst = lib().oly_batcher_prev(self._h)
-        hip = C.CDLL("libamdhip64.so")                       # device-to-device copy of N doubles
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        rc = hip.hipMemcpy(dst, t.data_ptr(), 8 * self.N, 3)  # hipMemcpyDeviceToDevice
-        if rc:
-            raise OlyError(f"hipMemcpy failed: {rc}")
+        rc = lib().oly_batcher_set_prev(self._h, ptr(t), self.eng._s())
+        check(self.eng.ctx.handle, rc, "oly_batcher_set_prev")
+        torch.cuda.current_stream(self.eng.device).synchronize()   # `t` may be a temporary
 
     def step(self, action):
         sp = self.spec

@@ -258,6 +258,15 @@ class VecLocoEnv:
         info = dict(fall_code=o["fall_code"][0], last=last, ctrl=o["ctrl"][0] if o["ctrl"] is not None else None)
         return self._obs, o["reward"][0], absorbing, info
 
+    # ----- block regime: T pre-computed physics states in ONE launch (what bench.py times)
+    def evaluate_block(self, qpos, qvel, actions=None, prev=None):
+        """qpos/qvel [T,N,*] f64 (+ actions [T,N,n_act] f32) -> dict(obs, reward, absorbing,
+        fall_code, ctrl, prev) with the per-env reward chain carried through the block; the
+        env's own carried state is not touched."""
+        if prev is None:
+            prev = self._prev.clone()
+        return self.eng.il_step(qpos, qvel, actions, prev, obs_f64=self.obs_f64)
+
     # ----- trajectory replay (loco_env_base.py:444-560)
     def play_trajectory_from_velocity(self, n_steps, record=True):
         """Advance all N envs along their reference trajectories by explicit Euler on the

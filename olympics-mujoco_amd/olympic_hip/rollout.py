@@ -122,3 +122,28 @@ def collect(env, policy, critic, buf, max_traj_len, deterministic=False):
             traj_len = torch.where(cut, torch.zeros_like(traj_len), traj_len)
         state = next_state
     return buf
+
+
+@torch.no_grad()
+def get_normalization_params(iters, policy, env, noise_std, engine=None):
+    """Observation mean / std from a noisy rollout, as rl/envs/normalize.py:35-48 computes them
+    (np.mean(states, 0), np.sqrt(np.var(states, 0) + 1e-8)) - with N environments in lock step
+    instead of `procs` ray workers, and the column sums reduced on the device (oly_col_stats).
+    Returns float64 numpy arrays like the reference."""
+    eng = engine or env.eng
+    N = env.num_envs
+    steps = max(1, iters // N)
+    state = env.reset().to(torch.float32)
+    cs = None
+    for _ in range(steps):
+        cs = eng.col_stats(state.contiguous(), cs)
+        action = policy(state)
+        action = action + torch.randn_like(action) * noise_std
+        state, _, done, _ = env.step(action)
+        state = state.to(torch.float32)
+        if bool(done.any()):
+            state = torch.where(done.bool().unsqueeze(1), env.reset(env_mask=done.bool()).to(torch.float32), state)
+    cnt = cs[0]
+    mean = cs[1] / cnt
+    var = torch.clamp(cs[2] / cnt - mean * mean, min=0.0)
+    return mean.cpu().numpy(), torch.sqrt(var + 1e-8).cpu().numpy()

@@ -370,3 +370,32 @@ def test_il_ctrl_matches_il_step(oracle):
     eng.ctx.call("oly_il_ctrl", N, _ffi.ptr(a), _ffi.ptr(out), _abi.OUT_CTRL_F64, eng._s())
     ref = oracle.il_step(sp, qpos, qvel, host(a)[None], np.zeros(N), ctrl_f64=True)
     assert np.array_equal(host(out), ref["ctrl"][0])
+
+
+def test_get_normalization_params_and_block_eval(oracle):
+    from olympic_hip.envs import LocoEnvBase
+    from olympic_hip.rollout import get_normalization_params
+    env = LocoEnvBase.make("UnitreeH1.walk.real", num_envs=64, seed=5).vec
+    torch.manual_seed(0)
+    policy = torch.nn.Linear(32, 11).cuda()
+    seen = []
+    orig = env.eng.col_stats
+
+    def spy(x, cs=None):
+        seen.append(host(x).copy())
+        return orig(x, cs)
+    env.eng.col_stats = spy
+    mean, std = get_normalization_params(64 * 5, policy, env, 0.1)
+    env.eng.col_stats = orig
+    states = np.concatenate(seen).astype(np.float64)
+    assert states.shape == (320, 32)
+    np.testing.assert_allclose(mean, states.mean(0), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(std, np.sqrt(states.var(0) + 1e-8), rtol=1e-8)
+    # block evaluation = the [T,N] regime of bench.py through the facade
+    sp = env.spec
+    qpos, qvel, act = h1_synthetic_block(sp, 6, 64, seed=9, fall_frac="wide")
+    prev = np.zeros(64)
+    o = env.evaluate_block(torch.as_tensor(qpos).cuda(), torch.as_tensor(qvel).cuda(), torch.as_tensor(act).cuda(),
+                           torch.as_tensor(prev).cuda())
+    ref = oracle.il_step(sp, qpos, qvel, act, prev, obs_f64=True)
+    assert np.array_equal(host(o["obs"]), ref["obs"]) and np.array_equal(host(o["absorbing"]), ref["absorbing"])
