@@ -706,6 +706,246 @@ __global__ __launch_bounds__(THREADS) void il_ctrl_kernel(const IlDev* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Persistent tile kernel for RUNTIME robot dimensions (any table-driven robot, foot-force
+// columns included): same life cycle as il_tile_kernel, but the per-element source offsets
+// live in LDS tables built once per workgroup (eo: observation element -> staged element,
+// co: control element -> staged action element | actuator) instead of registers.
+// ------------------------------------------------------------------------------------
+constexpr int DYN_ROWS = 64;
+
+struct DynCarve {
+  int a, eo, co, tact, total;
+  __host__ __device__ DynCarve(int nq, int nv, int n_grf, int n_act, int nu, int n_obs) {
+    auto al = [](int x) { return (x + 15) & ~15; };
+    a = al(DYN_ROWS * (nq + nv + n_grf) * 8);
+    eo = al(a + DYN_ROWS * n_act * 4);
+    co = al(eo + DYN_ROWS * n_obs * 4);
+    tact = al(co + DYN_ROWS * nu * 4);
+    total = al(tact + 4 * nu * 8);
+  }
+};
+
+template <bool OBS64, bool CTRL64>
+__global__ __launch_bounds__(THREADS) void il_dyn_tile_kernel(IlArgs p) {
+  constexpr int ROWS = DYN_ROWS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const IlDev* __restrict__ md = p.md;
+  const int nq = md->nq, nv = md->nv, n_grf = md->n_grf, n_act = md->n_act, nu = md->nu, n_obs = md->n_obs;
+  const DynCarve cv(nq, nv, n_grf, n_act, nu, n_obs);
+  const int tid = threadIdx.x, lane = tid & 63;
+  double* sq = reinterpret_cast<double*>(lds);
+  float* sa = reinterpret_cast<float*>(lds + cv.a);
+  unsigned* eo = reinterpret_cast<unsigned*>(lds + cv.eo);   // bit 31: divide by 1000 (grf column)
+  int* co = reinterpret_cast<int*>(lds + cv.co);             // (action element << 8) | actuator, -1: none
+  double* t_act = reinterpret_cast<double*>(lds + cv.tact);  // per ACTUATOR: mean|delta|lo|hi
+  const bool with_ctrl = p.ctrl != nullptr;
+  const int first_grf = n_obs - n_grf;
+
+  auto col_off = [&](int sidx) -> int {
+    if (sidx < nq) return sidx;
+    if (sidx < nq + nv) return ROWS * nq + (sidx - nq);
+    return ROWS * (nq + nv) + (sidx - nq - nv);
+  };
+  auto col_str = [&](int sidx) -> int { return sidx < nq ? nq : (sidx < nq + nv ? nv : n_grf); };
+
+  // ---- once per workgroup: element tables
+  for (int e = tid; e < ROWS * n_obs; e += THREADS) {
+    const int r = e / n_obs, c = e - r * n_obs;
+    const int sidx = md->src[c];
+    eo[e] = (unsigned)(col_off(sidx) + r * col_str(sidx)) | (c >= first_grf && n_grf > 0 ? 0x80000000u : 0u);
+  }
+  for (int e = tid; e < ROWS * nu; e += THREADS) {
+    const int r = e / nu, j = e - r * nu;
+    const int k = md->ctrl_src[j];
+    co[e] = k < 0 ? -1 : (((r * n_act + k) << 8) | j);
+  }
+  for (int j = tid; j < nu; j += THREADS) {
+    const int k = md->ctrl_src[j];
+    const int kk = k < 0 ? 0 : k;
+    t_act[j] = md->act_mean[kk];
+    t_act[nu + j] = md->act_delta[kk];
+    t_act[2 * nu + j] = md->ctrl_lo[kk];
+    t_act[3 * nu + j] = md->ctrl_hi[kk];
+  }
+  const int nf = md->n_fall;
+  const int rt = md->reward_type;
+  const int rew_sidx = md->reward_sidx;
+  const bool rew_grf = n_grf > 0 && md->reward_idx >= first_grf;
+  const double tvel = md->target_velocity;
+  const int use_abs = md->use_absorbing;
+  auto rew_f = [&](double s) -> float {
+    if (rt == OLY_REWARD_TARGET_VELOCITY) {
+      const double dv = s - tvel;
+      return (float)exp(-(dv * dv));
+    }
+    return (float)s;
+  };
+
+  // 16-B chunks per array and tile; each array is prefetched by its own short register run
+  // (base pointer + lane + k * THREADS: no per-chunk pointer arithmetic)
+  const int cq = ROWS * nq / 2, cvv = ROWS * nv / 2, cg = ROWS * n_grf / 2;
+  const int ca = with_ctrl ? ROWS * n_act / 4 : 0;
+  constexpr int KQ = 5, KG = 1, KA = 3;   // covers nq,nv <= 40, n_grf <= 8, n_act <= 48 at 64 rows
+  u32x4 rq[KQ], rv[KQ], rg[KG], ra[KA];
+  u32x4* lq = reinterpret_cast<u32x4*>(sq);
+  u32x4* lv = lq + cq;
+  u32x4* lg = lv + cvv;
+  u32x4* la = reinterpret_cast<u32x4*>(sa);
+  auto issue_loads = [&](long t) {
+    const long r0 = t * ROWS;
+    const u32x4* gq = reinterpret_cast<const u32x4*>(p.qpos + r0 * nq) + tid;
+    const u32x4* gv = reinterpret_cast<const u32x4*>(p.qvel + r0 * nv) + tid;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+      if (tid + k * THREADS < cq) rq[k] = ld16(gq + k * THREADS);
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+      if (tid + k * THREADS < cvv) rv[k] = ld16(gv + k * THREADS);
+    if (cg > 0) {
+      const u32x4* gg = reinterpret_cast<const u32x4*>(p.grf + r0 * n_grf) + tid;
+#pragma unroll
+      for (int k = 0; k < KG; ++k)
+        if (tid + k * THREADS < cg) rg[k] = ld16(gg + k * THREADS);
+    }
+    if (ca > 0) {
+      const u32x4* ga = reinterpret_cast<const u32x4*>(p.action + r0 * n_act) + tid;
+#pragma unroll
+      for (int k = 0; k < KA; ++k)
+        if (tid + k * THREADS < ca) ra[k] = ld16(ga + k * THREADS);
+    }
+  };
+  auto land = [&](long row0) {
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+      if (tid + k * THREADS < cq) lq[tid + k * THREADS] = rq[k];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+      if (tid + k * THREADS < cvv) lv[tid + k * THREADS] = rv[k];
+#pragma unroll
+    for (int k = 0; k < KG; ++k)
+      if (tid + k * THREADS < cg) lg[tid + k * THREADS] = rg[k];
+#pragma unroll
+    for (int k = 0; k < KA; ++k)
+      if (tid + k * THREADS < ca) la[tid + k * THREADS] = ra[k];
+    // chunks beyond the register runs (very wide robots): plain staged copy
+    for (int g = tid + KQ * THREADS; g < cq; g += THREADS)
+      lq[g] = ld16(reinterpret_cast<const u32x4*>(p.qpos + row0 * nq) + g);
+    for (int g = tid + KQ * THREADS; g < cvv; g += THREADS)
+      lv[g] = ld16(reinterpret_cast<const u32x4*>(p.qvel + row0 * nv) + g);
+    for (int g = tid + KG * THREADS; g < cg; g += THREADS)
+      lg[g] = ld16(reinterpret_cast<const u32x4*>(p.grf + row0 * n_grf) + g);
+    for (int g = tid + KA * THREADS; g < ca; g += THREADS)
+      la[g] = ld16(reinterpret_cast<const u32x4*>(p.action + row0 * n_act) + g);
+  };
+
+  const long ntiles = p.tile0;
+  long tile = blockIdx.x;
+  if (tile < ntiles) issue_loads(tile);
+  __syncthreads();  // tables
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long row0 = tile * ROWS;
+    land(row0);
+    __syncthreads();
+    const long next = tile + gridDim.x;
+    if (next < ntiles) issue_loads(next);
+
+    // ---- per-row scalars (wave 0: ROWS == 64)
+    if (tid < ROWS) {
+      const int r = tid;
+      const long gr = row0 + r;
+      unsigned code = 0;
+      for (int k = 0; k < nf; ++k) {
+        const int sidx = md->fall_sidx[k];
+        double v = sq[col_off(sidx) + r * col_str(sidx)];
+        if (n_grf > 0 && md->fall_idx[k] >= first_grf) v = v / 1000.0;
+        if (code == 0 && (v < md->fall_lo[k] || v > md->fall_hi[k])) code = (unsigned)(k + 1);
+      }
+      const unsigned ab = (code != 0 && use_abs) ? 1u : 0u;
+      if (rt == OLY_REWARD_NONE) {
+        p.reward[gr] = 0.0f;
+      } else {
+        double x = sq[col_off(rew_sidx) + r * col_str(rew_sidx)];
+        if (rew_grf) x = x / 1000.0;
+        if (gr < p.N) p.reward[gr] = rew_f(p.prev_in[gr]);
+        if (gr + p.N < p.R)
+          p.reward[gr + p.N] = rew_f(x);
+        else
+          p.prev_out[gr - (p.R - p.N)] = x;
+      }
+      unsigned a4 = 0, c4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int srcl = (lane & 15) * 4 + k;
+        a4 |= (unsigned)__shfl((int)ab, srcl, 64) << (8 * k);
+        c4 |= (unsigned)__shfl((int)code, srcl, 64) << (8 * k);
+      }
+      if (lane < 16) {
+        const long q4 = row0 / 4 + lane;
+        reinterpret_cast<unsigned*>(p.absorbing)[q4] = a4;
+        if (p.fall_code) reinterpret_cast<unsigned*>(p.fall_code)[q4] = c4;
+      }
+    }
+
+    // ---- observation tile
+    {
+      constexpr int OW = OBS64 ? 2 : 4;
+      const int nvec = ROWS * n_obs / OW;
+#pragma unroll 2
+      for (int i = tid; i < nvec; i += THREADS) {
+        unsigned o4[OW];
+        double v[OW];
+#pragma unroll
+        for (int k = 0; k < OW; ++k) o4[k] = eo[i * OW + k];
+#pragma unroll
+        for (int k = 0; k < OW; ++k) {
+          v[k] = sq[o4[k] & 0x7fffffffu];
+          if (o4[k] & 0x80000000u) v[k] = v[k] / 1000.0;
+        }
+        if (OBS64) {
+          f64x2 o;
+          o.x = v[0]; o.y = v[OW - 1];
+          st16(reinterpret_cast<f64x2*>(static_cast<double*>(p.obs) + row0 * n_obs) + i, o);
+        } else {
+          f32x4 o;
+          o.x = (float)v[0]; o.y = (float)v[1 % OW]; o.z = (float)v[2 % OW]; o.w = (float)v[3 % OW];
+          st16(reinterpret_cast<f32x4*>(static_cast<float*>(p.obs) + row0 * n_obs) + i, o);
+        }
+      }
+    }
+
+    // ---- control tile
+    if (with_ctrl) {
+      constexpr int CW = CTRL64 ? 2 : 4;
+      const int ncv = ROWS * nu / CW;
+      for (int i = tid; i < ncv; i += THREADS) {
+        double u[CW];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+          const int c = co[i * CW + q];
+          const int j = c & 0xff, ai = c >> 8;
+          const double a = (double)sa[c < 0 ? 0 : ai];
+          double x = a * t_act[nu + (c < 0 ? 0 : j)] + t_act[c < 0 ? 0 : j];
+          const double lo = t_act[2 * nu + (c < 0 ? 0 : j)], hi = t_act[3 * nu + (c < 0 ? 0 : j)];
+          if (x < lo) x = lo;
+          if (x > hi) x = hi;
+          u[q] = c < 0 ? 0.0 : x;
+        }
+        if (CTRL64) {
+          f64x2 o;
+          o.x = u[0]; o.y = u[CW - 1];
+          st16(reinterpret_cast<f64x2*>(static_cast<double*>(p.ctrl) + row0 * nu) + i, o);
+        } else {
+          f32x4 o;
+          o.x = (float)u[0]; o.y = (float)u[1 % CW]; o.z = (float)u[2 % CW]; o.w = (float)u[3 % CW];
+          st16(reinterpret_cast<f32x4*>(static_cast<float*>(p.ctrl) + row0 * nu) + i, o);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 using H1Dims = StaticDims<17, 17, 0, 11, 11, 32>;      // UnitreeH1, arms removed
 using AtlasDims = StaticDims<16, 16, 0, 10, 10, 30>;   // Atlas, arms + back removed (default)
 using TalosDims = StaticDims<18, 18, 0, 12, 12, 34>;   // Talos, arms removed (default)
@@ -769,6 +1009,41 @@ int launch_fast(oly_ctx* ctx, IlArgs a, int out_flags, int wg_per_cu, hipStream_
     OLY_LAUNCH_CHECK(ctx, "il_tile_kernel");
   }
   if (nfull * ROWS < a.R) return launch_generic<ROWS, D>(ctx, a, nfull, out_flags, s);
+  return OLY_OK;
+}
+
+// Runtime-shaped robots: full aligned tiles through the persistent dyn tile kernel, the
+// remainder through the generic per-tile kernel.
+int launch_dyn(oly_ctx* ctx, IlArgs a, int out_flags, hipStream_t s) {
+  const IlDev& h = ctx->il_host;
+  const DynCarve cv(h.nq, h.nv, h.n_grf, h.n_act, h.nu, h.n_obs);
+  const long nfull = (a.fast && cv.total <= 150 * 1024) ? a.R / DYN_ROWS : 0;
+  if (nfull > 0) {
+    int per_cu = (160 * 1024) / cv.total;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    long want = (long)ctx->num_cu * per_cu;
+    if (want > nfull) want = nfull;
+    IlArgs b = a;
+    b.tile0 = nfull;
+    dim3 grid((unsigned)want), block(THREADS);
+    const bool o64 = out_flags & OLY_OUT_OBS_F64, c64 = out_flags & OLY_OUT_CTRL_F64;
+#define OLY_K1D(O, C_)                                                                      \
+  do {                                                                                      \
+    auto k = il_dyn_tile_kernel<O, C_>;                                                     \
+    if (cv.total > 48 * 1024)                                                               \
+      OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, cv.total)); \
+    hipLaunchKernelGGL(k, grid, block, cv.total, s, b);                                     \
+  } while (0)
+    if (o64 && c64) OLY_K1D(true, true);
+    else if (o64) OLY_K1D(true, false);
+    else if (c64) OLY_K1D(false, true);
+    else OLY_K1D(false, false);
+#undef OLY_K1D
+    OLY_LAUNCH_CHECK(ctx, "il_dyn_tile_kernel");
+  }
+  if (nfull * DYN_ROWS < a.R) return launch_generic<DYN_ROWS, DynDims>(ctx, a, nfull, out_flags, s);
   return OLY_OK;
 }
 
@@ -883,6 +1158,8 @@ extern "C" int oly_il_step(oly_ctx* ctx, int T, int N, const double* qpos, const
     if (rows_env == 256) return launch_fast<256, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
     return launch_fast<128, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
   }
+  static const int dyn_env = [] { const char* e = getenv("OLY_K1_DYN_TILE"); return e ? atoi(e) : 1; }();
+  if (dyn_env) return launch_dyn(ctx, a, out_flags, oly_s(stream));
   return launch_generic<64, DynDims>(ctx, a, 0, out_flags, oly_s(stream));
 }
 
