@@ -111,12 +111,62 @@ __global__ __launch_bounds__(THREADS) void col_partial_kernel(int B, int D, int 
   }
 }
 
-__global__ void col_finish_kernel(int nblocks, int B, int D, const double* __restrict__ ws,
-                                  double* __restrict__ colstats, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+// D % 4 == 0 and 16-B aligned rows: a thread owns FOUR adjacent columns (one 16-B load per
+// row) and rows t / (D/4) + k * lanes; two rows in flight per iteration.
+__global__ __launch_bounds__(THREADS) void col_partial4_kernel(int B, int D, int rows_per_block,
+                                                               const float* __restrict__ x,
+                                                               double* __restrict__ ws) {
+  extern __shared__ double shc[];  // [lanes][D][2]
+  const int D4 = D >> 2;
+  const int lanes = blockDim.x / D4;
+  const int c4 = threadIdx.x % D4, rl = threadIdx.x / D4;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(B, r0 + rows_per_block);
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  auto acc = [&](const float4& v) {
+    const double a = v.x, b = v.y, c = v.z, d = v.w;
+    s[0] += a; ss[0] += a * a;
+    s[1] += b; ss[1] += b * b;
+    s[2] += c; ss[2] += c * c;
+    s[3] += d; ss[3] += d * d;
+  };
+  int r = r0 + rl;
+  for (; r + lanes < r1; r += 2 * lanes) {
+    const float4 v0 = x4[(size_t)r * D4 + c4];
+    const float4 v1 = x4[(size_t)(r + lanes) * D4 + c4];
+    acc(v0);
+    acc(v1);
+  }
+  if (r < r1) acc(x4[(size_t)r * D4 + c4]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    shc[(rl * D + 4 * c4 + k) * 2] = s[k];
+    shc[(rl * D + 4 * c4 + k) * 2 + 1] = ss[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const int c = threadIdx.x;
+    double ts = 0.0, tss = 0.0;
+    for (int l = 0; l < lanes; ++l) { ts += shc[(l * D + c) * 2]; tss += shc[(l * D + c) * 2 + 1]; }
+    ws[((size_t)blockIdx.x * D + c) * 2] = ts;
+    ws[((size_t)blockIdx.x * D + c) * 2 + 1] = tss;
+  }
+}
+
+// one wave per column: lane i sums partials i, i+64, ... in order, then the fixed shuffle tree
+__global__ __launch_bounds__(64) void col_finish_kernel(int nblocks, int B, int D,
+                                                        const double* __restrict__ ws,
+                                                        double* __restrict__ colstats, int accumulate) {
+  const int c = blockIdx.x;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblocks; ++b) { s += ws[((size_t)b * D + c) * 2]; ss += ws[((size_t)b * D + c) * 2 + 1]; }
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
+    s += ws[((size_t)b * D + c) * 2];
+    ss += ws[((size_t)b * D + c) * 2 + 1];
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (threadIdx.x != 0) return;
   if (accumulate) {
     colstats[c] += (double)B; colstats[D + c] += s; colstats[2 * D + c] += ss;
   } else {
@@ -159,6 +209,19 @@ extern "C" int oly_col_stats(oly_ctx* ctx, int B, int D, const float* x, double*
   if (!ctx) return OLY_EINVAL;
   if (B < 0 || D <= 0 || D > OLY_MAX_OBS || !colstats || (B > 0 && !x))
     OLY_FAIL(ctx, OLY_EINVAL, "oly_col_stats: bad argument (B=%d D=%d)", B, D);
+  if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && D >= 4) {
+    const int D4 = D >> 2, lanes4 = THREADS / D4, tpb4 = lanes4 * D4;
+    int nb4 = (B + 8 * lanes4 - 1) / (8 * lanes4);  // >= 8 rows per thread
+    if (nb4 < 1) nb4 = 1;
+    if (nb4 > OLY_STATS_MAX_BLOCKS) nb4 = OLY_STATS_MAX_BLOCKS;
+    const int rpb4 = (B + nb4 - 1) / nb4;
+    hipLaunchKernelGGL(col_partial4_kernel, dim3(nb4), dim3(tpb4), sizeof(double) * 2 * lanes4 * D,
+                       oly_s(stream), B, D, rpb4, x, ctx->stats_ws);
+    hipLaunchKernelGGL(col_finish_kernel, dim3(D), dim3(64), 0, oly_s(stream), nb4, B, D,
+                       ctx->stats_ws, colstats, accumulate);
+    OLY_LAUNCH_CHECK(ctx, "col stats kernels");
+    return OLY_OK;
+  }
   const int lanes = THREADS / D;
   const int tpb = lanes * D;
   int nb = (B + 64 * lanes - 1) / (64 * lanes);  // >= 64 rows per lane-row keeps blocks busy
@@ -167,7 +230,7 @@ extern "C" int oly_col_stats(oly_ctx* ctx, int B, int D, const float* x, double*
   const int rpb = (B + nb - 1) / nb;
   hipLaunchKernelGGL(col_partial_kernel, dim3(nb), dim3(tpb), sizeof(double) * 2 * tpb, oly_s(stream),
                      B, D, rpb, x, ctx->stats_ws);
-  hipLaunchKernelGGL(col_finish_kernel, dim3((D + 63) / 64), dim3(64), 0, oly_s(stream), nb, B, D,
+  hipLaunchKernelGGL(col_finish_kernel, dim3(D), dim3(64), 0, oly_s(stream), nb, B, D,
                      ctx->stats_ws, colstats, accumulate);
   OLY_LAUNCH_CHECK(ctx, "col stats kernels");
   return OLY_OK;

@@ -1,6 +1,7 @@
 // K8: discriminator-reward pre-amble and epilogue (the MLP GEMMs stay in PyTorch-ROCm).
 //   oly_disc_standardize  prepare_discrim_inputs gail_TRPO.py:297-313 + Standardizer.forward
 //                         imitation_lib/utils/networks.py:68-74
+//   oly_obs_filter        Normalize._obfilt rl/envs/normalize.py:139-147
 //   oly_disc_reparam      reparameterize networks.py:21-24
 //   oly_disc_reward       GAIL.make_discrim_reward gail_TRPO.py:320-327
 // Elementwise, HBM-bound: 8 B/element (standardise), 16 B (reparam), 8 B (reward).
@@ -22,6 +23,21 @@ __global__ __launch_bounds__(THREADS) void standardize_kernel(int B, int Dx, int
     const int c = mask ? mask[j] : j;
     // float32 batch minus float64 mean, over float64 std, narrowed by .float()
     out[e] = (float)(((double)x[(size_t)b * Dx + c] - mean[j]) / sd[j]);
+  }
+}
+
+// Normalize._obfilt (rl/envs/normalize.py:139-147): clip((obs - mean) / sqrt(var + eps), -c, c)
+__global__ __launch_bounds__(THREADS) void obs_filter_kernel(long total, int D,
+                                                             const float* __restrict__ x,
+                                                             const double* __restrict__ mean,
+                                                             const double* __restrict__ var, double eps,
+                                                             double clip, float* __restrict__ out) {
+  const long stride = (long)gridDim.x * THREADS;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += stride) {
+    const int j = (int)(e % D);
+    double v = ((double)x[e] - mean[j]) / sqrt(var[j] + eps);
+    if (clip > 0.0) v = fmin(fmax(v, -clip), clip);
+    out[e] = (float)v;
   }
 }
 
@@ -63,6 +79,19 @@ extern "C" int oly_disc_standardize(oly_ctx* ctx, int B, int Dx, int D, const fl
   hipLaunchKernelGGL(standardize_kernel, dim3(blocks_for((long)B * D)), dim3(THREADS), 0, oly_s(stream),
                      B, Dx, D, x, mask, mean, sd, out);
   OLY_LAUNCH_CHECK(ctx, "standardize_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_obs_filter(oly_ctx* ctx, int B, int D, const float* x, const double* mean,
+                              const double* var, double eps, double clip, float* out,
+                              oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (B < 0 || D <= 0 || !mean || !var || (B > 0 && (!x || !out)))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_obs_filter: bad argument");
+  if (B == 0) return OLY_OK;
+  hipLaunchKernelGGL(obs_filter_kernel, dim3(blocks_for((long)B * D)), dim3(THREADS), 0, oly_s(stream),
+                     (long)B * D, D, x, mean, var, eps, clip, out);
+  OLY_LAUNCH_CHECK(ctx, "obs_filter_kernel");
   return OLY_OK;
 }
 

@@ -56,6 +56,8 @@ class A3State(C.Structure):
 
 
 # name -> (restype, argtypes); device/host pointers are void*.
+STD_SCALAR, STD_PER_DIM, STD_FULL = 0, 1, 2
+
 SIGNATURES = {
     "oly_strerror": (C.c_char_p, [C.c_int]),
     "oly_last_error": (C.c_char_p, [vp]),
@@ -94,6 +96,11 @@ SIGNATURES = {
     "oly_disc_standardize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "oly_disc_reparam": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp]),
     "oly_disc_reward": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    "oly_obs_filter": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp]),
+    "oly_signed_perm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "oly_mirror_loss": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "oly_ppo_loss": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp,
+                               C.c_float, C.c_float, vp, vp, vp, vp, vp]),
     "oly_event_create": (C.c_int, [C.POINTER(vp)]),
     "oly_event_destroy": (C.c_int, [vp]),
     "oly_event_record": (C.c_int, [vp, vp]),

@@ -320,6 +320,17 @@ class Engine:
         self.ctx.call("oly_disc_standardize", B, Dx, D, ptr(x), ptr(mask), ptr(mean), ptr(std), ptr(out), self._s())
         return out
 
+    def obs_filter(self, x, mean, var, eps=1e-8, clip=10.0, out=None):
+        """Normalize._obfilt on a [B,D] float32 batch (out may be x itself)."""
+        B, D = int(x.shape[0]), int(x.shape[1])
+        _req(x, "x", (B, D), torch.float32, self.device)
+        _req(mean, "mean", (D,), torch.float64, self.device)
+        _req(var, "var", (D,), torch.float64, self.device)
+        out = _req(out if out is not None else self._new((B, D), torch.float32), "out", (B, D), torch.float32, self.device)
+        self.ctx.call("oly_obs_filter", B, D, ptr(x), ptr(mean), ptr(var), float(eps), float(clip or 0.0), ptr(out),
+                      self._s())
+        return out
+
     def disc_reparam(self, mu, logvar, eps, z=None):
         for t, nme in ((mu, "mu"), (logvar, "logvar"), (eps, "eps")):
             _req(t, nme, mu.shape, torch.float32, self.device)
@@ -333,3 +344,56 @@ class Engine:
                       (logits.numel(),), torch.float32, self.device)
         self.ctx.call("oly_disc_reward", C.c_int64(logits.numel()), ptr(logits), ptr(reward), self._s())
         return reward
+
+    # -------------------------------------------------------------- K9
+    def signed_perm(self, x, src, sign, out=None):
+        B, D = int(x.shape[0]), int(x.shape[1])
+        _req(x, "x", (B, D), torch.float32, self.device)
+        _req(src, "src", (D,), torch.int32, self.device)
+        _req(sign, "sign", (D,), torch.float32, self.device)
+        out = _req(out if out is not None else self._new((B, D), torch.float32), "out", (B, D), torch.float32, self.device)
+        self.ctx.call("oly_signed_perm", B, D, ptr(x), ptr(src), ptr(sign), ptr(out), self._s())
+        return out
+
+    def mirror_loss(self, det, mir, src, sign, want_grad=True):
+        """-> (loss [1] f64, grad_det, grad_mir)."""
+        B, A = int(det.shape[0]), int(det.shape[1])
+        _req(det, "det", (B, A), torch.float32, self.device)
+        _req(mir, "mir", (B, A), torch.float32, self.device)
+        _req(src, "src", (A,), torch.int32, self.device)
+        _req(sign, "sign", (A,), torch.float32, self.device)
+        loss = self._new((1,), torch.float64)
+        gd = self._new((B, A), torch.float32) if want_grad else None
+        gm = self._new((B, A), torch.float32) if want_grad else None
+        self.ctx.call("oly_mirror_loss", B, A, ptr(det), ptr(mir), ptr(src), ptr(sign), ptr(loss), ptr(gd), ptr(gm),
+                      self._s())
+        return loss, gd, gm
+
+    def _std_arg(self, std, B, A, name):
+        if std.numel() == 1:
+            mode, shape = _abi.STD_SCALAR, (1,)
+        elif std.numel() == A:
+            mode, shape = _abi.STD_PER_DIM, (A,)
+        else:
+            mode, shape = _abi.STD_FULL, (B, A)
+        return _req(std.reshape(shape), name, shape, torch.float32, self.device), mode
+
+    def ppo_loss(self, mu, std, old_mu, old_std, action, adv, ret, value, clip, vf_coeff=0.5, want_grad=True,
+                 want_grad_std=False):
+        """-> dict(scal [5] f64: actor, entropy_penalty, critic, approx_kl, clip_fraction;
+        grad_mu [B,A], grad_std [B,A] or None, grad_value [B])."""
+        B, A = int(mu.shape[0]), int(mu.shape[1])
+        for t, nme in ((mu, "mu"), (old_mu, "old_mu"), (action, "action")):
+            _req(t, nme, (B, A), torch.float32, self.device)
+        std, sm = self._std_arg(std, B, A, "std")
+        old_std, om = self._std_arg(old_std, B, A, "old_std")
+        adv, ret, value = (_req(t.reshape(B), nme, (B,), torch.float32, self.device)
+                           for t, nme in ((adv, "adv"), (ret, "ret"), (value, "value")))
+        scal = self._new((5,), torch.float64)
+        gmu = self._new((B, A), torch.float32) if want_grad else None
+        gsd = self._new((B, A), torch.float32) if want_grad_std else None
+        gv = self._new((B,), torch.float32) if want_grad else None
+        self.ctx.call("oly_ppo_loss", B, A, ptr(mu), ptr(std), sm, ptr(old_mu), ptr(old_std), om, ptr(action),
+                      ptr(adv), ptr(ret), ptr(value), float(clip), float(vf_coeff), ptr(scal), ptr(gmu), ptr(gsd),
+                      ptr(gv), self._s())
+        return dict(scal=scal, grad_mu=gmu, grad_std=gsd, grad_value=gv)

@@ -8,8 +8,9 @@ Reference: rl/algos/ppo.py
   PPOBuffer.finish_path + adv-norm     :68-84, :335-336 -> HIP kernels via rollout.PPORollout
 
 Where the reference fans n_proc single-env workers out over ray, here `env_fn()` returns ONE
-vectorised env and `num_procs` maps to its num_envs; the optimiser side is unchanged PyTorch
-(MFMA GEMMs).  Actor / critic modules are the reference's own (anything with
+vectorised env and `num_procs` maps to its num_envs; the optimiser side is PyTorch (MFMA GEMMs)
+with the loss terms and their gradients evaluated by one HIP kernel (update_policy_fused;
+update_policy keeps the reference's op-by-op form).  Actor / critic modules are the reference's own (anything with
 `forward(state, deterministic, anneal)`, `distribution(obs)` and a critic `forward(obs)`).
 """
 import os
@@ -71,6 +72,72 @@ class MLPCritic(torch.nn.Module):
         return self.network_out(x)
 
 
+def _plain_std(std, B, A):
+    """Normal() broadcasts a scalar / per-dim scale to a stride-0 [B,A] view: undo that so the
+    kernel reads one value (or one row) and autograd reduces the gradient for us."""
+    if std.dim() == 2 and tuple(std.shape) == (B, A):
+        st = std.stride()
+        if st == (0, 0):
+            return std[0, :1]
+        if st[0] == 0:
+            return std[0]
+        return std.contiguous()
+    return std.reshape(-1)
+
+
+class FusedPPOLoss(torch.autograd.Function):
+    """oly_ppo_loss: (actor_loss, entropy_penalty, critic_loss, approx_kl, clip_fraction) and
+    the gradients w.r.t. mu / std / value from the same pass (ppo.py:236-259,270-273)."""
+
+    @staticmethod
+    def forward(ctx, eng, mu, std, old_mu, old_std, action, adv, ret, value, clip, vf_coeff):
+        B, A = mu.shape
+        need_std = std.requires_grad
+        r = eng.ppo_loss(mu.contiguous(), std.contiguous(), old_mu.contiguous(), old_std.contiguous(),
+                         action.contiguous(), adv.reshape(B).contiguous(), ret.reshape(B).contiguous(),
+                         value.reshape(B).contiguous(), clip, vf_coeff, want_grad=True, want_grad_std=need_std)
+        ctx.save_for_backward(r["grad_mu"], r["grad_value"], r["grad_std"] if need_std else None,
+                              std if need_std else None)
+        ctx.value_shape, ctx.std_shape = value.shape, std.shape
+        out = r["scal"].to(torch.float32)
+        outs = tuple(out[i].clone() for i in range(5))
+        ctx.mark_non_differentiable(outs[3], outs[4])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_actor, g_ent, g_critic, g_kl, g_cf):
+        gmu, gv, gsd, std = ctx.saved_tensors
+        grad_mu = g_actor * gmu
+        grad_value = (g_critic * gv).reshape(ctx.value_shape)
+        grad_std = None
+        if gsd is not None:
+            B, A = gmu.shape
+            full = g_actor * gsd
+            if std.numel() == 1:
+                grad_std = full.sum().reshape(ctx.std_shape) - g_ent / std
+            elif std.numel() == A:
+                grad_std = full.sum(0).reshape(ctx.std_shape) - g_ent / (A * std)
+            else:
+                grad_std = full - g_ent / (B * A * std)
+        return None, grad_mu, grad_std, None, None, None, None, None, grad_value, None, None
+
+
+class FusedMirrorLoss(torch.autograd.Function):
+    """oly_mirror_loss: mean((det - mirror_action(mir))^2) with the signed permutation applied
+    in-kernel (ppo.py:261-268, wrappers.py:51-57)."""
+
+    @staticmethod
+    def forward(ctx, eng, det, mir, src, sign):
+        loss, gd, gm = eng.mirror_loss(det.contiguous(), mir.contiguous(), src, sign)
+        ctx.save_for_backward(gd, gm)
+        return loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        gd, gm = ctx.saved_tensors
+        return None, g * gd, g * gm, None, None
+
+
 class PPO:
     def __init__(self, args, save_path):
         self.gamma, self.lam = args["gamma"], args["lam"]
@@ -129,6 +196,28 @@ class PPO:
         return buf
 
     # ------------------------------------------------------------------ losses
+    def update_policy_fused(self, eng, obs_batch, action_batch, return_batch, advantage_batch,
+                            mirror_observation=None, act_src=None, act_sign=None):
+        """update_policy with the loss terms evaluated by oly_ppo_loss / oly_mirror_loss (mask = 1,
+        diagonal Gaussian policy).  Same return tuple; clip_fraction is a python float."""
+        policy, critic, old_policy = self.policy, self.critic, self.old_policy
+        values = critic(obs_batch)
+        pdf = policy.distribution(obs_batch)
+        B, A = pdf.loc.shape
+        with torch.no_grad():
+            old = old_policy.distribution(obs_batch)
+            old_mu, old_std = old.loc, _plain_std(old.scale, B, A)
+        actor_loss, entropy_penalty, critic_loss, approx_kl_div, clipf = FusedPPOLoss.apply(
+            eng, pdf.loc, _plain_std(pdf.scale, B, A), old_mu, old_std, action_batch, advantage_batch,
+            return_batch, values, self.clip, self.vf_coeff)
+        if mirror_observation is not None and act_src is not None:
+            det = policy(obs_batch)
+            mir = policy(mirror_observation(obs_batch))
+            mirror_loss = FusedMirrorLoss.apply(eng, det, mir, act_src, act_sign)
+        else:
+            mirror_loss = torch.zeros(1, device=obs_batch.device)
+        return actor_loss, entropy_penalty, critic_loss, approx_kl_div, mirror_loss, clipf
+
     def update_policy(self, obs_batch, action_batch, return_batch, advantage_batch, mask,
                       mirror_observation=None, mirror_action=None):
         policy, critic, old_policy = self.policy, self.critic, self.old_policy
@@ -165,6 +254,13 @@ class PPO:
         post = PPORollout(env.eng, gamma=self.gamma, lam=self.lam, eps=self.eps)
         obs_mirr = getattr(env, "mirror_clock_observation", None) if hasattr(env, "mirror_observation") else None
         act_mirr = getattr(env, "mirror_action", None)
+        fused = bool(getattr(self, "fused_loss", True)) and hasattr(env, "eng")
+        act_src = act_sign = None
+        if fused and act_mirr is not None and hasattr(env, "_act_src"):
+            act_src = env._act_src.to(env.eng.device, torch.int32)
+            act_sign = env._act_sgn.to(env.eng.device, torch.float32)
+        elif act_mirr is not None:
+            fused = False                                   # mirror given as a function: unfused torch path
         T = max(1, self.batch_size // env.num_envs)
         curr_anneal, start = 1.0, time.time()
         history = []
@@ -190,17 +286,27 @@ class PPO:
             for _ in range(self.epochs):
                 for idx in BatchSampler(SubsetRandomSampler(range(n)), minibatch, drop_last=True):
                     idx = torch.as_tensor(idx, device=observations.device)
-                    a_l, ent, c_l, kl, m_l, clipf = self.update_policy(
-                        observations[idx], actions[idx], returns[idx], advantages[idx], 1, obs_mirr, act_mirr)
+                    if fused:
+                        a_l, ent, c_l, kl, m_l, clipf = self.update_policy_fused(
+                            env.eng, observations[idx], actions[idx], returns[idx], advantages[idx], obs_mirr,
+                            act_src, act_sign)
+                    else:
+                        a_l, ent, c_l, kl, m_l, clipf = self.update_policy(
+                            observations[idx], actions[idx], returns[idx], advantages[idx], 1, obs_mirr, act_mirr)
                     self.actor_optimizer.zero_grad()
-                    (a_l + self.mirror_coeff * m_l + self.ent_coeff * ent).backward()
+                    self.critic_optimizer.zero_grad()
+                    if fused:
+                        # one graph node carries all terms; actor and critic share no parameters, so a
+                        # single backward gives each network exactly its own loss' gradient
+                        (a_l + self.mirror_coeff * m_l + self.ent_coeff * ent + c_l).sum().backward()
+                    else:
+                        (a_l + self.mirror_coeff * m_l + self.ent_coeff * ent).sum().backward()
+                        c_l.backward()
                     torch.nn.utils.clip_grad_norm_(policy.parameters(), self.grad_clip)
                     self.actor_optimizer.step()
-                    self.critic_optimizer.zero_grad()
-                    c_l.backward()
                     torch.nn.utils.clip_grad_norm_(critic.parameters(), self.grad_clip)
                     self.critic_optimizer.step()
-                    stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), clipf))
+                    stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), float(clipf)))
             ep_ret, ep_len = buf.episode_stats()
             mean_ret = float(np.mean(ep_ret)) if ep_ret else 0.0
             self.highest_reward = max(self.highest_reward, mean_ret)

@@ -628,3 +628,95 @@ int oly_disc_reward_cpu(int64_t B, const float* logits, float* reward) {
   }
   return OLY_OK;
 }
+
+/* Normalize._obfilt, rl/envs/normalize.py:139-147 (obs f32 in, statistics f64). */
+int oly_obs_filter_cpu(int B, int D, const float* x, const double* mean, const double* var,
+                       double eps, double clip, float* out) {
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < D; ++j) {
+      double v = ((double)x[(size_t)b * D + j] - mean[j]) / sqrt(var[j] + eps);
+      if (clip > 0.0) v = v < -clip ? -clip : (v > clip ? clip : v);
+      out[(size_t)b * D + j] = (float)v;
+    }
+  return OLY_OK;
+}
+
+/* x @ M with M from _get_symmetry_matrix (rl/envs/wrappers.py:51-57,75-82), stated on the
+ * (src, sign) form of the signed permutation. */
+int oly_signed_perm_cpu(int B, int D, const float* x, const int32_t* src, const float* sign,
+                        float* out) {
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < D; ++j) out[(size_t)b * D + j] = sign[j] * x[(size_t)b * D + src[j]];
+  return OLY_OK;
+}
+
+/* mirror loss, rl/algos/ppo.py:261-268, and its gradients. */
+int oly_mirror_loss_cpu(int B, int A, const float* det, const float* mir, const int32_t* src,
+                        const float* sign, double* loss_out, float* grad_det, float* grad_mir) {
+  double acc = 0.0;
+  const float gs = (float)(2.0 / ((double)B * A));
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < A; ++j) {
+      const size_t e = (size_t)b * A + j, m = (size_t)b * A + src[j];
+      const float d = det[e] - sign[j] * mir[m];
+      acc += (double)(d * d);
+      if (grad_det) grad_det[e] = gs * d;
+      if (grad_mir) grad_mir[m] = -sign[j] * (gs * d);
+    }
+  loss_out[0] = acc / ((double)B * A);
+  return OLY_OK;
+}
+
+static float oly_sd_at(const float* sd, int mode, int row, int A, int j) {
+  return mode == OLY_STD_SCALAR ? sd[0] : mode == OLY_STD_PER_DIM ? sd[j] : sd[(size_t)row * A + j];
+}
+
+/* PPO.update_policy, rl/algos/ppo.py:236-259,270-273 with torch.distributions.Normal's
+ * log_prob / entropy written out; fp32 per element as torch evaluates, fp64 sums. */
+int oly_ppo_loss_cpu(int B, int A, const float* mu, const float* sd, int sd_mode,
+                     const float* old_mu, const float* old_sd, int old_sd_mode,
+                     const float* action, const float* adv, const float* ret, const float* value,
+                     float clip, float vf_coeff, double* scal_out, float* grad_mu, float* grad_sd,
+                     float* grad_value) {
+  const float c = 0.9189385332046727f, lo = 1.0f - clip, hi = 1.0f + clip;
+  const float invB = 1.0f / (float)B;
+  double s_actor = 0, s_ent = 0, s_crit = 0, s_kl = 0, s_cf = 0;
+  for (int b = 0; b < B; ++b) {
+    float lp = 0.0f, olp = 0.0f, ent = 0.0f;
+    for (int j = 0; j < A; ++j) {
+      const size_t e = (size_t)b * A + j;
+      const float s = oly_sd_at(sd, sd_mode, b, A, j), os = oly_sd_at(old_sd, old_sd_mode, b, A, j);
+      const float t = action[e] - mu[e], ot = action[e] - old_mu[e];
+      lp += -(t * t) / (2.0f * (s * s)) - logf(s) - c;
+      olp += -(ot * ot) / (2.0f * (os * os)) - logf(os) - c;
+      ent += (0.5f + c) + logf(s);
+    }
+    const float lr = lp - olp, ratio = expf(lr);
+    const float cpi = ratio * adv[b];
+    const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
+    const float cl = rc * adv[b];
+    s_actor += (double)(cpi < cl ? cpi : cl);
+    s_ent += (double)ent;
+    const float dv = ret[b] - value[b];
+    s_crit += (double)(dv * dv);
+    s_kl += (double)((ratio - 1.0f) - lr);
+    s_cf += fabsf(ratio - 1.0f) > clip ? 1.0 : 0.0;
+    if (grad_value) grad_value[b] = vf_coeff * 2.0f * (value[b] - ret[b]) * invB;
+    const float inr = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    const float w = cpi < cl ? 1.0f : (cpi == cl ? 0.5f + 0.5f * inr : inr);
+    const float g_lp = -invB * adv[b] * w * ratio;
+    for (int j = 0; j < A; ++j) {
+      const size_t e = (size_t)b * A + j;
+      const float s = oly_sd_at(sd, sd_mode, b, A, j);
+      const float t = action[e] - mu[e];
+      if (grad_mu) grad_mu[e] = g_lp * t / (s * s);
+      if (grad_sd) grad_sd[e] = g_lp * (t * t / (s * s * s) - 1.0f / s);
+    }
+  }
+  scal_out[0] = -s_actor / B;
+  scal_out[1] = -s_ent / ((double)B * A);
+  scal_out[2] = (double)vf_coeff * s_crit / B;
+  scal_out[3] = s_kl / B;
+  scal_out[4] = s_cf / B;
+  return OLY_OK;
+}

@@ -74,6 +74,18 @@ int oly_disc_reparam_cpu(int64_t n, const float* mu, const float* logvar, const 
                          float* z);
 int oly_disc_reward_cpu(int64_t B, const float* logits, float* reward);
 
+int oly_obs_filter_cpu(int B, int D, const float* x, const double* mean, const double* var,
+                       double eps, double clip, float* out);
+int oly_signed_perm_cpu(int B, int D, const float* x, const int32_t* src, const float* sign,
+                        float* out);
+int oly_mirror_loss_cpu(int B, int A, const float* det, const float* mir, const int32_t* src,
+                        const float* sign, double* loss_out, float* grad_det, float* grad_mir);
+int oly_ppo_loss_cpu(int B, int A, const float* mu, const float* std, int std_mode,
+                     const float* old_mu, const float* old_std, int old_std_mode,
+                     const float* action, const float* adv, const float* ret, const float* value,
+                     float clip, float vf_coeff, double* scal_out, float* grad_mu, float* grad_std,
+                     float* grad_value);
+
 /* OpenMP-parallel variant used only by bench.py's cpu_baseline leg (threads <= 0: all). */
 int oly_il_step_cpu_mt(const oly_il_model* m, int T, int N, const double* qpos,
                        const double* qvel, const float* action, double* prev_inout, void* obs,

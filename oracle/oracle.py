@@ -239,3 +239,55 @@ def disc_reward(logits):
     r = np.empty_like(logits)
     _chk(lib().oly_disc_reward_cpu(C.c_int64(logits.size), _p(logits), _p(r)), "disc_reward")
     return r
+
+
+def obs_filter(x, mean, var, eps=1e-8, clip=10.0):
+    x = _c(x, np.float32)
+    mean, var = _c(mean, np.float64), _c(var, np.float64)
+    out = np.empty_like(x)
+    _chk(lib().oly_obs_filter_cpu(x.shape[0], x.shape[1], _p(x), _p(mean), _p(var), C.c_double(eps),
+                                  C.c_double(clip), _p(out)), "obs_filter")
+    return out
+
+
+def signed_perm(x, src, sign):
+    x = _c(x, np.float32)
+    src, sign = _c(src, np.int32), _c(sign, np.float32)
+    out = np.empty_like(x)
+    _chk(lib().oly_signed_perm_cpu(x.shape[0], x.shape[1], _p(x), _p(src), _p(sign), _p(out)), "signed_perm")
+    return out
+
+
+def mirror_loss(det, mir, src, sign):
+    det, mir = _c(det, np.float32), _c(mir, np.float32)
+    src, sign = _c(src, np.int32), _c(sign, np.float32)
+    loss = np.zeros(1)
+    gd, gm = np.empty_like(det), np.empty_like(mir)
+    _chk(lib().oly_mirror_loss_cpu(det.shape[0], det.shape[1], _p(det), _p(mir), _p(src), _p(sign), _p(loss),
+                                   _p(gd), _p(gm)), "mirror_loss")
+    return loss[0], gd, gm
+
+
+def _std_mode(std, B, A):
+    std = _c(np.asarray(std, dtype=np.float32), np.float32)
+    if std.size == 1:
+        return std.reshape(1), 0
+    if std.size == A:
+        return std.reshape(A), 1
+    assert std.shape == (B, A)
+    return std, 2
+
+
+def ppo_loss(mu, std, old_mu, old_std, action, adv, ret, value, clip, vf_coeff=0.5):
+    """-> (scal[5] = actor, entropy_penalty, critic, approx_kl, clip_fraction; grad_mu, grad_std, grad_value)"""
+    mu, old_mu, action = _c(mu, np.float32), _c(old_mu, np.float32), _c(action, np.float32)
+    B, A = mu.shape
+    std, sm = _std_mode(std, B, A)
+    old_std, om = _std_mode(old_std, B, A)
+    adv, ret, value = (_c(np.asarray(a).reshape(-1), np.float32) for a in (adv, ret, value))
+    scal = np.zeros(5)
+    gmu, gsd, gv = np.empty_like(mu), np.empty_like(mu), np.empty(B, np.float32)
+    _chk(lib().oly_ppo_loss_cpu(B, A, _p(mu), _p(std), sm, _p(old_mu), _p(old_std), om, _p(action), _p(adv),
+                                _p(ret), _p(value), C.c_float(clip), C.c_float(vf_coeff), _p(scal), _p(gmu),
+                                _p(gsd), _p(gv)), "ppo_loss")
+    return scal, gmu, gsd, gv

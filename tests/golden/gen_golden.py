@@ -22,6 +22,7 @@ fixtures do.  Fixture -> reference function map (file:line in /root/reference):
                   advantage normalisation of PPO.train (:335-336)
   running_stats.npz RunningMeanStd.update (rl/envs/normalize.py:182-208),
                   Standardizer.update_mean_std (imitation_lib/utils/networks.py:76-81)
+  normalize.npz   Normalize._obfilt (rl/envs/normalize.py:139-147) online + frozen
   trajectory.npz  Trajectory.__init__/reset_trajectory/get_next_sample/
                   create_dataset (olympic_mujoco/utils/trajectory.py)
   a3_task.npz     create_phase_reward (tasks/rewards.py:270), WalkingTask.reset/
@@ -292,6 +293,31 @@ def gen_running_stats():
          rms_mean=np.array(rms_mean), rms_var=np.array(rms_var), rms_count=np.array(rms_count),
          st_mean=np.array(st_mean), st_std=np.array(st_std), st_fwd_in=xs32[2],
          st_fwd_out=out.numpy(), st_fwd_mean=np.array(st.mean), st_fwd_std=np.array(st.std))
+
+
+def gen_normalize():
+    """Normalize._obfilt (rl/envs/normalize.py:139-147) online and frozen, on float32 batches
+    (the vectorised envs hand float32 observations to the filter)."""
+    rng = np.random.default_rng(12)
+
+    class Venv:
+        observation_space = np.zeros(6)
+        action_space = np.zeros(2)
+        num_envs = 1
+    nz = ns.normalize.Normalize(Venv(), clipob=2.5)
+    xs = [rng.normal(0.5, 3.0, (n, 6)).astype(np.float32) for n in (7, 33, 64)]
+    outs, means, vars_, counts = [], [], [], []
+    for x in xs:
+        outs.append(nz._obfilt(x))
+        means.append(nz.ob_rms.mean.copy())
+        vars_.append(nz.ob_rms.var.copy())
+        counts.append(nz.ob_rms.count)
+    nz.online = False
+    frozen_in = rng.normal(0.0, 6.0, (40, 6)).astype(np.float32)
+    frozen_out = nz._obfilt(frozen_in)
+    save("normalize.npz", lens=np.array([len(x) for x in xs]), x=np.concatenate(xs), out=np.concatenate(outs),
+         mean=np.array(means), var=np.array(vars_), count=np.array(counts), clipob=2.5, epsilon=1e-8,
+         frozen_in=frozen_in, frozen_out=frozen_out)
 
 
 # --------------------------------------------------------------- G4 trajectory
@@ -875,7 +901,7 @@ def gen_il_robot(cls_name, mod, xml, defaults):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd", "robots"]
+    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd", "robots", "norm"]
     tab = gen_h1_tables() if any(w in which for w in ("tables", "h1", "traj")) else None
     if "h1" in which:
         gen_h1_step(tab)
@@ -883,6 +909,8 @@ if __name__ == "__main__":
         gen_ppo()
     if "stats" in which:
         gen_running_stats()
+    if "norm" in which:
+        gen_normalize()
     if "traj" in which:
         gen_trajectory(tab)
     if "contacts" in which:

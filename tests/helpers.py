@@ -26,3 +26,28 @@ def a3_fixture_arrays(g, k):
     return st, inp
 
 
+
+
+def ppo_update_arrays(g):
+    """numpy forward of the fixture's actor / old actor / critic (relu MLPs) on its obs, and the
+    mirrored forward: everything oly_ppo_loss / oly_mirror_loss take as inputs."""
+    from olympic_hip.wrappers import _signed_perm
+
+    def mlp(x, tag, layers, head):
+        for i in range(2):
+            x = np.maximum(x @ g[f"{tag}.{layers}.{i}.weight"].T + g[f"{tag}.{layers}.{i}.bias"], 0)
+        return (x @ g[f"{tag}.{head}.weight"].T + g[f"{tag}.{head}.bias"]).astype(np.float32)
+    obs = g["obs"].astype(np.float32)
+    o_src, o_sgn = _signed_perm(g["mirrored_obs"].tolist())
+    a_src, a_sgn = _signed_perm(g["mirrored_acts"].tolist())
+    mobs = obs[:, o_src] * o_sgn
+    for i in (31, 32):                                     # mirror_clock_observation: sin(arcsin(x) + pi)
+        mobs[:, i] = np.sin(np.arcsin(mobs[:, i]) + np.float32(np.pi))
+    return dict(mu=mlp(obs, "pi", "actor_layers", "means"), old_mu=mlp(obs, "old", "actor_layers", "means"),
+                value=mlp(obs, "vf", "critic_layers", "network_out").reshape(-1),
+                mir=mlp(mobs.astype(np.float32), "pi", "actor_layers", "means"),
+                act_src=a_src.astype(np.int32), act_sign=a_sgn.astype(np.float32),
+                obs_src=o_src.astype(np.int32), obs_sign=o_sgn.astype(np.float32),
+                std=np.float32(g["fixed_std"]), action=g["act"].astype(np.float32),
+                adv=g["adv"].reshape(-1).astype(np.float32), ret=g["ret"].reshape(-1).astype(np.float32),
+                clip=float(g["clip"]))

@@ -604,3 +604,151 @@ def test_make_atlas_env_steps(eng):
     assert obs.shape == (env.spec.n_obs,) == (30,)
     o2, r, ab, _ = env.step(np.zeros(env.spec.n_act))
     assert o2.shape == (30,) and 0.0 < r <= 1.0 and ab is False
+
+
+# ------------------------------------------------------------------------------ K9 / normalisers
+def _ppo_case(rng, B, A, mode):
+    mu = rng.normal(0, 0.3, (B, A)).astype(np.float32)
+    old_mu = (mu + rng.normal(0, 0.05, (B, A))).astype(np.float32)
+    std = {0: np.array([0.22], np.float32), 1: rng.uniform(0.1, 0.4, A).astype(np.float32),
+           2: rng.uniform(0.1, 0.4, (B, A)).astype(np.float32)}[mode]
+    old_std = std if mode != 2 else (std * rng.uniform(0.9, 1.1, (B, A))).astype(np.float32)
+    action = (old_mu + rng.normal(0, 0.25, (B, A))).astype(np.float32)
+    adv = rng.normal(0, 1, B).astype(np.float32)
+    adv[::17] = 0.0                                          # tie of the two surrogate branches
+    ret, value = rng.normal(0, 1, B).astype(np.float32), rng.normal(0, 1, B).astype(np.float32)
+    return mu, std, old_mu, old_std, action, adv, ret, value
+
+
+@pytest.mark.parametrize("B,A,mode", [(64, 12, 0), (1, 3, 1), (5000, 12, 2), (777, 64, 1), (300000, 11, 0)])
+def test_ppo_loss_vs_oracle(eng, oracle, B, A, mode):
+    """Tolerance: device expf/logf vs libm are within 1-2 ulp per element; the sums are fp64 on
+    both sides -> 2e-5 relative on the loss terms, 1e-4 relative (1e-9 absolute) on gradients."""
+    rng = np.random.default_rng(B + A + mode)
+    c = _ppo_case(rng, B, A, mode)
+    r = eng.ppo_loss(*(dev(x) for x in c), 0.2, 0.5, want_grad=True, want_grad_std=True)
+    scal, gmu, gsd, gv = oracle.ppo_loss(*c, 0.2, 0.5)
+    np.testing.assert_allclose(host(r["scal"]), scal, rtol=2e-5, atol=1e-7)
+    assert scal[4] > 0 or B == 1                               # the case exercises clipping
+    np.testing.assert_allclose(host(r["grad_value"]), gv, rtol=1e-6, atol=0)
+    np.testing.assert_allclose(host(r["grad_mu"]), gmu, rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(host(r["grad_std"]), gsd, rtol=1e-4, atol=1e-9)
+
+
+def test_ppo_loss_golden_and_autograd(eng, golden):
+    """(a) the reference's update_policy numbers; (b) the fused Function's parameter gradients
+    equal torch autograd of the op-by-op form (ppo.update_policy) within fp32 rounding."""
+    from helpers import ppo_update_arrays
+    from olympic_hip.ppo import PPO, MLPCritic, MLPGaussianActor
+    g = golden("ppo_update.npz")
+    a = ppo_update_arrays(g)
+    r = eng.ppo_loss(dev(a["mu"]), dev(np.array([a["std"]])), dev(a["old_mu"]), dev(np.array([a["std"]])),
+                     dev(a["action"]), dev(a["adv"]), dev(a["ret"]), dev(a["value"]), a["clip"], 0.5)
+    s = host(r["scal"])
+    for i, n in enumerate(("actor_loss", "entropy_penalty", "critic_loss", "approx_kl_div", "clip_fraction")):
+        np.testing.assert_allclose(s[i], float(g[n]), rtol=3e-5, atol=3e-7, err_msg=n)
+    loss, gd, gm = eng.mirror_loss(dev(a["mu"]), dev(a["mir"]), dev(a["act_src"]), dev(a["act_sign"]))
+    np.testing.assert_allclose(float(loss), float(g["mirror_loss"]), rtol=3e-5)
+
+    def load(mod, tag):
+        mod.load_state_dict({k[len(tag) + 1:]: torch.tensor(g[k]) for k in g.files if k.startswith(tag + ".")})
+        return mod.cuda()
+    std = torch.tensor(float(g["fixed_std"]))
+    ppo = PPO.__new__(PPO)
+    ppo.clip, ppo.vf_coeff = a["clip"], 0.5
+    t = lambda k: dev(g[k], torch.float32)
+    from olympic_hip.wrappers import SymmetricEnv
+
+    class Dummy:
+        base_obs_len = 41
+    sym = SymmetricEnv(Dummy, mirrored_obs=g["mirrored_obs"].tolist(), mirrored_act=g["mirrored_acts"].tolist(),
+                       clock_inds=[31, 32])
+    grads = []
+    for fused in (False, True):
+        ppo.policy = load(MLPGaussianActor(41, 12, fixed_std=std), "pi")
+        ppo.old_policy = load(MLPGaussianActor(41, 12, fixed_std=std), "old")
+        ppo.critic = load(MLPCritic(41), "vf")
+        if fused:
+            out = ppo.update_policy_fused(eng, t("obs"), t("act"), t("ret"), t("adv"), sym.mirror_clock_observation,
+                                          dev(a["act_src"]), dev(a["act_sign"]))
+        else:
+            out = ppo.update_policy(t("obs"), t("act"), t("ret"), t("adv"), 1, sym.mirror_clock_observation,
+                                    sym.mirror_action)
+        (out[0] + 0.4 * out[4] + 0.01 * out[1] + out[2]).sum().backward()   # actor and critic share no parameters
+        grads.append([p.grad.clone() for p in list(ppo.policy.parameters()) + list(ppo.critic.parameters())])
+        for i, n in enumerate(("actor_loss", "entropy_penalty", "critic_loss", "approx_kl_div", "mirror_loss")):
+            np.testing.assert_allclose(float(out[i]), float(g[n]), rtol=3e-5, atol=3e-7, err_msg=n)
+    for gu, gf in zip(*grads):
+        scale = float(gu.abs().max()) + 1e-12
+        assert float((gu - gf).abs().max()) <= 2e-5 * scale
+
+
+def test_ppo_loss_learned_std_autograd(eng):
+    """learn_std actors: d/d std through the fused Function (per-dim parameter and full [B,A])."""
+    from olympic_hip.ppo import FusedPPOLoss
+    rng = np.random.default_rng(3)
+    B, A = 257, 6
+    mu, _, old_mu, _, action, adv, ret, value = (dev(x) for x in _ppo_case(rng, B, A, 0))
+    for shape in ((A,), (B, A)):
+        log_std = torch.full(shape, -1.2, device="cuda").requires_grad_()
+        mu_p = mu.clone().requires_grad_()
+        res = []
+        for fused in (False, True):
+            log_std.grad = mu_p.grad = None
+            std = log_std.exp()
+            if fused:
+                a_l, ent, c_l, _, _ = FusedPPOLoss.apply(eng, mu_p, std, old_mu, std.detach() * 1.05, action, adv, ret,
+                                                         value, 0.2, 0.5)
+            else:
+                pdf = torch.distributions.Normal(mu_p, std.expand(B, A))
+                old = torch.distributions.Normal(old_mu, (std.detach() * 1.05).expand(B, A))
+                lp, olp = pdf.log_prob(action).sum(-1), old.log_prob(action).sum(-1)
+                ratio = (lp - olp).exp()
+                a_l = -torch.min(ratio * adv, ratio.clamp(0.8, 1.2) * adv).mean()
+                ent = -pdf.entropy().mean()
+            (a_l + 0.3 * ent).backward()
+            res.append((float(a_l), float(ent), log_std.grad.clone(), mu_p.grad.clone()))
+        (a0, e0, gs0, gm0), (a1, e1, gs1, gm1) = res
+        assert a0 == pytest.approx(a1, rel=2e-5) and e0 == pytest.approx(e1, rel=2e-6)
+        assert float((gs0 - gs1).abs().max()) <= 3e-5 * float(gs0.abs().max())
+        assert float((gm0 - gm1).abs().max()) <= 3e-5 * float(gm0.abs().max())
+
+
+def test_signed_perm_and_mirror_loss(eng, oracle, golden):
+    from olympic_hip.wrappers import _signed_perm
+    g = golden("symmetry.npz")
+    for tab, x, want in ((g["mirrored_obs"], g["obs"], g["obs_mirror"]), (g["mirrored_acts"], g["act"], g["act_mirror"])):
+        src, sgn = _signed_perm(tab.tolist())
+        out = eng.signed_perm(dev(x, torch.float32), dev(src, torch.int32), dev(sgn))
+        assert np.array_equal(host(out), want.astype(np.float32))          # +-1 times one input: exact
+    rng = np.random.default_rng(5)
+    B, A = 4096, 12
+    src, sgn = _signed_perm(g["mirrored_acts"].tolist())
+    det, mir = rng.normal(0, 1, (B, A)).astype(np.float32), rng.normal(0, 1, (B, A)).astype(np.float32)
+    loss, gd, gm = eng.mirror_loss(dev(det), dev(mir), dev(src, torch.int32), dev(sgn))
+    el, egd, egm = oracle.mirror_loss(det, mir, src, sgn)
+    assert float(loss) == pytest.approx(el, rel=1e-12)                      # same fp32 squares, fp64 sum
+    assert np.array_equal(host(gd), egd) and np.array_equal(host(gm), egm)  # mul/sub only: exact
+
+
+def test_obs_filter_and_device_running_mean_std(eng, oracle, golden):
+    from olympic_hip.normalize import RunningMeanStd
+    g = golden("normalize.npz")
+    clip, eps = float(g["clipob"]), float(g["epsilon"])
+    out = eng.obs_filter(dev(g["frozen_in"]), dev(g["mean"][-1]), dev(g["var"][-1]), eps, clip)
+    assert np.array_equal(host(out), g["frozen_out"].astype(np.float32))    # fp64 sub/div/sqrt: exact
+    rms = RunningMeanStd(eng, shape=(6,))
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    for i in range(len(g["lens"])):
+        xb = dev(g["x"][off[i]:off[i + 1]])
+        rms.update(xb)
+        np.testing.assert_allclose(host(rms.mean), g["mean"][i], rtol=2e-6, atol=2e-7)   # reference moments fp32
+        np.testing.assert_allclose(host(rms.var), g["var"][i], rtol=2e-5)
+        assert rms.count == pytest.approx(float(g["count"][i]))
+        o = eng.obs_filter(xb, rms.mean, rms.var, eps, clip)
+        assert np.array_equal(host(o), oracle.obs_filter(g["x"][off[i]:off[i + 1]], host(rms.mean), host(rms.var), eps, clip))
+        np.testing.assert_allclose(host(o), g["out"][off[i]:off[i + 1]], rtol=2e-5, atol=2e-6)
+    big = np.random.default_rng(0).normal(0, 3, (100000, 32)).astype(np.float32)
+    m, v = big.mean(0, dtype=np.float64), big.var(0, dtype=np.float64)
+    o = eng.obs_filter(dev(big), dev(m), dev(v), 1e-8, 10.0)
+    assert np.array_equal(host(o), oracle.obs_filter(big, m, v, 1e-8, 10.0))

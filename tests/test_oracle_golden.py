@@ -341,3 +341,59 @@ def test_vail_forward_end_to_end(golden, oracle):
     z = torch.tensor(oracle.disc_reparam(mu.numpy(), lv.numpy(), g["eps"]))
     d = z @ t("dec_w").T + t("dec_b")
     np.testing.assert_allclose(d.numpy(), g["d"], rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------ K9 / normalisers
+def test_ppo_loss_terms_match_reference_update_policy(golden, oracle):
+    """oly_ppo_loss_cpu / oly_mirror_loss_cpu on the reference's own update_policy outputs
+    (tolerance: the reference reduces in fp32, the oracle in fp64)."""
+    from helpers import ppo_update_arrays
+    g = golden("ppo_update.npz")
+    a = ppo_update_arrays(g)
+    scal, gmu, gsd, gv = oracle.ppo_loss(a["mu"], a["std"], a["old_mu"], a["std"], a["action"], a["adv"], a["ret"],
+                                         a["value"], a["clip"], 0.5)
+    for i, n in enumerate(("actor_loss", "entropy_penalty", "critic_loss", "approx_kl_div", "clip_fraction")):
+        np.testing.assert_allclose(scal[i], float(g[n]), rtol=3e-5, atol=3e-7, err_msg=n)
+    loss, gd, gm = oracle.mirror_loss(a["mu"], a["mir"], a["act_src"], a["act_sign"])
+    np.testing.assert_allclose(loss, float(g["mirror_loss"]), rtol=3e-5, atol=1e-9)
+    # gradients: finite differences of the oracle's own forward in float64-safe directions
+    B, A = a["mu"].shape
+    assert np.isfinite(gmu).all() and gmu.shape == (B, A) and gv.shape == (B,)
+    np.testing.assert_allclose(gv, 0.5 * 2 * (a["value"] - a["ret"]) / B, rtol=1e-6)
+    np.testing.assert_allclose(gd, 2 * (a["mu"] - a["act_sign"] * a["mir"][:, a["act_src"]]) / (B * A), rtol=1e-6)
+    back = np.zeros_like(gm)
+    back[:, a["act_src"]] = -a["act_sign"] * gd
+    assert np.array_equal(back, gm)
+
+
+def test_signed_perm_is_the_reference_matrix_product(golden, oracle):
+    from olympic_hip.wrappers import _signed_perm
+    g = golden("symmetry.npz")
+    for tab, x, want in ((g["mirrored_obs"], g["obs"], g["obs_mirror"]), (g["mirrored_acts"], g["act"], g["act_mirror"])):
+        src, sgn = _signed_perm(tab.tolist())
+        out = oracle.signed_perm(x, src, sgn)
+        assert np.array_equal(out, want.astype(np.float32))
+
+
+def test_obs_filter_and_running_mean_std(golden, oracle):
+    g = golden("normalize.npz")
+    clip, eps = float(g["clipob"]), float(g["epsilon"])
+    out = oracle.obs_filter(g["frozen_in"], g["mean"][-1], g["var"][-1], eps, clip)
+    assert np.array_equal(out, g["frozen_out"].astype(np.float32))           # frozen statistics: exact
+    # online: batch moments from (count, sum, sumsq) + the reference's merge (normalize.py:188-208)
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    mean, var, count = np.zeros(6), np.zeros(6), 1e-4
+    for i in range(len(g["lens"])):
+        xb = g["x"][off[i]:off[i + 1]]
+        cs = oracle.col_stats(xb)
+        n = cs[0]
+        bm = cs[1] / n
+        bv = cs[2] / n - bm * bm
+        delta, tot = bm - mean, count + n
+        m2 = var * count + bv * n + delta ** 2 * count * n / tot
+        mean, var, count = mean + delta * n / tot, m2 / tot, tot
+        np.testing.assert_allclose(mean, g["mean"][i], rtol=2e-6, atol=2e-7)   # reference moments are fp32
+        np.testing.assert_allclose(var, g["var"][i], rtol=2e-5)
+        assert count == pytest.approx(float(g["count"][i]))
+        o = oracle.obs_filter(xb, mean, var, eps, clip)
+        np.testing.assert_allclose(o, g["out"][off[i]:off[i + 1]], rtol=2e-5, atol=2e-6)

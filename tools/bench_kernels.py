@@ -65,6 +65,22 @@ def main():
     o = torch.empty_like(xs)
     ms = timeit(eng, lambda: eng.disc_standardize(xs, None, mean, std, o))
     out["K8_standardize_[409600,32]"] = dict(ms=ms, GBps=8 * xs.numel() / ms / 1e6)
+    # K9: PPO loss terms (forward + gradients in one pass) at full-batch and minibatch sizes
+    for Bp in (T * N, 4096):
+        A = 12
+        mu, omu, act = rnd((Bp, A)) * 0.3, rnd((Bp, A)) * 0.3, rnd((Bp, A)) * 0.3
+        sd = torch.full((1,), 0.22, device=dev)
+        av, rt, vl = rnd((Bp,)), rnd((Bp,)), rnd((Bp,))
+        ms = timeit(eng, lambda: eng.ppo_loss(mu, sd, omu, sd, act, av, rt, vl, 0.2, 0.5))
+        out[f"K9_ppo_loss_[{Bp},12]"] = dict(ms=ms, GBps=(16 * A + 16) * Bp / ms / 1e6, bytes_per_row=16 * A + 16)
+    src = torch.tensor([6, 7, 8, 9, 10, 11, 0, 1, 2, 3, 4, 5], dtype=torch.int32, device=dev)
+    sg = torch.ones(12, device=dev)
+    ms = timeit(eng, lambda: eng.mirror_loss(mu, omu, src, sg))
+    out["K9_mirror_loss_[4096,12]"] = dict(ms=ms)
+    xo = rnd((T * N // 8, 32))
+    mean, var = torch.zeros(32, dtype=torch.float64, device=dev), torch.ones(32, dtype=torch.float64, device=dev)
+    ms = timeit(eng, lambda: eng.obs_filter(xo, mean, var, 1e-8, 10.0, out=xo))
+    out["obs_filter_[204800,32]"] = dict(ms=ms, GBps=8 * xo.numel() / ms / 1e6)
     # K3
     gb = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)
     eng.contact_configure(gb, 0, 7, 10)
