@@ -158,6 +158,15 @@ class VecA3Env:
         self.state["target_reached"][idx] = 0
         self.state["goal"][idx] = 0.0
 
+    def state_dict(self):
+        """Task state carried between steps (phase counters, target indices, sequences, goals)."""
+        return dict(iteration_count=self.iteration_count, **{k: v.clone() for k, v in self.state.items()})
+
+    def load_state_dict(self, d):
+        self.iteration_count = d["iteration_count"]
+        for k, v in self.state.items():
+            v.copy_(d[k])
+
     def step(self, actions):
         """(obs [N,41], total_reward [N], done [N] bool, rewards [N,6])  StickFigureA3.py:187-200."""
         actions = actions.to(torch.float32).contiguous()

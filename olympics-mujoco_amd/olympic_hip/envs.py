@@ -317,6 +317,27 @@ class VecLocoEnv:
                              "happen.\n\nViolations:\n" + self.spec.fall_names[k] + " violated.\n")
         return ds
 
+    # ----- checkpoint / resume: everything an iteration carries besides the policy
+    def state_dict(self):
+        d = dict(prev=self._prev.clone(), episode_steps=self.episode_steps.clone(),
+                 qpos=self.physics.qpos.clone(), qvel=self.physics.qvel.clone(),
+                 rng=self._rng.bit_generator.state, obs=None if self._obs is None else self._obs.clone())
+        if self.trajectories is not None:
+            d.update(cur_traj=self._cur_traj.clone(), cur_step=self._cur_step.clone(), origin=self._origin.clone(),
+                     sample=self._sample.clone())
+        return d
+
+    def load_state_dict(self, d):
+        self._prev = d["prev"].to(self.device).clone()
+        self.episode_steps.copy_(d["episode_steps"])
+        self.physics.set_state(d["qpos"].to(self.device), d["qvel"].to(self.device))
+        self._rng.bit_generator.state = d["rng"]
+        self._obs = None if d["obs"] is None else d["obs"].to(self.device).clone()
+        if self.trajectories is not None:
+            for k, t in (("cur_traj", self._cur_traj), ("cur_step", self._cur_step), ("origin", self._origin),
+                         ("sample", self._sample)):
+                t.copy_(d[k])
+
     def get_kinematic_obs_mask(self):
         return np.arange(self.spec.n_pos + self.spec.n_vel - 2)       # loco_env_base.py:886
 

@@ -50,10 +50,10 @@ class Normalize:
                  epsilon=1e-8):
         self.venv = venv
         self.eng = venv.eng
-        self._observation_space = venv.observation_space
-        self._action_space = venv.action_space
-        d = int(np.prod(np.shape(self._observation_space))) if not hasattr(self._observation_space, "shape") else \
-            int(np.prod(self._observation_space.shape))
+        info = getattr(venv, "info", None)                     # mushroom-style envs keep the spaces in .info
+        self._observation_space = venv.observation_space if hasattr(venv, "observation_space") else info.observation_space
+        self._action_space = venv.action_space if hasattr(venv, "action_space") else info.action_space
+        d = int(np.prod(self._observation_space.shape))
         self.ob_rms = ob_rms if ob_rms is not None else (RunningMeanStd(self.eng, shape=(d,)) if ob else None)
         self.ret_rms = RunningMeanStd(self.eng, shape=()) if ret else None
         self.clipob, self.cliprew = clipob, cliprew

@@ -138,6 +138,80 @@ class FusedMirrorLoss(torch.autograd.Function):
         return None, g * gd, g * gm, None, None
 
 
+class GraphedUpdate:
+    """One PPO minibatch update (fused losses -> backward -> grad clip -> Adam on actor and
+    critic) captured once as a HIP graph and replayed per minibatch: at the reference's
+    minibatch sizes the update is ~150 tiny launches and purely launch-bound.
+
+    The minibatch is copied into static buffers; parameters, optimiser state and the old
+    policy are updated in place, so replay sees their current values."""
+
+    def __init__(self, ppo, eng, batch, obs_dim, act_dim, obs_mirr=None, act_src=None, act_sign=None, warmup=3):
+        dev = eng.device
+        self.obs = torch.zeros((batch, obs_dim), dtype=torch.float32, device=dev)
+        self.act = torch.zeros((batch, act_dim), dtype=torch.float32, device=dev)
+        self.ret = torch.zeros((batch, 1), dtype=torch.float32, device=dev)
+        self.adv = torch.zeros((batch, 1), dtype=torch.float32, device=dev)
+        opts = (ppo.actor_optimizer, ppo.critic_optimizer)
+        for o in opts:
+            for gparam in o.param_groups:
+                if not gparam.get("capturable", False):
+                    raise ValueError("GraphedUpdate needs Adam(capturable=True)")
+        nets = (ppo.policy, ppo.critic)
+        keep = [deepcopy(m.state_dict()) for m in nets]
+        keep_opt = [{p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in o.state.items()}
+                    for o in opts]
+
+        def body():
+            # Normal(validate_args=True) reads its check back to the host: not capturable
+            validate = torch.distributions.Distribution._validate_args
+            torch.distributions.Distribution.set_default_validate_args(False)
+            try:
+                return body_()
+            finally:
+                torch.distributions.Distribution.set_default_validate_args(validate)
+
+        def body_():
+            a_l, ent, c_l, kl, m_l, clipf = ppo.update_policy_fused(eng, self.obs, self.act, self.ret, self.adv,
+                                                                    obs_mirr, act_src, act_sign)
+            for o in opts:
+                o.zero_grad(set_to_none=True)
+            (a_l + ppo.mirror_coeff * m_l + ppo.ent_coeff * ent + c_l).sum().backward()
+            torch.nn.utils.clip_grad_norm_(ppo.policy.parameters(), ppo.grad_clip)
+            opts[0].step()
+            torch.nn.utils.clip_grad_norm_(ppo.critic.parameters(), ppo.grad_clip)
+            opts[1].step()
+            return torch.stack([a_l.detach(), ent.detach(), c_l.detach(), kl.detach(), m_l.detach().reshape(()),
+                                clipf.detach()])
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.stats = body()
+        for m, sd in zip(nets, keep):                         # warm-up steps must not count as training
+            m.load_state_dict(sd)
+        for o, saved in zip(opts, keep_opt):                  # in place: the graph holds these buffers
+            for p, st in o.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if p in saved:
+                            v.copy_(saved[p][k])
+                        else:
+                            v.zero_()
+
+    def __call__(self, observations, actions, returns, advantages, idx):
+        torch.index_select(observations, 0, idx, out=self.obs)
+        torch.index_select(actions, 0, idx, out=self.act)
+        torch.index_select(returns, 0, idx, out=self.ret)
+        torch.index_select(advantages, 0, idx, out=self.adv)
+        self.graph.replay()
+        return self.stats
+
+
 class PPO:
     def __init__(self, args, save_path):
         self.gamma, self.lam = args["gamma"], args["lam"]
@@ -248,8 +322,9 @@ class PPO:
     def train(self, env_fn, policy, critic, n_itr, anneal_rate=1.0, verbose=True):
         self.old_policy = deepcopy(policy)
         self.policy, self.critic = policy, critic
-        self.actor_optimizer = optim.Adam(policy.parameters(), lr=self.lr, eps=self.eps)
-        self.critic_optimizer = optim.Adam(critic.parameters(), lr=self.lr, eps=self.eps)
+        use_graph = bool(getattr(self, "use_graph", False))
+        self.actor_optimizer = optim.Adam(policy.parameters(), lr=self.lr, eps=self.eps, capturable=use_graph)
+        self.critic_optimizer = optim.Adam(critic.parameters(), lr=self.lr, eps=self.eps, capturable=use_graph)
         env = env_fn()
         post = PPORollout(env.eng, gamma=self.gamma, lam=self.lam, eps=self.eps)
         obs_mirr = getattr(env, "mirror_clock_observation", None) if hasattr(env, "mirror_observation") else None
@@ -283,9 +358,15 @@ class PPO:
             minibatch = self.minibatch_size or n
             t1 = time.time()
             stats = []
+            if use_graph and fused and getattr(self, "_graphed", None) is None:
+                self._graphed = GraphedUpdate(self, env.eng, minibatch, observations.shape[1], actions.shape[1],
+                                              obs_mirr, act_src, act_sign)
             for _ in range(self.epochs):
                 for idx in BatchSampler(SubsetRandomSampler(range(n)), minibatch, drop_last=True):
                     idx = torch.as_tensor(idx, device=observations.device)
+                    if use_graph and fused:
+                        stats.append(self._graphed(observations, actions, returns, advantages, idx).clone())
+                        continue
                     if fused:
                         a_l, ent, c_l, kl, m_l, clipf = self.update_policy_fused(
                             env.eng, observations[idx], actions[idx], returns[idx], advantages[idx], obs_mirr,
@@ -307,6 +388,8 @@ class PPO:
                     torch.nn.utils.clip_grad_norm_(critic.parameters(), self.grad_clip)
                     self.critic_optimizer.step()
                     stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), float(clipf)))
+            if stats and torch.is_tensor(stats[0]):
+                stats = torch.stack(stats).cpu().tolist()      # one device->host copy per iteration
             ep_ret, ep_len = buf.episode_stats()
             mean_ret = float(np.mean(ep_ret)) if ep_ret else 0.0
             self.highest_reward = max(self.highest_reward, mean_ret)

@@ -76,11 +76,19 @@ class SymmetricEnv:
     def __getattr__(self, attr):
         return getattr(self.env, attr)
 
+    def _on(self, name, device):
+        """Mirror tables cached per device (no host->device copy per call; graph-capturable)."""
+        cache = self.__dict__.setdefault("_dev_tables", {})
+        key = (name, str(device))
+        if key not in cache:
+            cache[key] = getattr(self, name).to(device)
+        return cache[key]
+
     def mirror_action(self, action):
-        return action[..., self._act_src.to(action.device)] * self._act_sgn.to(action.device)
+        return action[..., self._on("_act_src", action.device)] * self._on("_act_sgn", action.device)
 
     def mirror_observation(self, obs):
-        return obs[..., self._obs_src.to(obs.device)] * self._obs_sgn.to(obs.device)
+        return obs[..., self._on("_obs_src", obs.device)] * self._on("_obs_sgn", obs.device)
 
     def mirror_clock_observation(self, obs):
         """Mirror, then shift the clock entries by half a period: sin(arcsin(x) + pi) = -x

@@ -20,6 +20,9 @@ _LIB = None
 
 
 def build(force=False):
+    if os.environ.get("OLY_ORACLE_ASAN") == "1":           # sanitizer run of the CPU suite (tests/test_host_cpu.py)
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "asan"])
+        return os.path.join(_HERE, "liboly_oracle_asan.so")
     so = os.path.join(_HERE, "liboly_oracle.so")
     src = [os.path.join(_HERE, f) for f in ("oly_oracle.c", "oly_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):

@@ -232,7 +232,8 @@ def test_vec_a3_env_replays_golden_sequence(golden):
         np.testing.assert_allclose(host(rew6), g["rew6"][:, k], rtol=2e-6, atol=1e-7)
 
 
-def test_ppo_train_iterations_on_vec_a3(golden, tmp_path):
+@pytest.mark.parametrize("mode", ["torch_losses", "fused", "fused_graph"])
+def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode):
     """Config 3 end to end: VecA3Env (synthetic physics readback) -> PPO.train: rollout,
     return scan + adv-norm on the device, clipped-surrogate updates in PyTorch."""
     from olympic_hip.a3 import ReplayA3Physics, VecA3Env
@@ -275,6 +276,7 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path):
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=2048, epochs=2,
                 max_traj_len=16, use_gae=False, num_procs=N, max_grad_norm=0.05, mirror_coeff=0.0, eval_freq=100)
     ppo = PPO(args, str(tmp_path))
+    ppo.fused_loss, ppo.use_graph = mode != "torch_losses", mode == "fused_graph"
     torch.manual_seed(0)
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
     w0 = pi.means.weight.detach().clone()
@@ -284,6 +286,14 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path):
     assert ppo.total_steps == 2 * 16 * N
     lines = open(ppo.train_fn).read().strip().splitlines()
     assert lines[0] == "ep_returns,ep_lens" and len(lines) == 3
+    # the three update paths are the same algorithm: same seed -> same trained weights (fp32 rounding)
+    _TRAINED[mode] = torch.cat([p.detach().reshape(-1) for p in list(pi.parameters()) + list(vf.parameters())]).cpu()
+    if "torch_losses" in _TRAINED and mode != "torch_losses":
+        a, b = _TRAINED["torch_losses"], _TRAINED[mode]
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+_TRAINED = {}
 
 
 def test_gail_fit_reward_and_advantage_pipeline(golden, oracle):
@@ -399,3 +409,73 @@ def test_get_normalization_params_and_block_eval(oracle):
                            torch.as_tensor(prev).cuda())
     ref = oracle.il_step(sp, qpos, qvel, act, prev, obs_f64=True)
     assert np.array_equal(host(o["obs"]), ref["obs"]) and np.array_equal(host(o["absorbing"]), ref["absorbing"])
+
+
+# ----------------------------------------------------------------- checkpoint / resume, normalisers
+def test_vec_env_state_dict_resume(oracle):
+    """Stop after 7 steps, restore into a fresh env, continue: identical to the uninterrupted run."""
+    from olympic_hip.envs import ReplayPhysics, VecLocoEnv
+    sp = specs.unitree_h1("walk")
+    T, N = 14, 512
+    qpos, qvel, act = h1_synthetic_block(sp, T, N, seed=5, fall_frac="wide")
+    cu = lambda a: torch.as_tensor(a).cuda()
+
+    def run(env, t0, t1):
+        out = []
+        for t in range(t0, t1):
+            o, r, a, _ = env.step(cu(act[t]))
+            out.append((host(o), host(r), host(a)))
+        return out
+    full_env = VecLocoEnv(sp, N, physics=ReplayPhysics(sp, cu(qpos), cu(qvel)), random_start=False)
+    full = run(full_env, 0, T)
+    a_env = VecLocoEnv(sp, N, physics=ReplayPhysics(sp, cu(qpos), cu(qvel)), random_start=False)
+    run(a_env, 0, 7)
+    ckpt = a_env.state_dict()
+    b_env = VecLocoEnv(sp, N, physics=ReplayPhysics(sp, cu(qpos[7:]), cu(qvel[7:])), random_start=False)
+    b_env.load_state_dict(ckpt)
+    rest = run(b_env, 7, T)
+    for (o1, r1, a1), (o2, r2, a2) in zip(full[7:], rest):
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(a1, a2)
+    assert np.array_equal(host(b_env.episode_steps), host(full_env.episode_steps))
+
+
+def test_runningmeanstd_incremental_equals_batch():
+    """The reference's only unit test (rl/envs/normalize.py:210-225) on the device class."""
+    from olympic_hip.engine import Engine
+    from olympic_hip.normalize import RunningMeanStd
+    eng = Engine(0)
+    rng = np.random.default_rng(0)
+    for shape in ((), (2,)):
+        xs = [rng.standard_normal((n,) + shape).astype(np.float32) for n in (3, 4, 5)]
+        rms = RunningMeanStd(eng, epsilon=0.0, shape=shape)
+        x = np.concatenate(xs, axis=0)
+        for xi in xs:
+            rms.update(torch.as_tensor(xi).cuda())
+        ms1 = [x.mean(axis=0, dtype=np.float64).reshape(-1), x.var(axis=0, dtype=np.float64).reshape(-1)]
+        ms2 = [host(rms.mean), host(rms.var)]
+        assert np.allclose(ms1[0], ms2[0]) and np.allclose(ms1[1], ms2[1])
+
+
+def test_normalize_wrapper_on_vec_env():
+    """Normalize(VecLocoEnv): online statistics + clipped filter per vec step; frozen afterwards."""
+    from olympic_hip.envs import ReplayPhysics, VecLocoEnv
+    from olympic_hip.normalize import Normalize
+    sp = specs.unitree_h1("walk")
+    T, N = 6, 1024
+    qpos, qvel, act = h1_synthetic_block(sp, T, N, seed=9, fall_frac="none")
+    cu = lambda a: torch.as_tensor(a).cuda()
+    env = Normalize(VecLocoEnv(sp, N, physics=ReplayPhysics(sp, cu(qpos), cu(qvel)), random_start=False), clipob=5.0)
+    raw = []
+    for t in range(T):
+        o, r, d, _ = env.step(cu(act[t]))
+        raw.append(host(env.venv._obs))
+        assert o.shape == (N, sp.n_obs) and float(o.abs().max()) <= 5.0
+    allx = np.concatenate(raw).astype(np.float64)
+    np.testing.assert_allclose(host(env.ob_rms.mean), allx.mean(0), rtol=1e-6, atol=1e-6)    # eps-count prior 1e-4
+    np.testing.assert_allclose(host(env.ob_rms.var), allx.var(0), rtol=1e-5, atol=1e-8)
+    want = np.clip((raw[-1] - host(env.ob_rms.mean)) / np.sqrt(host(env.ob_rms.var) + 1e-8), -5, 5).astype(np.float32)
+    assert np.array_equal(host(o), want)
+    env.online = False
+    cnt = env.ob_rms.count
+    env.step(cu(act[0]))
+    assert env.ob_rms.count == cnt

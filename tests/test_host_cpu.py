@@ -362,3 +362,23 @@ def test_atlas_talos_registered():
     with pytest.raises(ValueError):
         Atlas.generate("run", "real")
     assert Talos._default_back is False and Atlas._default_back is True
+
+
+# ------------------------------------------------------------------------------ sanitizers
+def test_oracle_golden_suite_under_asan_ubsan():
+    """The oracle's golden tests once more with the C code built -fsanitize=address,undefined
+    (GPU ASan does not exist on this pool; the CPU restatement shares the indexing logic)."""
+    import shutil
+    import subprocess
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or shutil.which("make") is None:
+        pytest.skip("no libasan in this toolchain")
+    env = dict(os.environ, OLY_ORACLE_ASAN="1", LD_PRELOAD=asan, OMP_NUM_THREADS="2",
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_oracle_golden.py")],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
