@@ -164,7 +164,9 @@ def test_il_argument_errors(eng):
 
 # --------------------------------------------------------------------------------- K6
 @pytest.mark.parametrize("mode", [_abi.SCAN_RETURN, _abi.SCAN_GAE])
-@pytest.mark.parametrize("T,N", [(1, 1), (5, 3), (400, 257), (33, 4096)])
+@pytest.mark.parametrize("T,N", [(1, 1), (5, 3), (400, 257), (33, 4096),       # fallback kernel (N % 4), one tile
+                                 (7, 20), (400, 4096), (97, 1028),             # 16-env workgroups, ragged last group
+                                 (70, 16388), (45, 32776)])                    # 32- and 64-env workgroups
 def test_scan_vs_oracle(eng, oracle, mode, T, N):
     rng = np.random.default_rng(T * 7 + N)
     r = rng.uniform(-0.3, 1, (T, N)).astype(np.float32)
@@ -177,6 +179,20 @@ def test_scan_vs_oracle(eng, oracle, mode, T, N):
     e_ret, e_adv = oracle.return_scan(mode, 0.99, 0.97, r, v, vn, flags)
     assert np.array_equal(host(ret), e_ret)        # same fp op sequence, no FMA: bit-exact
     assert np.array_equal(host(adv), e_adv)
+
+
+def test_scan_unaligned_views_take_the_fallback(eng, oracle):
+    """Buffers that are not 16-byte aligned (views at an odd element offset) are legal input."""
+    rng = np.random.default_rng(2)
+    T, N = 50, 64
+    r, v, vn = (rng.normal(0, 1, T * N + 1).astype(np.float32) for _ in range(3))
+    flags = (rng.uniform(size=T * N + 1) < 0.05).astype(np.uint8) * 3
+    view = lambda a: dev(a)[1:].view(T, N)
+    for mode in (_abi.SCAN_RETURN, _abi.SCAN_GAE):
+        ret, adv = eng.return_scan(mode, 0.99, 0.97, view(r), view(v), view(vn), view(flags))
+        e_ret, e_adv = oracle.return_scan(mode, 0.99, 0.97, r[1:].reshape(T, N), v[1:].reshape(T, N),
+                                          vn[1:].reshape(T, N), flags[1:].reshape(T, N))
+        assert np.array_equal(host(ret), e_ret) and np.array_equal(host(adv), e_adv)
 
 
 def test_scan_golden_ppo(eng, golden):
