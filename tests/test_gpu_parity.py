@@ -195,6 +195,36 @@ def test_scan_unaligned_views_take_the_fallback(eng, oracle):
         assert np.array_equal(host(ret), e_ret) and np.array_equal(host(adv), e_adv)
 
 
+@pytest.mark.parametrize("mode", [_abi.SCAN_RETURN, _abi.SCAN_GAE])
+def test_scan_config5_full_size_shard_independence(eng, mode):
+    """Config 5 at full size ([400, 32768] = 8 x 4096): environments are independent, so the
+    whole block (64-env workgroups) must equal its eight 4096-env shards scanned separately
+    (16-env workgroups) bit for bit; the (count, sum, sumsq) triples of the shards add up to
+    the block's (the quantity the RCCL all-gather carries)."""
+    T, N, G = 400, 32768, 8
+    g = torch.Generator(device="cuda").manual_seed(11)
+    r, v, vn = (torch.empty((T, N), device="cuda").normal_(0, 1, generator=g) for _ in range(3))
+    fl = (torch.rand((T, N), device="cuda", generator=g) < 1 / 300).to(torch.uint8) * _abi.FLAG_LAST
+    fl |= ((torch.rand((T, N), device="cuda", generator=g) < 0.5).to(torch.uint8) * _abi.FLAG_ABSORBING) & (fl >> 1)
+    ret, adv = eng.return_scan(mode, 0.99, 0.97, r, v, vn, fl)
+    tot = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for k in range(G):
+        sl = slice(k * N // G, (k + 1) * N // G)
+        rs, as_ = eng.return_scan(mode, 0.99, 0.97, *(t[:, sl].contiguous() for t in (r, v, vn, fl)))
+        assert torch.equal(rs, ret[:, sl]) and torch.equal(as_, adv[:, sl])
+        tot += eng.adv_stats(as_)
+    whole = eng.adv_stats(adv)
+    assert float(whole[0]) == float(tot[0]) == T * N
+    np.testing.assert_allclose(host(whole), host(tot), rtol=1e-12)
+    # episode cuts really cut: a LAST step's return does not depend on anything after it
+    t0 = 123
+    cut = fl[t0].bool() & (fl[t0] & _abi.FLAG_LAST).bool()
+    if mode == _abi.SCAN_RETURN and bool(cut.any()):
+        boot = torch.where((fl[t0] & _abi.FLAG_ABSORBING).bool(), torch.zeros_like(vn[t0]), vn[t0])
+        want = ((0.99 * torch.ones((), dtype=torch.float32, device="cuda")) * boot).double() + r[t0].double()
+        assert torch.equal(ret[t0][cut], want.float()[cut])
+
+
 def test_scan_golden_ppo(eng, golden):
     g = golden("ppo_returns.npz")
     L = g["ep_len"]
