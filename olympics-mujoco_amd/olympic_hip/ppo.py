@@ -21,7 +21,6 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 import torch.optim as optim
-from torch.utils.data.sampler import BatchSampler, SubsetRandomSampler
 
 from . import _abi
 from .rollout import PPORollout, RolloutBuffer
@@ -50,7 +49,7 @@ class MLPGaussianActor(torch.nn.Module):
         mu = self._mean(state)
         if deterministic:
             return mu
-        return torch.distributions.Normal(mu, self.fixed_std * anneal).sample()
+        return torch.distributions.Normal(mu, self.fixed_std * anneal, validate_args=False).sample()
 
     def distribution(self, inputs):
         return torch.distributions.Normal(self._mean(inputs), self.fixed_std)
@@ -251,22 +250,24 @@ class PPO:
         buf = RolloutBuffer(T, N, obs_dim, act_dim, dev)
         state = env.reset().to(torch.float32)
         traj_len = torch.zeros(N, dtype=torch.int32, device=dev)
+        value = critic(state).reshape(N)
         for t in range(T):
             action = policy(state, deterministic=deterministic, anneal=anneal)
-            value = critic(state).reshape(N)
             next_state, reward, done, _ = env.step(action)
             next_state = next_state.to(torch.float32)
             buf.store(state, action, reward.to(torch.float32), value)
             traj_len += 1
             done = done.bool()
             cut = done | (traj_len >= max_traj_len) | (t == T - 1)
-            buf.next_values[t] = critic(next_state).reshape(N)
+            next_value = critic(next_state).reshape(N)            # V(s_{t+1}): bootstrap now, value of step t+1 next
+            buf.next_values[t] = next_value
             buf.flags[t] = (cut.to(torch.uint8) * _abi.FLAG_LAST) | (done.to(torch.uint8) * _abi.FLAG_ABSORBING)
             if t < T - 1 and bool(cut.any()):
                 fresh = env.reset(env_mask=cut).to(torch.float32)
                 next_state = torch.where(cut.unsqueeze(1), fresh, next_state)
                 traj_len = torch.where(cut, torch.zeros_like(traj_len), traj_len)
-            state = next_state
+                next_value = critic(next_state).reshape(N)        # reset envs start from a new state
+            state, value = next_state, next_value
         return buf
 
     # ------------------------------------------------------------------ losses
@@ -358,14 +359,24 @@ class PPO:
             minibatch = self.minibatch_size or n
             t1 = time.time()
             stats = []
-            if use_graph and fused and getattr(self, "_graphed", None) is None:
-                self._graphed = GraphedUpdate(self, env.eng, minibatch, observations.shape[1], actions.shape[1],
-                                              obs_mirr, act_src, act_sign)
+            graphed = None
+            if use_graph and fused:
+                # Captured anew for every iteration's update phase (~15 ms).  A graph kept across
+                # iterations was observed on this ROCm / PyTorch build to drift from the eager
+                # update (first-layer bias gradients) once the rollout's eager allocations had run
+                # between replays; back-to-back replays within one update phase reproduce the eager
+                # update (tests/test_gpu_facade.py::test_ppo_train_iterations_on_vec_a3).
+                graphed = GraphedUpdate(self, env.eng, minibatch, observations.shape[1], actions.shape[1],
+                                        obs_mirr, act_src, act_sign)
             for _ in range(self.epochs):
-                for idx in BatchSampler(SubsetRandomSampler(range(n)), minibatch, drop_last=True):
-                    idx = torch.as_tensor(idx, device=observations.device)
-                    if use_graph and fused:
-                        stats.append(self._graphed(observations, actions, returns, advantages, idx).clone())
+                # BatchSampler(SubsetRandomSampler(range(n)), minibatch, drop_last=True) draws ONE
+                # torch.randperm(n) from the default CPU generator and cuts it into consecutive
+                # batches; the same permutation is cut on the device here (no per-index Python loop)
+                perm = torch.randperm(n).to(observations.device)
+                for b in range(n // minibatch):
+                    idx = perm[b * minibatch:(b + 1) * minibatch]
+                    if graphed is not None:
+                        stats.append(graphed(observations, actions, returns, advantages, idx).clone())
                         continue
                     if fused:
                         a_l, ent, c_l, kl, m_l, clipf = self.update_policy_fused(
@@ -390,6 +401,7 @@ class PPO:
                     stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), float(clipf)))
             if stats and torch.is_tensor(stats[0]):
                 stats = torch.stack(stats).cpu().tolist()      # one device->host copy per iteration
+            del graphed
             ep_ret, ep_len = buf.episode_stats()
             mean_ret = float(np.mean(ep_ret)) if ep_ret else 0.0
             self.highest_reward = max(self.highest_reward, mean_ret)

@@ -42,21 +42,18 @@ class RolloutBuffer:
         return self.ptr * self.N
 
     def episode_stats(self):
-        """ep_returns / ep_lens of the segments that END inside the block (logging only)."""
+        """ep_returns / ep_lens of the segments that END inside the block (logging only), in
+        env-major, time-ascending order; computed on the device, one copy back."""
         last = (self.flags & _abi.FLAG_LAST).bool()
         last[-1] = True
-        r = self.rewards.double()
-        csum = torch.cumsum(r, dim=0)
-        ep_returns, ep_lens = [], []
-        lh = last.cpu()
-        ch = csum.cpu()
-        for n in range(self.N):
-            start, base = 0, 0.0
-            for t in torch.nonzero(lh[:, n]).flatten().tolist():
-                ep_returns.append(float(ch[t, n]) - base)
-                ep_lens.append(t + 1 - start)
-                start, base = t + 1, float(ch[t, n])
-        return ep_returns, ep_lens
+        csum = torch.cumsum(self.rewards.double(), dim=0)
+        n_i, t_i = torch.nonzero(last.t(), as_tuple=True)          # sorted by env, then time
+        end = csum[t_i, n_i]
+        same = torch.zeros_like(n_i, dtype=torch.bool)
+        same[1:] = n_i[1:] == n_i[:-1]
+        prev_t = torch.where(same, torch.roll(t_i, 1), torch.full_like(t_i, -1))
+        base = torch.where(same, torch.roll(end, 1), torch.zeros_like(end))
+        return (end - base).cpu().tolist(), (t_i - prev_t).cpu().tolist()
 
 
 class PPORollout:

@@ -118,6 +118,7 @@ def test_ppo_rollout_block(oracle):
     er, el = buf.episode_stats()
     assert len(er) == len(el) == int((ends | (torch.arange(T, device="cuda") == T - 1).unsqueeze(1)).sum())
     assert sum(el) == T * N
+    assert abs(sum(er) - float(buf.rewards.double().sum())) < 1e-9 * T * N
 
 
 def test_collect_with_torch_policy(oracle):
