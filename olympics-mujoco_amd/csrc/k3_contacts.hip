@@ -103,6 +103,62 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
     }
   }
 }
+// IL ground forces: 16 lanes per environment walk the W substeps in order; per substep the
+// first matching contact of every sensor pair is found by ballot + find-first-set over the
+// 16-lane group (slot order == contact order), lanes 0..2 of the group fetch its force[:3].
+__global__ __launch_bounds__(THREADS) void il_grf_kernel(GrfDev gd, int W, int N, int C,
+                                                         const int* __restrict__ ncon,
+                                                         const int* __restrict__ geom1,
+                                                         const int* __restrict__ geom2,
+                                                         const double* __restrict__ force6,
+                                                         double* __restrict__ grf_step,
+                                                         double* __restrict__ grf_mean) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane & (SLOTS - 1);
+  const int grp = lane / SLOTS;
+  const long wave = ((long)blockIdx.x * THREADS + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * THREADS) >> 6;
+  const int passes = (C + SLOTS - 1) / SLOTS;
+  const int ncomp = 3 * gd.n_pairs;
+  for (long base = wave * 4; base < N; base += nwaves * 4) {
+    const long n = base + grp;
+    const bool env_ok = n < N;
+    double acc = 0.0;  // lane `slot` < ncomp accumulates component `slot` of the window sum
+    for (int w = 0; w < W; ++w) {
+      const int nc = env_ok ? min(max(ncon[(size_t)w * N + n], 0), C) : 0;
+      int first[OLY_MAX_GRF_PAIRS];
+#pragma unroll
+      for (int k = 0; k < OLY_MAX_GRF_PAIRS; ++k) first[k] = -1;
+      for (int ps = 0; ps < passes; ++ps) {
+        const int i = ps * SLOTS + slot;
+        int ga = -1, gb = -1;
+        if (env_ok && i < nc) {
+          const size_t e = ((size_t)w * N + n) * C + i;
+          const int g1 = geom1[e], g2 = geom2[e];
+          if (g1 >= 0 && g1 < gd.ngeom) ga = gd.geom_group[g1];
+          if (g2 >= 0 && g2 < gd.ngeom) gb = gd.geom_group[g2];
+        }
+#pragma unroll
+        for (int k = 0; k < OLY_MAX_GRF_PAIRS; ++k) {
+          if (k >= gd.n_pairs) break;
+          const bool hit = ga >= 0 && gb >= 0 &&
+                           ((ga == gd.pair_a[k] && gb == gd.pair_b[k]) || (ga == gd.pair_b[k] && gb == gd.pair_a[k]));
+          const unsigned long long m = (__ballot(hit) >> (grp * SLOTS)) & 0xFFFFull;
+          if (first[k] < 0 && m) first[k] = ps * SLOTS + (__ffsll((long long)m) - 1);
+        }
+      }
+      if (env_ok && slot < ncomp) {
+        const int k = slot / 3, c = slot - 3 * k;
+        double v = 0.0;
+        if (first[k] >= 0) v = force6[(((size_t)w * N + n) * C + first[k]) * 6 + c];
+        if (grf_step) grf_step[((size_t)w * N + n) * ncomp + slot] = v;
+        acc += v;
+      }
+    }
+    if (env_ok && slot < ncomp) grf_mean[(size_t)n * ncomp + slot] = acc / (double)W;
+  }
+}
+
 }  // namespace
 
 extern "C" int oly_contact_configure(oly_ctx* ctx, int ngeom, const int32_t* geom_bodyid_host,
@@ -140,5 +196,41 @@ extern "C" int oly_contact_reduce(oly_ctx* ctx, int N, int C, const int32_t* nco
                      N, C, ncon, geom1, geom2, force6, pos_z, n_r, n_l, idx_r, idx_l, grf_r, grf_l, min_z,
                      bad);
   OLY_LAUNCH_CHECK(ctx, "contact_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_grf_configure(oly_ctx* ctx, int ngeom, const int32_t* geom_group_host, int n_pairs,
+                                 const int32_t* pair_a, const int32_t* pair_b) {
+  if (!ctx) return OLY_EINVAL;
+  ctx->grf_ok = false;
+  if (ngeom <= 0 || !geom_group_host || n_pairs <= 0 || n_pairs > OLY_MAX_GRF_PAIRS || !pair_a || !pair_b)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_grf_configure: bad argument (ngeom=%d n_pairs=%d)", ngeom, n_pairs);
+  OLY_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->grf.geom_group) { (void)hipFree(ctx->grf.geom_group); ctx->grf.geom_group = nullptr; }
+  if (hipMalloc(&ctx->grf.geom_group, sizeof(int) * ngeom) != hipSuccess)
+    OLY_FAIL(ctx, OLY_ENOMEM, "oly_grf_configure: hipMalloc failed");
+  OLY_HIP(ctx, hipMemcpy(ctx->grf.geom_group, geom_group_host, sizeof(int) * ngeom, hipMemcpyHostToDevice));
+  ctx->grf.ngeom = ngeom;
+  ctx->grf.n_pairs = n_pairs;
+  for (int k = 0; k < n_pairs; ++k) { ctx->grf.pair_a[k] = pair_a[k]; ctx->grf.pair_b[k] = pair_b[k]; }
+  ctx->grf_ok = true;
+  return OLY_OK;
+}
+
+extern "C" int oly_il_ground_forces(oly_ctx* ctx, int W, int N, int C, const int32_t* ncon,
+                                    const int32_t* geom1, const int32_t* geom2, const double* force6,
+                                    double* grf_step, double* grf_mean, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->grf_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_il_ground_forces before oly_grf_configure");
+  if (W <= 0 || N < 0 || C <= 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_il_ground_forces: bad W, N or C");
+  if (N == 0) return OLY_OK;
+  if (!ncon || !geom1 || !geom2 || !force6 || !grf_mean)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_il_ground_forces: NULL pointer");
+  long waves = ((long)N + 3) / 4;
+  long blocks = (waves * 64 + THREADS - 1) / THREADS;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(il_grf_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->grf, W, N, C,
+                     ncon, geom1, geom2, force6, grf_step, grf_mean);
+  OLY_LAUNCH_CHECK(ctx, "il_grf_kernel");
   return OLY_OK;
 }

@@ -56,6 +56,7 @@ extern "C" void oly_destroy(oly_ctx* ctx) {
   if (ctx->stats_ws) (void)hipFree(ctx->stats_ws);
   if (ctx->contact.geom_bodyid) (void)hipFree(ctx->contact.geom_bodyid);
   if (ctx->traj.rows) (void)hipFree(ctx->traj.rows);
+  if (ctx->grf.geom_group) (void)hipFree(ctx->grf.geom_group);
   delete ctx;
 }
 

@@ -38,6 +38,12 @@ struct ContactDev {
   int* geom_bodyid;  // device [ngeom]
 };
 
+struct GrfDev {
+  int ngeom, n_pairs;
+  int pair_a[OLY_MAX_GRF_PAIRS], pair_b[OLY_MAX_GRF_PAIRS];
+  int* geom_group;  // device [ngeom]
+};
+
 struct TrajDev {
   int n_keys, n_traj, len, pad;
   double* rows;  // device [n_traj, len, n_keys] (sample-major copy of the reference table)
@@ -58,6 +64,8 @@ struct oly_ctx {
   bool contact_ok;
   TrajDev traj;
   bool traj_ok;
+  GrfDev grf;
+  bool grf_ok;
   double* stats_ws;  // device [OLY_STATS_MAX_BLOCKS * 2 * OLY_MAX_OBS... ] partial sums
   size_t stats_ws_bytes;
   unsigned scan_attr_done = 0;  // dynamic-LDS limit of the pipelined scan kernels raised on this device

@@ -308,6 +308,32 @@ class Engine:
         self.ctx.call("oly_col_stats", B, D, ptr(x), ptr(colstats), int(acc), self._s())
         return colstats
 
+    # -------------------------------------------------------------- K3 (IL ground forces)
+    def grf_configure(self, geom_group, pairs):
+        """geom_group [ngeom] (collision-group index per geom, -1 none); pairs [(group_a, group_b), ...]."""
+        gg = np.ascontiguousarray(geom_group, dtype=np.int32)
+        pa = np.ascontiguousarray([a for a, _ in pairs], dtype=np.int32)
+        pb = np.ascontiguousarray([b for _, b in pairs], dtype=np.int32)
+        self.ctx.call("oly_grf_configure", len(gg), ptr(gg), len(pairs), ptr(pa), ptr(pb))
+        self.n_grf_pairs = len(pairs)
+        return self
+
+    def il_ground_forces(self, ncon, geom1, geom2, force6, want_steps=False):
+        """[W,N,...] substep contact slots -> dict(mean [N,3P], steps [W,N,3P] or None)."""
+        if not getattr(self, "n_grf_pairs", 0):
+            raise OlyError("il_ground_forces before grf_configure")
+        W, N, Cc = (int(v) for v in geom1.shape)
+        _req(ncon, "ncon", (W, N), torch.int32, self.device)
+        _req(geom1, "geom1", (W, N, Cc), torch.int32, self.device)
+        _req(geom2, "geom2", (W, N, Cc), torch.int32, self.device)
+        _req(force6, "force6", (W, N, Cc, 6), torch.float64, self.device)
+        k = 3 * self.n_grf_pairs
+        mean = self._new((N, k), torch.float64)
+        steps = self._new((W, N, k), torch.float64) if want_steps else None
+        self.ctx.call("oly_il_ground_forces", W, N, Cc, ptr(ncon), ptr(geom1), ptr(geom2), ptr(force6), ptr(steps),
+                      ptr(mean), self._s())
+        return dict(mean=mean, steps=steps)
+
     # -------------------------------------------------------------- K8
     def disc_standardize(self, x, mask, mean, std, out=None):
         B, Dx = int(x.shape[0]), int(x.shape[1])

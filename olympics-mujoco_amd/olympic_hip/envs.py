@@ -107,18 +107,31 @@ class KinematicPhysics:
     def step(self, ctrl):
         return self.qpos, self.qvel
 
+    def substep_contacts(self):
+        """use_foot_forces: dict(ncon [W,N], geom1/geom2 [W,N,C], force6 [W,N,C,6]) of the W
+        intermediate steps of the control step just taken, or None (no contacts: zeros)."""
+        return None
+
 
 class ReplayPhysics(KinematicPhysics):
-    """Replays pre-generated [T,N,nq]/[T,N,nv] device blocks, one row per step()."""
+    """Replays pre-generated [T,N,nq]/[T,N,nv] device blocks, one row per step();
+    `contacts` = dict of [T,W,N,...] blocks replays the per-substep contact readback too."""
 
-    def __init__(self, spec, qpos_block, qvel_block):
+    def __init__(self, spec, qpos_block, qvel_block, contacts=None):
         super().__init__(spec, qpos_block.shape[1], qpos_block.device)
         self.qb, self.vb, self.t = qpos_block, qvel_block, 0
+        self.cb, self._last = contacts, None
 
     def step(self, ctrl):
         self.qpos, self.qvel = self.qb[self.t], self.vb[self.t]
+        self._last = self.t
         self.t = (self.t + 1) % self.qb.shape[0]
         return self.qpos, self.qvel
+
+    def substep_contacts(self):
+        if self.cb is None or self._last is None:
+            return None
+        return {k: v[self._last] for k, v in self.cb.items()}
 
 
 # ------------------------------------------------------------------------------ vec env
@@ -135,6 +148,8 @@ class VecLocoEnv:
         self.num_envs = int(num_envs)
         self.eng = engine or Engine(device)
         self.eng.il_configure(spec)
+        if spec.n_grf:
+            self.eng.grf_configure(spec.geom_group, spec.grf_pairs)
         self.device = self.eng.device
         self.obs_f64 = obs_f64
         self.physics = physics or KinematicPhysics(spec, self.num_envs, self.device)
@@ -162,12 +177,12 @@ class VecLocoEnv:
     def _obs_low(self):
         lo = np.concatenate([self.spec.joint_lo, -np.inf * np.ones(self.spec.n_vel)])
         lo[:6] = -np.inf                       # pelvis joints are limited="false" (h1.xml:88-93)
-        return lo[self.spec.n_drop:]
+        return np.concatenate([lo[self.spec.n_drop:], -np.inf * np.ones(self.spec.n_grf)])   # grf: :727-728
 
     def _obs_high(self):
         hi = np.concatenate([self.spec.joint_hi, np.inf * np.ones(self.spec.n_vel)])
         hi[:6] = np.inf
-        return hi[self.spec.n_drop:]
+        return np.concatenate([hi[self.spec.n_drop:], np.inf * np.ones(self.spec.n_grf)])
 
     @property
     def dt(self):
@@ -184,12 +199,22 @@ class VecLocoEnv:
         qvel[:, self._vadr] = sample[:, sp.n_pos:sp.n_pos + sp.n_vel]
         self.physics.set_state(qpos, qvel, env_mask)
 
-    def _observe(self, action=None):
+    def _observe(self, action=None, fresh=False):
         """Post-physics half of step(): one oly_il_step over [1,N]."""
         o = self.eng.il_step(self.physics.qpos.unsqueeze(0).contiguous(), self.physics.qvel.unsqueeze(0).contiguous(),
                              None if action is None else action.unsqueeze(0).contiguous(), self._prev,
-                             obs_f64=self.obs_f64, ctrl_f64=False)
+                             grf_mean=self._grf_mean(fresh), obs_f64=self.obs_f64, ctrl_f64=False)
         return o
+
+    def _grf_mean(self, fresh):
+        """mean_grf.mean of the control step (loco_env_base.py:1072-1084); zeros right after a
+        reset (mean_grf.reset(), :584) and when the physics reports no contacts."""
+        if not self.spec.n_grf:
+            return None
+        c = None if fresh else self.physics.substep_contacts()
+        if c is None:
+            return torch.zeros((1, self.num_envs, self.spec.n_grf), dtype=torch.float64, device=self.device)
+        return self.eng.il_ground_forces(c["ncon"], c["geom1"], c["geom2"], c["force6"])["mean"].unsqueeze(0)
 
     # ----- reset (loco_env_base.py:568-657)
     def reset(self, env_mask=None, obs=None):
@@ -228,7 +253,7 @@ class VecLocoEnv:
             self.set_sim_state(self._sample, env_mask)
         # self._obs = _create_observation(_build_obs(data)); the reward's "previous obs" is this one
         prev_keep = self._prev.clone()
-        o = self._observe()
+        o = self._observe(fresh=True)
         new_prev = o["prev"]
         if env_mask is not None:
             new_prev = torch.where(env_mask, new_prev, prev_keep)
@@ -246,7 +271,7 @@ class VecLocoEnv:
         if getattr(self.physics, "needs_ctrl", False):      # un-normalised, clamped, actuator-ordered
             pre = self.eng.il_step(self.physics.qpos.unsqueeze(0).contiguous(),
                                    self.physics.qvel.unsqueeze(0).contiguous(), actions.unsqueeze(0),
-                                   self._prev.clone(), want_fall_code=False)
+                                   self._prev.clone(), grf_mean=self._grf_mean(True), want_fall_code=False)
             ctrl = pre["ctrl"][0]
         self.physics.step(ctrl)
         o = self._observe(actions)
@@ -396,12 +421,12 @@ class UnitreeH1(LocoEnvBase):
     def __init__(self, task="walk", disable_arms=True, disable_back_joint=None, use_foot_forces=False,
                  use_absorbing_states=True, random_start=True, init_step_no=None, reward_type="target_velocity",
                  num_envs=1, device=0, traj_params=None, physics=None, seed=None, **unused):
-        if use_foot_forces:
-            raise NotImplementedError("use_foot_forces=True needs the host contact batcher (next-row f1)")
         if disable_back_joint is None:
             disable_back_joint = self._default_back
         self.spec = self._spec_fn(task, disable_arms=disable_arms, disable_back_joint=disable_back_joint,
                                   use_absorbing_states=use_absorbing_states, reward_type=reward_type)
+        if use_foot_forces:                      # the physics object supplies substep_contacts()
+            self.spec.with_foot_forces(type(self).__name__)
         traj = None
         if traj_params:
             traj = self.load_trajectory(traj_params)

@@ -44,3 +44,19 @@ def tables_from_mjcf(xml_path, removed_joints=(), removed_motors=()):
         cr = tuple(float(v) for v in m.get("ctrlrange").split()) if m.get("ctrlrange") else default_ctrl
         motors.append((m.get("name"), m.get("joint"), float((m.get("gear") or "1").split()[0]), cr[0], cr[1]))
     return dict(joints=joints, motors=motors, nq=qadr, nv=vadr)
+
+
+def geoms_from_mjcf(xml_path):
+    """Geom names (None if unnamed) in compiled geom-id order: bodies are numbered depth-first
+    in document order (world = 0) and a body's own geoms come before those of later bodies."""
+    root = ET.parse(xml_path).getroot()
+    bodies = []
+
+    def walk(body):
+        bodies.append(body)
+        for el in body:
+            if el.tag == "body":
+                walk(el)
+
+    walk(root.find("worldbody"))
+    return [g.get("name") for b in bodies for g in b if g.tag == "geom"]

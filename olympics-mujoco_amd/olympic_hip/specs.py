@@ -92,7 +92,25 @@ class ILRobotSpec:
     reward_type: int = _abi.REWARD_TARGET_VELOCITY
     target_velocity: float = 1.25
     use_absorbing_states: bool = True
+    geom_group: Optional[np.ndarray] = None     # collision-group index per geom id (use_foot_forces)
+    grf_pairs: Optional[list] = None            # [(group_a, group_b)] sensor pairs, 3 columns each
     _keep: list = field(default_factory=list, repr=False)
+
+    def with_foot_forces(self, robot_name):
+        """use_foot_forces=True (loco_env_base.py:119-124,750-757): appends mean_grf / 1000 columns
+        (3 per sensor pair) and switches to n_substeps = 1, n_intermediate_steps = 10."""
+        from .robot_data import ROBOTS
+        d = ROBOTS[robot_name]
+        if d.get("grf_pairs") is None:
+            raise NotImplementedError(f"{robot_name}: the reference's ground-force vector and its declared size "
+                                      "disagree (atlas.py:336-342); use_foot_forces is unusable there")
+        gi = {g: i for i, (g, _) in enumerate(d["collision_groups"])}
+        gg = np.full(d["n_geom"], -1, np.int32)
+        for g, ids in d["collision_groups"]:
+            gg[ids] = gi[g]
+        self.geom_group, self.grf_pairs = gg, [(gi[a], gi[b]) for a, b in d["grf_pairs"]]
+        self.n_grf = 3 * len(self.grf_pairs)
+        return self
 
     @property
     def n_obs(self) -> int:

@@ -74,6 +74,10 @@ int oly_disc_reparam_cpu(int64_t n, const float* mu, const float* logvar, const 
                          float* z);
 int oly_disc_reward_cpu(int64_t B, const float* logits, float* reward);
 
+int oly_il_ground_forces_cpu(int ngeom, const int32_t* geom_group, int n_pairs, const int32_t* pair_a,
+                             const int32_t* pair_b, int W, int N, int C, const int32_t* ncon,
+                             const int32_t* geom1, const int32_t* geom2, const double* force6,
+                             double* grf_step, double* grf_mean);
 int oly_obs_filter_cpu(int B, int D, const float* x, const double* mean, const double* var,
                        double eps, double clip, float* out);
 int oly_signed_perm_cpu(int B, int D, const float* x, const int32_t* src, const float* sign,

@@ -294,3 +294,17 @@ def ppo_loss(mu, std, old_mu, old_std, action, adv, ret, value, clip, vf_coeff=0
                                 _p(ret), _p(value), C.c_float(clip), C.c_float(vf_coeff), _p(scal), _p(gmu),
                                 _p(gsd), _p(gv)), "ppo_loss")
     return scal, gmu, gsd, gv
+
+
+def il_ground_forces(geom_group, pairs, ncon, geom1, geom2, force6):
+    """-> (grf_step [W,N,3P], grf_mean [N,3P])."""
+    gg = _c(geom_group, np.int32)
+    pa = _c([a for a, _ in pairs], np.int32)
+    pb = _c([b for _, b in pairs], np.int32)
+    ncon, geom1, geom2, force6 = _c(ncon, np.int32), _c(geom1, np.int32), _c(geom2, np.int32), _c(force6, np.float64)
+    W, N, Cc = geom1.shape
+    step = np.zeros((W, N, 3 * len(pairs)))
+    mean = np.zeros((N, 3 * len(pairs)))
+    _chk(lib().oly_il_ground_forces_cpu(len(gg), _p(gg), len(pairs), _p(pa), _p(pb), W, N, Cc, _p(ncon), _p(geom1),
+                                        _p(geom2), _p(force6), _p(step), _p(mean)), "il_ground_forces")
+    return step, mean

@@ -798,3 +798,56 @@ def test_obs_filter_and_device_running_mean_std(eng, oracle, golden):
     m, v = big.mean(0, dtype=np.float64), big.var(0, dtype=np.float64)
     o = eng.obs_filter(dev(big), dev(m), dev(v), 1e-8, 10.0)
     assert np.array_equal(host(o), oracle.obs_filter(big, m, v, 1e-8, 10.0))
+
+
+# ------------------------------------------------------------------------------ K3: IL ground forces
+@pytest.mark.parametrize("W,N,C", [(1, 1, 16), (10, 4097, 16), (10, 33, 40), (3, 1000, 5)])
+def test_il_ground_forces_vs_oracle(eng, oracle, W, N, C):
+    """First matching contact per sensor pair (either geom order), force[:3], in-order window mean:
+    selections are index work (bit-exact), the mean is W in-order adds and one divide (bit-exact)."""
+    rng = np.random.default_rng(W + N + C)
+    ngeom = 30
+    gg = np.full(ngeom, -1, np.int32)
+    gg[0], gg[[7, 8]], gg[[20]], gg[[21]], gg[[22]] = 0, 1, 2, 3, 4
+    pairs = [(0, 1), (0, 2), (0, 3), (0, 4)][:1 + (N % 4)]
+    ncon = rng.integers(0, C + 3, (W, N)).astype(np.int32)            # also > C: clamped
+    g1 = np.where(rng.uniform(size=(W, N, C)) < 0.5, 0, rng.integers(-1, ngeom + 1, (W, N, C))).astype(np.int32)
+    g2 = rng.choice([0, 7, 8, 20, 21, 22, 3, 29, -1, ngeom], size=(W, N, C)).astype(np.int32)
+    swap = rng.uniform(size=(W, N, C)) < 0.3
+    g1, g2 = np.where(swap, g2, g1).astype(np.int32), np.where(swap, g1, g2).astype(np.int32)
+    f6 = rng.normal(0, 200, (W, N, C, 6))
+    eng.grf_configure(gg, pairs)
+    o = eng.il_ground_forces(dev(ncon), dev(g1), dev(g2), dev(f6), want_steps=True)
+    e_step, e_mean = oracle.il_ground_forces(gg, pairs, ncon, g1, g2, f6)
+    assert np.array_equal(host(o["steps"]), e_step)
+    assert np.array_equal(host(o["mean"]), e_mean)
+    assert (e_step != 0).any() or N == 1
+
+
+def test_h1_env_with_foot_forces(eng, oracle):
+    """UnitreeH1(use_foot_forces=True): obs = [joint obs, mean_grf / 1000] with the window mean of
+    the control step's substep contacts; zeros right after reset."""
+    from olympic_hip.envs import ReplayPhysics, VecLocoEnv
+    sp = specs.unitree_h1("walk").with_foot_forces("UnitreeH1")
+    assert sp.n_grf == 6 and sp.n_obs == 38 and sp.geom_group[0] == 0 and sp.geom_group[22] == 1 and sp.geom_group[12] == 2
+    T, N, W, C = 5, 256, 10, 16
+    qpos, qvel, act = h1_synthetic_block(sp, T, N, seed=3, fall_frac="wide")
+    rng = np.random.default_rng(4)
+    con = dict(ncon=rng.integers(0, 6, (T, W, N)).astype(np.int32),
+               geom1=np.zeros((T, W, N, C), np.int32),
+               geom2=rng.choice([12, 22, 5, 30], size=(T, W, N, C)).astype(np.int32),
+               force6=rng.normal(0, 300, (T, W, N, C, 6)))
+    phys = ReplayPhysics(sp, dev(qpos), dev(qvel), contacts={k: dev(v) for k, v in con.items()})
+    env = VecLocoEnv(sp, N, engine=eng, physics=phys, random_start=False)
+    first = env.reset()
+    assert first.shape == (N, 38) and not host(first)[:, 32:].any()           # mean_grf.reset()
+    means = np.stack([oracle.il_ground_forces(sp.geom_group, sp.grf_pairs, con["ncon"][t], con["geom1"][t],
+                                              con["geom2"][t], con["force6"][t])[1] for t in range(T)])
+    ref = oracle.il_step(sp, qpos, qvel, act, host(env._prev), grf_mean=means)
+    for t in range(T):
+        o, r, a, _ = env.step(dev(act[t]))
+        assert np.array_equal(host(o), ref["obs"][t])
+        assert np.array_equal(host(o)[:, 32:], (means[t] / 1000.0).astype(np.float32))
+        assert np.array_equal(host(a), ref["absorbing"][t].astype(bool))
+    with pytest.raises(NotImplementedError):
+        specs.atlas("walk").with_foot_forces("Atlas")

@@ -397,3 +397,35 @@ def test_obs_filter_and_running_mean_std(golden, oracle):
         assert count == pytest.approx(float(g["count"][i]))
         o = oracle.obs_filter(xb, mean, var, eps, clip)
         np.testing.assert_allclose(o, g["out"][off[i]:off[i + 1]], rtol=2e-5, atol=2e-6)
+
+
+def test_il_ground_forces_hand_cases(oracle):
+    """No reference oracle exists for _get_collision_force / RunningAveragedWindow (mushroom-rl,
+    absent: parity unpinned); pinned to hand-derived cases of the restated definition."""
+    gg = np.array([0, -1, 1, 1, 2], np.int32)                     # floor, -, foot_r x2, foot_l
+    pairs = [(0, 1), (0, 2)]
+    f = np.zeros((2, 1, 4, 6))
+    f[0, 0] = [[1, 2, 3, 9, 9, 9], [4, 5, 6, 9, 9, 9], [7, 8, 9, 9, 9, 9], [10, 11, 12, 9, 9, 9]]
+    f[1, 0] = 10 * f[0, 0]
+    g1 = np.array([[[1, 0, 3, 0]], [[4, 2, 0, 0]]], np.int32)
+    g2 = np.array([[[2, 2, 0, 4]], [[0, 0, 3, 4]]], np.int32)
+    ncon = np.array([[4], [3]], np.int32)
+    step, mean = oracle.il_ground_forces(gg, pairs, ncon, g1, g2, f)
+    # substep 0: contact 0 has an ungrouped geom; contact 1 = (floor, foot_r); contact 2 = (foot_r, floor)
+    # comes later; contact 3 = (floor, foot_l)
+    assert step[0, 0].tolist() == [4, 5, 6, 10, 11, 12]
+    # substep 1: contact 0 = (foot_l, floor) reversed order counts; contact 1 = (foot_r, floor); the 4th is beyond ncon
+    assert step[1, 0].tolist() == [40, 50, 60, 10, 20, 30]
+    assert mean[0].tolist() == [22, 27.5, 33, 10, 15.5, 21]
+    step0, mean0 = oracle.il_ground_forces(gg, pairs, np.zeros((2, 1), np.int32), g1, g2, f)
+    assert not step0.any() and not mean0.any()
+
+
+def test_robot_geom_tables():
+    from olympic_hip.robot_data import ROBOTS
+    h1 = ROBOTS["UnitreeH1"]
+    assert dict(h1["collision_groups"]) == {"floor": [0], "foot_r": [22], "foot_l": [12]} and h1["n_geom"] == 42
+    assert h1["grf_pairs"] == [("floor", "foot_r"), ("floor", "foot_l")]
+    assert ROBOTS["Atlas"]["grf_pairs"] is None and len(ROBOTS["Talos"]["grf_pairs"]) == 2
+    sp = specs.unitree_h1("walk").with_foot_forces("UnitreeH1")
+    assert sp.grf_pairs == [(0, 1), (0, 2)] and sp.n_obs == 38
