@@ -136,3 +136,86 @@ class GAILAdvantage:
         buf.ptr = T
         v_target, adv = self.post.finish(buf, normalize=True)
         return r, v_target, adv
+
+
+# ------------------------------------------------------------------------------ discriminator fitting
+def logit_bernoulli_entropy(logits):
+    """(1 - sigmoid(x)) * x - logsigmoid(x)   imitation_lib/utils/math.py:34-39."""
+    return (1.0 - torch.sigmoid(logits)) * logits - torch.nn.functional.logsigmoid(logits)
+
+
+def gail_discriminator_loss(logits, target, entcoeff=1e-3):
+    """GailDiscriminatorLoss.forward (imitation_lib/utils/math.py:24-32):
+    mean(max(x,0) - x*z + log(1 + exp(-|x|))) - entcoeff * mean(bernoulli entropy)."""
+    bce = torch.maximum(logits, torch.zeros_like(logits)) - logits * target + torch.log(1 + torch.exp(-torch.abs(logits)))
+    return torch.mean(bce) - entcoeff * torch.mean(logit_bernoulli_entropy(logits))
+
+
+class VDBLoss:
+    """Variational-discriminator-bottleneck loss with the dual variable beta updated on every
+    call (imitation_lib/utils/math.py:42-90): bce + beta * (mean KL - I_c) [+ entropy]."""
+
+    def __init__(self, info_constraint, lr_beta, use_bernoulli_ent=False, entcoeff=1e-3):
+        self._info_constr, self._lr_beta = info_constraint, lr_beta
+        self._use_bernoulli_ent, self.entcoeff = use_bernoulli_ent, entcoeff
+        self._beta = 0.1
+
+    @staticmethod
+    def kl_divergence(mu, logvar):
+        return 0.5 * torch.sum(torch.pow(mu, 2) + torch.exp(logvar) - logvar - 1, dim=1)
+
+    def __call__(self, inputs, target):
+        logits, mu, logvar = inputs
+        bottleneck = self.kl_divergence(mu, logvar).mean() - self._info_constr
+        bce = torch.nn.functional.binary_cross_entropy_with_logits(torch.squeeze(logits), torch.squeeze(target))
+        ent = logit_bernoulli_entropy(logits) if self._use_bernoulli_ent else torch.zeros_like(bce)
+        loss = bce + self._beta * bottleneck + ent
+        with torch.no_grad():                                   # dual ascent, clipped at 0 (:80-82)
+            self._beta = max(0, self._beta + self._lr_beta * bottleneck)
+        return loss
+
+
+class DiscriminatorTrainer:
+    """The discriminator half of GAIL._fit_discriminator (gail_TRPO.py:167-218), states-only
+    input as in the UnitreeH1 configuration: per epoch draw as many demonstration states as
+    policy states, update the standardiser with the concatenated batch, targets 0 (policy) / 1
+    (demonstrations) or the noisy variants, one optimiser step.  Random numbers (minibatch
+    indices, noisy targets, VAIL eps) come from the caller's torch.Generator.
+
+    mushroom's TorchApproximator.fit (absent) drives the optimiser in the reference; one Adam
+    step per epoch on the whole concatenated batch is this class's stated reading of it."""
+
+    def __init__(self, reward: "DiscriminatorReward", demo_states, loss, lr=5e-5, weight_decay=1e-3,
+                 n_epochs=1, use_noisy_targets=False, variational=True):
+        self.r, self.loss, self.n_epochs = reward, loss, n_epochs
+        dev = reward.eng.device
+        self.demo = torch.as_tensor(np.asarray(demo_states), dtype=torch.float32, device=dev)
+        self.noisy, self.variational = use_noisy_targets, variational
+        self.opt = torch.optim.Adam(reward.net.parameters(), lr=lr, weight_decay=weight_decay)
+
+    def fit(self, plcy_obs, generator=None):
+        r, dev = self.r, self.r.eng.device
+        n = plcy_obs.shape[0]
+        losses = []
+        for _ in range(self.n_epochs):
+            idx = torch.randint(0, self.demo.shape[0], (n,), device=dev, generator=generator)
+            x = torch.cat([plcy_obs.to(torch.float32), self.demo[idx]]).contiguous()
+            xs = r.stand.forward(x, r.mask)                      # updates the running statistics
+            if self.noisy:
+                demo_t = torch.empty((n, 1), device=dev).uniform_(0.80, 0.99, generator=generator)
+                plcy_t = torch.empty((n, 1), device=dev).uniform_(0.01, 0.10, generator=generator)
+            else:
+                plcy_t, demo_t = torch.zeros((n, 1), device=dev), torch.ones((n, 1), device=dev)
+            target = torch.cat([plcy_t, demo_t])
+            mu, logvar = r.net.encode(xs)
+            if self.variational:
+                eps = torch.randn(mu.shape, device=dev, generator=generator)
+                z = mu + torch.exp(logvar / 2) * eps
+                loss = self.loss((r.net.decoder(z), mu, logvar), target)
+            else:
+                loss = self.loss(r.net.decoder(mu), target)
+            self.opt.zero_grad()
+            loss.backward()
+            self.opt.step()
+            losses.append(float(loss.detach()))
+        return losses

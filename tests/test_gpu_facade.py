@@ -480,3 +480,27 @@ def test_normalize_wrapper_on_vec_env():
     cnt = env.ob_rms.count
     env.step(cu(act[0]))
     assert env.ob_rms.count == cnt
+
+
+def test_discriminator_trainer_separates_demo_from_policy():
+    """GAIL._fit_discriminator on the device: after a few hundred steps the VAIL reward of
+    demonstration-like states exceeds that of policy-like states, and beta stays >= 0."""
+    from olympic_hip.engine import Engine
+    from olympic_hip.gail import DiscriminatorReward, DiscriminatorTrainer, VariationalDiscriminator, VDBLoss
+    eng = Engine(0)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    torch.manual_seed(0)
+    demo = torch.empty((4000, 32), device="cuda").normal_(0.5, 1.0, generator=gen)
+    plcy = lambda n: torch.empty((n, 32), device="cuda").normal_(-0.5, 1.0, generator=gen)
+    net = VariationalDiscriminator(32).cuda()
+    rew = DiscriminatorReward(eng, net, state_mask=np.arange(32))
+    loss = VDBLoss(info_constraint=0.5, lr_beta=1e-5)
+    tr = DiscriminatorTrainer(rew, demo.cpu().numpy(), loss, lr=1e-3, n_epochs=1)
+    first = tr.fit(plcy(1000), gen)[0]
+    for _ in range(150):
+        last = tr.fit(plcy(1000), gen)[0]
+    assert np.isfinite([first, last]).all() and last < first and loss._beta >= 0
+    r_demo = rew(demo[:1000].contiguous(), generator=gen).mean().item()
+    r_plcy = rew(plcy(1000), generator=gen).mean().item()
+    assert r_demo > r_plcy
+    assert float(rew.stand.colstats[0, 0]) == 151 * 2000 + 2 * 1000      # standardiser saw every forward

@@ -382,3 +382,15 @@ def test_oracle_golden_suite_under_asan_ubsan():
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+# ------------------------------------------------------------------------------ discriminator losses
+def test_discriminator_losses_match_reference(golden):
+    """GailDiscriminatorLoss / VDBLoss (imitation_lib/utils/math.py) on the reference's own logits."""
+    from olympic_hip.gail import VDBLoss, gail_discriminator_loss
+    g = golden("vail_disc.npz")
+    t = lambda k: torch.tensor(g[k])
+    np.testing.assert_allclose(float(gail_discriminator_loss(t("d"), t("target"))), float(g["gail_loss"]), rtol=2e-6)
+    vl = VDBLoss(info_constraint=0.1, lr_beta=1e-5)
+    np.testing.assert_allclose(float(vl((t("d"), t("mu"), t("logvar")), t("target"))), float(g["vdb_loss"]), rtol=2e-6)
+    np.testing.assert_allclose(float(vl._beta), float(g["vdb_beta_after"]), rtol=1e-6)
