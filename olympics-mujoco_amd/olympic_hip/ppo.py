@@ -376,6 +376,10 @@ class PPO:
                 for b in range(n // minibatch):
                     idx = perm[b * minibatch:(b + 1) * minibatch]
                     if graphed is not None:
+                        every = getattr(self, "graph_recapture_every", None)     # test hook: fresh graph every k replays
+                        if every and len(stats) and len(stats) % every == 0:
+                            graphed = GraphedUpdate(self, env.eng, minibatch, observations.shape[1], actions.shape[1],
+                                                    obs_mirr, act_src, act_sign)
                         stats.append(graphed(observations, actions, returns, advantages, idx).clone())
                         continue
                     if fused:

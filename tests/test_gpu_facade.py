@@ -233,8 +233,9 @@ def test_vec_a3_env_replays_golden_sequence(golden):
         np.testing.assert_allclose(host(rew6), g["rew6"][:, k], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("mode", ["torch_losses", "fused", "fused_graph"])
-def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode):
+@pytest.mark.parametrize("minibatch,n_itr", [(2048, 2), (256, 2)])
+@pytest.mark.parametrize("mode", ["torch_losses", "fused", "fused_graph", "fused_graph_fresh"])
+def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr):
     """Config 3 end to end: VecA3Env (synthetic physics readback) -> PPO.train: rollout,
     return scan + adv-norm on the device, clipped-surrogate updates in PyTorch."""
     from olympic_hip.a3 import ReplayA3Physics, VecA3Env
@@ -274,24 +275,32 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode):
             else:
                 self.state["phase"][env_mask] = 0
             return torch.zeros((N, 41), device="cuda")
-    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=2048, epochs=2,
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=minibatch, epochs=2,
                 max_traj_len=16, use_gae=False, num_procs=N, max_grad_norm=0.05, mirror_coeff=0.0, eval_freq=100)
     ppo = PPO(args, str(tmp_path))
-    ppo.fused_loss, ppo.use_graph = mode != "torch_losses", mode == "fused_graph"
+    ppo.fused_loss, ppo.use_graph = mode != "torch_losses", mode.startswith("fused_graph")
+    if mode == "fused_graph_fresh":
+        ppo.graph_recapture_every = 1            # every update runs as the FIRST replay of a new capture
     torch.manual_seed(0)
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
     w0 = pi.means.weight.detach().clone()
-    hist = ppo.train(Env, pi, vf, n_itr=2, verbose=False)
-    assert len(hist) == 2 and all(np.isfinite(h["losses"]).all() for h in hist)
+    hist = ppo.train(Env, pi, vf, n_itr=n_itr, verbose=False)
+    assert len(hist) == n_itr and all(np.isfinite(h["losses"]).all() for h in hist)
     assert not torch.equal(w0, pi.means.weight)                      # the optimiser stepped
-    assert ppo.total_steps == 2 * 16 * N
+    assert ppo.total_steps == n_itr * 16 * N
     lines = open(ppo.train_fn).read().strip().splitlines()
-    assert lines[0] == "ep_returns,ep_lens" and len(lines) == 3
-    # the three update paths are the same algorithm: same seed -> same trained weights (fp32 rounding)
-    _TRAINED[mode] = torch.cat([p.detach().reshape(-1) for p in list(pi.parameters()) + list(vf.parameters())]).cpu()
-    if "torch_losses" in _TRAINED and mode != "torch_losses":
-        a, b = _TRAINED["torch_losses"], _TRAINED[mode]
+    assert lines[0] == "ep_returns,ep_lens" and len(lines) == n_itr + 1
+    # the update paths are the same algorithm: same seed -> same trained weights.  Across
+    # implementations that holds to fp32 rounding for a few updates (16 at minibatch 2048; Adam
+    # amplifies rounding noise over longer runs, so no bound is asserted at 128 updates).  A graph
+    # replayed many times against one re-captured before every update runs the SAME kernels, so
+    # those two must agree bit for bit: that is the check that replays do not go stale.
+    _TRAINED[mode, minibatch] = torch.cat([p.detach().reshape(-1) for p in list(pi.parameters()) + list(vf.parameters())]).cpu()
+    if ("torch_losses", minibatch) in _TRAINED and mode != "torch_losses" and minibatch == 2048:
+        a, b = _TRAINED["torch_losses", minibatch], _TRAINED[mode, minibatch]
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    if mode == "fused_graph_fresh":
+        assert torch.equal(_TRAINED["fused_graph", minibatch], _TRAINED["fused_graph_fresh", minibatch])
 
 
 _TRAINED = {}
