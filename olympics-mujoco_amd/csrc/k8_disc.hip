@@ -26,6 +26,58 @@ __global__ __launch_bounds__(THREADS) void standardize_kernel(int B, int Dx, int
   }
 }
 
+// Row-major [B,D] with D % 4 == 0 and 16-B aligned rows: one float4 per lane, the column of a
+// chunk is a 32-bit modulo of the chunk index (no 64-bit division per element).
+__global__ __launch_bounds__(THREADS) void standardize4_kernel(long total4, int D4,
+                                                               const float4* __restrict__ x,
+                                                               const double* __restrict__ mean,
+                                                               const double* __restrict__ sd,
+                                                               float4* __restrict__ out) {
+  const long stride = (long)gridDim.x * THREADS;
+  long e = (long)blockIdx.x * THREADS + threadIdx.x;
+  if (e >= total4) return;
+  int c4 = (int)(e % D4);
+  const int step = (int)(stride % D4);
+  for (; e < total4; e += stride) {
+    const float4 v = x[e];
+    const int j = 4 * c4;
+    float4 o;
+    o.x = (float)(((double)v.x - mean[j]) / sd[j]);
+    o.y = (float)(((double)v.y - mean[j + 1]) / sd[j + 1]);
+    o.z = (float)(((double)v.z - mean[j + 2]) / sd[j + 2]);
+    o.w = (float)(((double)v.w - mean[j + 3]) / sd[j + 3]);
+    out[e] = o;
+    c4 += step;
+    if (c4 >= D4) c4 -= D4;
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void obs_filter4_kernel(long total4, int D4, const float4* __restrict__ x,
+                                                              const double* __restrict__ mean,
+                                                              const double* __restrict__ var, double eps,
+                                                              double clip, float4* __restrict__ out) {
+  const long stride = (long)gridDim.x * THREADS;
+  long e = (long)blockIdx.x * THREADS + threadIdx.x;
+  if (e >= total4) return;
+  int c4 = (int)(e % D4);
+  const int step = (int)(stride % D4);
+  for (; e < total4; e += stride) {
+    const float4 v = x[e];
+    const int j = 4 * c4;
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double t = ((double)in[k] - mean[j + k]) / sqrt(var[j + k] + eps);
+      if (clip > 0.0) t = fmin(fmax(t, -clip), clip);
+      o[k] = (float)t;
+    }
+    out[e] = make_float4(o[0], o[1], o[2], o[3]);
+    c4 += step;
+    if (c4 >= D4) c4 -= D4;
+  }
+}
+
 // Normalize._obfilt (rl/envs/normalize.py:139-147): clip((obs - mean) / sqrt(var + eps), -c, c)
 __global__ __launch_bounds__(THREADS) void obs_filter_kernel(long total, int D,
                                                              const float* __restrict__ x,
@@ -76,6 +128,13 @@ extern "C" int oly_disc_standardize(oly_ctx* ctx, int B, int Dx, int D, const fl
   if (B < 0 || Dx <= 0 || D <= 0 || (!mask && D != Dx) || !mean || !sd || (B > 0 && (!x || !out)))
     OLY_FAIL(ctx, OLY_EINVAL, "oly_disc_standardize: bad argument");
   if (B == 0) return OLY_OK;
+  if (!mask && (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const long total4 = (long)B * (D / 4);
+    hipLaunchKernelGGL(standardize4_kernel, dim3(blocks_for(total4)), dim3(THREADS), 0, oly_s(stream), total4, D / 4,
+                       reinterpret_cast<const float4*>(x), mean, sd, reinterpret_cast<float4*>(out));
+    OLY_LAUNCH_CHECK(ctx, "standardize4_kernel");
+    return OLY_OK;
+  }
   hipLaunchKernelGGL(standardize_kernel, dim3(blocks_for((long)B * D)), dim3(THREADS), 0, oly_s(stream),
                      B, Dx, D, x, mask, mean, sd, out);
   OLY_LAUNCH_CHECK(ctx, "standardize_kernel");
@@ -89,6 +148,13 @@ extern "C" int oly_obs_filter(oly_ctx* ctx, int B, int D, const float* x, const 
   if (B < 0 || D <= 0 || !mean || !var || (B > 0 && (!x || !out)))
     OLY_FAIL(ctx, OLY_EINVAL, "oly_obs_filter: bad argument");
   if (B == 0) return OLY_OK;
+  if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const long total4 = (long)B * (D / 4);
+    hipLaunchKernelGGL(obs_filter4_kernel, dim3(blocks_for(total4)), dim3(THREADS), 0, oly_s(stream), total4, D / 4,
+                       reinterpret_cast<const float4*>(x), mean, var, eps, clip, reinterpret_cast<float4*>(out));
+    OLY_LAUNCH_CHECK(ctx, "obs_filter4_kernel");
+    return OLY_OK;
+  }
   hipLaunchKernelGGL(obs_filter_kernel, dim3(blocks_for((long)B * D)), dim3(THREADS), 0, oly_s(stream),
                      (long)B * D, D, x, mean, var, eps, clip, out);
   OLY_LAUNCH_CHECK(ctx, "obs_filter_kernel");

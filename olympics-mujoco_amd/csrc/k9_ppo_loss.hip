@@ -128,15 +128,22 @@ __global__ __launch_bounds__(THREADS) void ppo_loss_kernel(PpoArgs p, int RB) {
     if (r < rows) {
       const long row = row0 + r;
       float lp = 0.0f, olp = 0.0f, ent = 0.0f;
+      // a scalar std is the same value in every element: its log and 2*var are taken once (same
+      // numbers torch computes elementwise on the broadcast tensor)
+      const bool sc = p.sd_mode == OLY_STD_SCALAR, osc = p.old_sd_mode == OLY_STD_SCALAR;
+      const float sd0 = sc ? p.sd[0] : 1.0f, osd0 = osc ? p.old_sd[0] : 1.0f;
+      const float lsd0 = logf(sd0), losd0 = logf(osd0), v20 = 2.0f * (sd0 * sd0), ov20 = 2.0f * (osd0 * osd0);
       for (int j = 0; j < A; ++j) {
         const float a = s_act[r * AS + j];
-        const float sd = sd_at(p.sd, p.sd_mode, row, A, j);
-        const float osd = sd_at(p.old_sd, p.old_sd_mode, row, A, j);
+        const float sd = sc ? sd0 : sd_at(p.sd, p.sd_mode, row, A, j);
+        const float osd = osc ? osd0 : sd_at(p.old_sd, p.old_sd_mode, row, A, j);
+        const float lsd = sc ? lsd0 : logf(sd), losd = osc ? losd0 : logf(osd);
+        const float v2 = sc ? v20 : 2.0f * (sd * sd), ov2 = osc ? ov20 : 2.0f * (osd * osd);
         const float t = a - s_mu[r * AS + j], ot = a - s_old[r * AS + j];
         // Normal.log_prob: -((v - loc)**2) / (2*var) - log(scale) - log(sqrt(2 pi))
-        lp += -(t * t) / (2.0f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI;
-        olp += -(ot * ot) / (2.0f * (osd * osd)) - logf(osd) - LOG_SQRT_2PI;
-        ent += ENTROPY_CONST + logf(sd);
+        lp += -(t * t) / v2 - lsd - LOG_SQRT_2PI;
+        olp += -(ot * ot) / ov2 - losd - LOG_SQRT_2PI;
+        ent += ENTROPY_CONST + lsd;
       }
       const float log_ratio = lp - olp;
       const float ratio = expf(log_ratio);

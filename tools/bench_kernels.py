@@ -28,8 +28,86 @@ def timeit(eng, fn, reps=20, warm=3):
     return t.elapsed_ms() / reps
 
 
+def big(eng):
+    """HBM-bound sizes (>= 0.5 GB of algorithmic traffic per launch): fraction of the 8 TB/s peak
+    each secondary kernel reaches when launch latency and tail effects are negligible."""
+    dev = eng.device
+    g = torch.Generator(device="cuda").manual_seed(0)
+    out = {}
+
+    def rnd(shape, dt=torch.float32):
+        return torch.empty(shape, dtype=dt, device=dev).normal_(0, 1, generator=g)
+
+    def rec(name, ms, nbytes):
+        out[name] = dict(ms=ms, GB=nbytes / 1e9, GBps=nbytes / ms / 1e6, frac_of_8TBps=nbytes / ms / 1e6 / 8000.0)
+    T, N = 400, 262144
+    r, v, nv = rnd((T, N)), rnd((T, N)), rnd((T, N))
+    fl = ((torch.rand((T, N), device=dev, generator=g) < 1 / 300).to(torch.uint8) * 3)
+    ret, adv = torch.empty_like(r), torch.empty_like(r)
+    for mode, name, bpe in ((_abi.SCAN_RETURN, "K6_return_[400,262144]", 17), (_abi.SCAN_GAE, "K6_gae_[400,262144]", 21)):
+        rec(name, timeit(eng, lambda: eng.return_scan(mode, 0.99, 0.97, r, v, nv, fl, ret, adv), reps=10), bpe * T * N)
+    st = torch.empty(3, dtype=torch.float64, device=dev)
+    rec("K7_stats_[104857600]", timeit(eng, lambda: eng.adv_stats(adv, st), reps=10), 4 * T * N)
+    rec("K7_normalize_[104857600]", timeit(eng, lambda: eng.adv_normalize(adv, st, 1, 1e-5), reps=10), 8 * T * N)
+    x = adv.view(-1, 32)
+    rec("K7_col_stats_[3276800,32]", timeit(eng, lambda: eng.col_stats(x), reps=10), 4 * x.numel())
+    rec("K8_reward_[104857600]", timeit(eng, lambda: eng.disc_reward(adv.view(-1), ret.view(-1)), reps=10), 8 * T * N)
+    mean, std = torch.zeros(32, dtype=torch.float64, device=dev), torch.ones(32, dtype=torch.float64, device=dev)
+    o = ret.view(-1, 32)
+    rec("K8_standardize_[3276800,32]", timeit(eng, lambda: eng.disc_standardize(x, None, mean, std, o), reps=10), 8 * x.numel())
+    rec("obs_filter_[3276800,32]", timeit(eng, lambda: eng.obs_filter(x, mean, std, 1e-8, 10.0, out=o), reps=10), 8 * x.numel())
+    del r, v, nv, fl, ret, adv, x, o
+    # K9 at full-batch size
+    Bp, A = 4 * 1638400, 12
+    mu, omu, act = rnd((Bp, A)) * 0.3, rnd((Bp, A)) * 0.3, rnd((Bp, A)) * 0.3
+    sd = torch.full((1,), 0.22, device=dev)
+    av, rt, vl = rnd((Bp,)), rnd((Bp,)), rnd((Bp,))
+    rec("K9_ppo_loss_[6553600,12]", timeit(eng, lambda: eng.ppo_loss(mu, sd, omu, sd, act, av, rt, vl, 0.2, 0.5), reps=10),
+        (16 * A + 16) * Bp)
+    del mu, omu, act, av, rt, vl
+    # K3 / K2 at 1 Mi envs
+    gb = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)
+    eng.contact_configure(gb, 0, 7, 10)
+    Nc, C = 1 << 20, 16
+    ncon = torch.randint(0, 17, (Nc,), device=dev, generator=g, dtype=torch.int32)
+    g1 = torch.zeros((Nc, C), dtype=torch.int32, device=dev)
+    g2 = torch.randint(0, 13, (Nc, C), device=dev, generator=g, dtype=torch.int32)
+    f6 = rnd((Nc, C, 6), torch.float64)
+    pz = rnd((Nc, C), torch.float64)
+    rec("K3_contacts_[1048576,16]", timeit(eng, lambda: eng.contact_reduce(ncon, g1, g2, f6, pz, want_idx=False), reps=10),
+        (4 + C * 64 + 60) * Nc)
+    eng.grf_configure(np.array([0, -1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 2, 2], np.int32), [(0, 1), (0, 2)])
+    W = 4
+    rec("K3_il_ground_forces_[4,262144,16]",
+        timeit(eng, lambda: eng.il_ground_forces(ncon[:Nc].view(W, -1), g1.view(W, Nc // W, C), g2.view(W, Nc // W, C),
+                                                 f6.view(W, Nc // W, C, 6)), reps=10), (4 + C * 8 + 2 * 24) * Nc)   # ncon + geom pairs + the two selected force rows
+    del f6, pz, g1, g2
+    sp = specs.A3Spec(mass=41.5)
+    eng.a3_configure(sp, np.zeros((4, sp.period)))
+    Na = 1 << 20
+    inp = dict(qpos=rnd((Na, 25), torch.float64), qvel=rnd((Na, 24), torch.float64),
+               act_len=rnd((Na, 12), torch.float64), act_vel=rnd((Na, 12), torch.float64),
+               lf_pos=rnd((Na, 3), torch.float64), rf_pos=rnd((Na, 3), torch.float64),
+               lf_vel=rnd((Na, 3), torch.float64), rf_vel=rnd((Na, 3), torch.float64),
+               root_pos=rnd((Na, 3), torch.float64), root_quat=rnd((Na, 4), torch.float64),
+               head_pos=rnd((Na, 3), torch.float64), grf_l=rnd((Na,), torch.float64).abs() * 100,
+               grf_r=rnd((Na,), torch.float64).abs() * 100, min_z=rnd((Na,), torch.float64) * 0.01,
+               n_r=torch.ones(Na, dtype=torch.int32, device=dev), n_l=torch.ones(Na, dtype=torch.int32, device=dev),
+               bad=torch.zeros(Na, dtype=torch.uint8, device=dev))
+    z32 = lambda val=0: torch.full((Na,), val, dtype=torch.int32, device=dev)
+    st2 = dict(phase=z32(), t1=z32(), t2=z32(1), reached_frames=z32(), target_reached=torch.zeros(Na, dtype=torch.uint8, device=dev),
+               mode=z32(2), seq_len=z32(20), sequence=rnd((Na, 20, 4), torch.float64),
+               goal=torch.zeros((Na, 8), dtype=torch.float64, device=dev))
+    o2 = dict(obs=torch.empty((Na, 41), dtype=torch.float32, device=dev), rew6=torch.empty((Na, 6), dtype=torch.float32, device=dev),
+              reward=torch.empty(Na, dtype=torch.float32, device=dev), done=torch.empty(Na, dtype=torch.uint8, device=dev))
+    rec("K2_a3_step_[1048576]", timeit(eng, lambda: eng.a3_step(inp, st2, out=o2), reps=10), (930 + 257) * Na)
+    print(json.dumps(out, indent=1))
+
+
 def main():
     eng = Engine(0)
+    if "--big" in sys.argv:
+        return big(eng)
     dev = eng.device
     g = torch.Generator(device="cuda").manual_seed(0)
     out = {}
