@@ -181,6 +181,26 @@ def test_scan_vs_oracle(eng, oracle, mode, T, N):
     assert np.array_equal(host(adv), e_adv)
 
 
+def test_scan_random_shapes(eng, oracle):
+    """Random [T,N] with N % 4 == 0 (pipelined kernel: ragged last tile, ragged last workgroup,
+    1..3 tiles in flight) and random cut densities, both modes, bit-exact."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        T = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 129, 200]))
+        N = 4 * int(rng.integers(1, 700))
+        dens = float(rng.choice([0.0, 1 / 300, 0.05, 0.5, 1.0]))
+        r, v, vn = (rng.normal(0, 1, (T, N)).astype(np.float32) for _ in range(3))
+        last = rng.uniform(size=(T, N)) < dens
+        ab = last & (rng.uniform(size=(T, N)) < 0.5)
+        ab |= (~last) & (rng.uniform(size=(T, N)) < 0.01)              # absorbing without last: ignored by RETURN
+        flags = (last * _abi.FLAG_LAST + ab * _abi.FLAG_ABSORBING).astype(np.uint8)
+        mode = _abi.SCAN_RETURN if case % 2 == 0 else _abi.SCAN_GAE
+        gam, lam = float(rng.choice([0.99, 1.0, 0.0, 0.9])), float(rng.choice([0.97, 1.0, 0.0]))
+        ret, adv = eng.return_scan(mode, gam, lam, dev(r), dev(v), dev(vn), dev(flags))
+        e_ret, e_adv = oracle.return_scan(mode, gam, lam, r, v, vn, flags)
+        assert np.array_equal(host(ret), e_ret) and np.array_equal(host(adv), e_adv), (case, T, N, dens, mode)
+
+
 def test_scan_unaligned_views_take_the_fallback(eng, oracle):
     """Buffers that are not 16-byte aligned (views at an odd element offset) are legal input."""
     rng = np.random.default_rng(2)
