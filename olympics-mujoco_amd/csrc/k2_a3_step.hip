@@ -11,6 +11,8 @@
 // stream.  Integer state (phase, t1, t2, frame counters, flags) is bit-exact; every fp64
 // expression keeps the reference's evaluation order (compiled with -ffp-contract=off).
 // Bound: HBM, ~930 B read + ~257 B written per env.
+#include <type_traits>
+
 #include "oly_common.h"
 
 namespace {
@@ -54,7 +56,10 @@ __device__ __forceinline__ double norm3d(double a0, double a1, double a2) {
 template <bool OBS64>
 __global__ __launch_bounds__(THREADS) void a3_step_kernel(A3Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  double* s_obs = reinterpret_cast<double*>(lds_raw);  // [THREADS][n_obs]
+  // the tile is staged in the OUTPUT type (the narrowing happens once, at the LDS store): half
+  // the LDS of a double tile for the default f32 observation -> twice the resident workgroups
+  using obs_t = typename std::conditional<OBS64, double, float>::type;
+  obs_t* s_obs = reinterpret_cast<obs_t*>(lds_raw);  // [THREADS][n_obs]
   const A3Dev* __restrict__ m = p.md;
   const int n_obs = m->n_obs, nu = m->nu, nq = m->nq, nv = m->nv, period = m->period;
   const int tid = threadIdx.x;
@@ -202,32 +207,29 @@ __global__ __launch_bounds__(THREADS) void a3_step_kernel(A3Args p) {
       pitch = atan2(-Rb[2][0], cy);
     }
     const double ci = cos(roll / 2.0), si = sin(roll / 2.0), cj = cos(pitch / 2.0), sj = sin(pitch / 2.0);
-    double* o = s_obs + (size_t)tid * n_obs;
-    o[0] = ci * cj;
-    o[1] = si * cj;
-    o[2] = ci * sj;
-    o[3] = -(si * sj);
-    o[4] = qvel[3]; o[5] = qvel[4]; o[6] = qvel[5];
+    obs_t* o = s_obs + (size_t)tid * n_obs;
+    o[0] = (obs_t)(ci * cj);
+    o[1] = (obs_t)(si * cj);
+    o[2] = (obs_t)(ci * sj);
+    o[3] = (obs_t)(-(si * sj));
+    o[4] = (obs_t)qvel[3]; o[5] = (obs_t)qvel[4]; o[6] = (obs_t)qvel[5];
     const double ang = 2 * PI * phase / (double)period;
-    o[7 + 2 * nu] = sin(ang);
-    o[8 + 2 * nu] = cos(ang);
+    o[7 + 2 * nu] = (obs_t)sin(ang);
+    o[8 + 2 * nu] = (obs_t)cos(ang);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[9 + 2 * nu + i] = goal[i];
+    for (int i = 0; i < 8; ++i) o[9 + 2 * nu + i] = (obs_t)goal[i];
   }
   // motor position / velocity columns: dense [N,nu] streams, one element per lane
   const int rows = min(THREADS, p.N - n0);
   for (int e = tid; e < rows * nu; e += THREADS) {
     const int r = e / nu, i = e - r * nu;
     const double g = m->gear[i];
-    s_obs[(size_t)r * n_obs + 7 + i] = p.in.act_len[(size_t)n0 * nu + e] / g;
-    s_obs[(size_t)r * n_obs + 7 + nu + i] = p.in.act_vel[(size_t)n0 * nu + e] / g;
+    s_obs[(size_t)r * n_obs + 7 + i] = (obs_t)(p.in.act_len[(size_t)n0 * nu + e] / g);
+    s_obs[(size_t)r * n_obs + 7 + nu + i] = (obs_t)(p.in.act_vel[(size_t)n0 * nu + e] / g);
   }
   __syncthreads();
   for (int e = tid; e < rows * n_obs; e += THREADS) {
-    if (OBS64)
-      static_cast<double*>(p.obs)[(size_t)n0 * n_obs + e] = s_obs[e];
-    else
-      static_cast<float*>(p.obs)[(size_t)n0 * n_obs + e] = (float)s_obs[e];
+    static_cast<obs_t*>(p.obs)[(size_t)n0 * n_obs + e] = s_obs[e];
   }
 }
 
@@ -300,7 +302,7 @@ extern "C" int oly_a3_step(oly_ctx* ctx, int N, const oly_a3_inputs* in, const o
   A3Args a;
   a.md = ctx->a3_dev; a.N = N; a.in = *in; a.st = *st; a.obs = obs; a.rew6 = rew6; a.reward = reward;
   a.done = done;
-  const size_t lds = sizeof(double) * THREADS * ctx->a3_host.n_obs;
+  const size_t lds = ((out_flags & OLY_OUT_OBS_F64) ? sizeof(double) : sizeof(float)) * THREADS * ctx->a3_host.n_obs;
   dim3 grid((N + THREADS - 1) / THREADS), block(THREADS);
   if (out_flags & OLY_OUT_OBS_F64)
     hipLaunchKernelGGL(a3_step_kernel<true>, grid, block, lds, oly_s(stream), a);

@@ -72,17 +72,20 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
       if (is_l && idx_l) idx_l[(size_t)n * C + cnt_l + __popc(ml & below)] = i;
       cnt_r += __popc(mr);
       cnt_l += __popc(ml);
-      // in-order sums: walk the 16 slots of the group, every lane of the group ends up with
-      // the same chain ((0 + n0) + n1) + ... as the reference's loop
-#pragma unroll
-      for (int k = 0; k < SLOTS; ++k) {
+      // in-order sums over the MATCHING slots only (ascending slot = contact order): every lane
+      // of the group ends up with the same chain ((0 + n_a) + n_b) + ... as the reference's loop;
+      // the trip count is the largest number of foot contacts among the wave's four environments
+      unsigned rem = mr | ml;
+      while (__any(rem != 0u)) {
+        const int k = rem ? (__ffs((int)rem) - 1) : 0;
         const double vk = __shfl(nrm, grp * SLOTS + k, 64);
-        if ((mr >> k) & 1u) sum_r += vk;
-        if ((ml >> k) & 1u) sum_l += vk;
         const double zk = __shfl(pz, grp * SLOTS + k, 64);
-        if (((mr | ml) >> k) & 1u) {
+        if (rem) {
+          if ((mr >> k) & 1u) sum_r += vk;
+          if ((ml >> k) & 1u) sum_l += vk;
           if (!have || zk < mz) mz = zk;
           have = true;
+          rem &= rem - 1u;
         }
       }
     }
