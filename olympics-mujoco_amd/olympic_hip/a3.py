@@ -171,24 +171,146 @@ class VecA3Env:
         """(obs [N,41], total_reward [N], done [N] bool, rewards [N,6])  StickFigureA3.py:187-200."""
         actions = actions.to(torch.float32).contiguous()
         target = self.eng.a3_pd_target(actions)
-        inp = self.physics.step(target)
+        o = self._evaluate(self.physics.step(target))
+        return o["obs"], o["reward"], o["done"].bool(), o["rew6"]
+
+    def _evaluate(self, inp):
+        """K3 + K2 on one physics readback (task.step -> calc_reward -> done -> get_obs)."""
         cr = self.eng.contact_reduce(inp["ncon"], inp["geom1"], inp["geom2"], inp["force6"], inp["cpos_z"],
                                      want_idx=False)
         kin = {k: inp[k] for k in ("qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel", "rf_vel",
                                    "root_pos", "root_quat", "head_pos")}
         kin.update(grf_l=cr["grf_l"], grf_r=cr["grf_r"], min_z=cr["min_z"], n_r=cr["n_r"], n_l=cr["n_l"],
                    bad=cr["bad"])
-        o = self.eng.a3_step(kin, self.state, obs_f64=self.obs_f64)
-        return o["obs"], o["reward"], o["done"].bool(), o["rew6"]
+        return self.eng.a3_step(kin, self.state, obs_f64=self.obs_f64)
 
 
 class ReplayA3Physics:
     """Replays recorded / synthetic per-step input dicts ([K,N,...] device tensors)."""
 
-    def __init__(self, blocks):
-        self.blocks, self.k = blocks, 0
+    def __init__(self, blocks, mass=41.5):
+        self.blocks, self.k, self.mass = blocks, 0, mass
+        self._cur = {n: v[0] for n, v in blocks.items()}
 
     def step(self, target):
-        out = {n: v[self.k] for n, v in self.blocks.items()}
+        self._cur = {n: v[self.k] for n, v in self.blocks.items()}
         self.k = (self.k + 1) % next(iter(self.blocks.values())).shape[0]
-        return out
+        return self._cur
+
+    def readback(self):
+        return self._cur
+
+    def set_state(self, env_ids, qpos, qvel):
+        """Replay has no dynamics: reports the recorded foot / root poses of the listed envs."""
+        idx = torch.as_tensor(np.asarray(env_ids, dtype=np.int64), device=self._cur["lf_pos"].device)
+        g = lambda k: self._cur[k][idx].cpu().numpy()
+        return dict(lfoot_pos=g("lf_pos"), rfoot_pos=g("rf_pos"), root_quat=g("root_quat"))
+
+
+class AlgorithmType:
+    """olympic_mujoco/enums/enums.py"""
+    REINFORCEMENT_LEARNING = "reinforcement_learning"
+    IMITATION_LEARNING = "imitation_learning"
+
+
+class StickFigureA3:
+    """Reinforcement-learning StickFigureA3 with the reference's interface
+    (real_humanoid_robots/StickFigureA3.py:60-260; used as `partial(StickFigureA3,
+    algorithm_type=REINFORCEMENT_LEARNING)` by examples/reinforcement_learning_ppo/a3):
+
+        env.robot.{mirrored_obs, mirrored_acts, clock_inds, iteration_count, actuators}
+        env.observation_space / action_space (np.zeros(41) / np.zeros(12)), env.base_obs_len
+        env.reset() / reset_model() -> obs;  env.step(a) -> (obs, total_reward, done, rewards dict)
+
+    num_envs = 1 gives exactly that scalar API (numpy in / out); larger values step N envs
+    (`.vec` is the VecA3Env).  The physics object owns MuJoCo:
+        physics.set_state(env_ids, qpos [n,25], qvel [n,24]) -> dict(lfoot_pos, rfoot_pos, root_quat) [n,..] (numpy)
+        physics.step(target [N,12]) -> readback dict (oly_a3_inputs fields + contact slots), device tensors
+        physics.readback() -> the same dict for the current state
+        physics.mass  (mj_getTotalmass)
+    """
+
+    REWARD_NAMES = ("foot_frc_score", "foot_vel_score", "orient_cost", "height_error", "step_reward",
+                    "upper_body_reward")                                   # walking_task.py:96-103
+
+    def __init__(self, algorithm_type=AlgorithmType.REINFORCEMENT_LEARNING, num_envs=1, physics=None, mass=None,
+                 device=0, engine=None, rs=None, **unused):
+        from types import SimpleNamespace
+        from .engine import Engine
+        from .robot_data import ROBOTS
+        from .specs import A3Spec
+        name = getattr(algorithm_type, "name", str(algorithm_type)).lower()
+        if "reinforcement" not in name:
+            raise NotImplementedError("StickFigureA3: only the reinforcement-learning mode is on the accelerated path")
+        if physics is None:
+            raise ValueError("StickFigureA3 needs a physics object (MuJoCo stays on the host)")
+        d = ROBOTS["StickFigureA3"]
+        spec = A3Spec(mass=float(mass if mass is not None else physics.mass))
+        self.spec, self.physics = spec, physics
+        self.vec = VecA3Env(spec, num_envs, engine or Engine(device), physics, np.asarray(d["geom_bodyid"], np.int32),
+                            d["bodies"]["world"], d["bodies"]["right_foot"], d["bodies"]["left_foot"], obs_f64=True, rs=rs)
+        self.rs = rs if rs is not None else np.random
+        self.robot = SimpleNamespace(mirrored_obs=list(spec.mirrored_obs), mirrored_acts=list(spec.mirrored_acts),
+                                     clock_inds=list(spec.clock_inds), iteration_count=np.inf,      # robot.py:55
+                                     actuators=list(range(spec.nu)))
+        self.observation_space = np.zeros(spec.n_obs)
+        self.action_space = np.zeros(spec.nu)
+        self.base_obs_len = spec.n_obs
+        init = np.zeros(spec.nq)
+        init[:3], init[3:7] = [0, 0, 0.81], [1, 0, 0, 0]                   # robot.py:60-86
+        init[7:] = np.asarray(spec.half_sitting_pose_deg) * np.pi / 180.0
+        self._init_qpos, self._init_qvel = init, np.zeros(spec.nv)
+
+    @property
+    def num_envs(self):
+        return self.vec.num_envs
+
+    @property
+    def eng(self):
+        return self.vec.eng
+
+    def _draw_init_state(self):
+        """reset_model's draws, in the reference's order (StickFigureA3.py:213-228)."""
+        rs, sp, c = self.rs, self.spec, 0.02
+        qpos = self._init_qpos + rs.uniform(low=-c, high=c, size=sp.nq)
+        qvel = self._init_qvel + rs.uniform(low=-c, high=c, size=sp.nv)
+        qpos[0], qpos[1], qpos[2] = rs.uniform(-1, 1), rs.uniform(-1, 1), 1.34
+        pitch, yaw = rs.uniform(-5, 5) * np.pi / 180, rs.uniform(-np.pi, np.pi)
+        cj, sj, ck, sk = np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw / 2), np.sin(yaw / 2)
+        qpos[3:7] = [cj * ck, -sj * sk, sj * ck, cj * sk]                  # euler2quat(0, pitch, yaw), sxyz
+        return qpos, qvel
+
+    def reset_model(self, env_ids=None):
+        ids = list(range(self.num_envs)) if env_ids is None else list(env_ids)
+        for i in ids:          # per env: state draws, then WalkingTask.reset's draws (same stream order)
+            qpos, qvel = self._draw_init_state()
+            kin = self.physics.set_state([i], qpos[None], qvel[None])
+            self.vec.iteration_count = self.robot.iteration_count if np.isfinite(self.robot.iteration_count) else 10 ** 9
+            self.vec.reset_task([i], kin["lfoot_pos"], kin["rfoot_pos"], kin["root_quat"])
+        return self._get_obs()
+
+    def _get_obs(self):
+        """get_obs of the current state without advancing the task: phase is stepped back by one
+        around the kernel's phase increment (the kernel evaluates WalkingTask.step + get_obs)."""
+        inp = self.physics.readback()
+        keep = {k: v.clone() for k, v in self.vec.state.items()}
+        self.vec.state["phase"].sub_(1)
+        obs = self.vec._evaluate(inp)["obs"]
+        for k, v in keep.items():
+            self.vec.state[k].copy_(v)
+        return obs if self.num_envs > 1 else obs[0].cpu().numpy()
+
+    def reset(self, env_mask=None):
+        if env_mask is None:
+            return self.reset_model()
+        ids = torch.nonzero(env_mask).flatten().tolist()
+        return self.reset_model(ids)
+
+    def step(self, a):
+        if self.num_envs > 1:
+            return self.vec.step(a)
+        act = torch.as_tensor(np.asarray(a, dtype=np.float32)[None], device=self.eng.device)
+        obs, rew, done, rew6 = self.vec.step(act)
+        r6 = rew6[0].cpu().numpy()
+        return (obs[0].cpu().numpy(), float(sum(float(x) for x in r6)), bool(done[0]),
+                {n: float(v) for n, v in zip(self.REWARD_NAMES, r6)})

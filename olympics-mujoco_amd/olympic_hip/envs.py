@@ -521,6 +521,22 @@ class Talos(UnitreeH1):
     _default_back = False
 
 
+
+
+class StickFigureA3(LocoEnvBase):
+    """Registry entry for the RL-mode StickFigureA3 (`LocoEnvBase.make("StickFigureA3.run.real",
+    algorithm_type=REINFORCEMENT_LEARNING, physics=...)`, show_a3_walk.py:77).  The trajectory
+    datasets only matter in imitation mode, which is not on the accelerated path."""
+    valid_task_confs = ValidTaskConf(tasks=["walk", "run", "test"], data_types=["real", "perfect"])   # StickFigureA3.py:23-25
+
+    @classmethod
+    def generate(cls, task="walk", dataset_type="real", **kwargs):
+        from .a3 import StickFigureA3 as _A3
+        check_validity_task_mode_dataset(cls.__name__, task, None, dataset_type, *cls.valid_task_confs.get_all())
+        return _A3(**kwargs)
+
+
 UnitreeH1.register()
 Atlas.register()
 Talos.register()
+StickFigureA3.register()

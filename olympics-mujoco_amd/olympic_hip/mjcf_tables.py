@@ -60,3 +60,20 @@ def geoms_from_mjcf(xml_path):
 
     walk(root.find("worldbody"))
     return [g.get("name") for b in bodies for g in b if g.tag == "geom"]
+
+
+def bodies_from_mjcf(xml_path):
+    """(body names in compiled body-id order, world first; geom -> body id list in geom-id order)."""
+    root = ET.parse(xml_path).getroot()
+    bodies = []
+
+    def walk(body):
+        bodies.append(body)
+        for el in body:
+            if el.tag == "body":
+                walk(el)
+
+    walk(root.find("worldbody"))
+    names = ["world"] + [b.get("name") for b in bodies[1:]]
+    geom_body = [i for i, b in enumerate(bodies) for g in b if g.tag == "geom"]
+    return names, geom_body

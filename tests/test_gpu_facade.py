@@ -513,3 +513,62 @@ def test_discriminator_trainer_separates_demo_from_policy():
     r_plcy = rew(plcy(1000), generator=gen).mean().item()
     assert r_demo > r_plcy
     assert float(rew.stand.colstats[0, 0]) == 151 * 2000 + 2 * 1000      # standardiser saw every forward
+
+
+def test_stickfigure_a3_reference_api(golden):
+    """partial(StickFigureA3, algorithm_type=REINFORCEMENT_LEARNING) as train_a3_walk.py uses it:
+    robot.mirrored_*, spaces, scalar reset/step with the rewards dict, SymmetricEnv wrapping, and
+    the registry path of show_a3_walk.py."""
+    from functools import partial
+    from olympic_hip.a3 import AlgorithmType, ReplayA3Physics, StickFigureA3
+    from olympic_hip.envs import LocoEnvBase
+    from olympic_hip.wrappers import SymmetricEnv
+    g = golden("a3_task.npz")
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    keys = ("qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel", "rf_vel", "root_pos", "root_quat",
+            "head_pos", "ncon", "geom1", "geom2", "force6", "cpos_z")
+    e = 3
+    blocks = {n: dev(np.swapaxes(g[n], 0, 1)[:, e:e + 1]) for n in keys}
+
+    def make_phys():
+        return ReplayA3Physics(blocks, mass=float(g["mass"]))
+    env_fn = partial(StickFigureA3, algorithm_type=AlgorithmType.REINFORCEMENT_LEARNING, physics=make_phys())
+    env = env_fn()
+    assert env.observation_space.shape[0] == 41 and env.action_space.shape[0] == 12 and env.base_obs_len == 41
+    assert env.robot.mirrored_obs == g["mirrored_obs"].tolist() if "mirrored_obs" in g.files else len(env.robot.mirrored_obs) == 41
+    assert env.robot.clock_inds == [31, 32] and len(env.robot.mirrored_acts) == 12
+    # the fixture's reset for env e: same RNG seed, same foot / root poses -> same task state
+    np.random.seed(1000 + e)
+    env.robot.iteration_count = int(g["iter_count"][e])
+    env.vec.iteration_count = env.robot.iteration_count
+    env.vec.reset_task([0], g["reset_lfoot"][e:e + 1], g["reset_rfoot"][e:e + 1], g["reset_root_quat"][e:e + 1])
+    assert int(env.vec.state["mode"][0]) == int(g["mode"][e]) and int(env.vec.state["phase"][0]) == int(g["phase0"][e])
+    K = 12
+    for k in range(K):
+        obs, total, done, rewards = env.step(np.zeros(12))
+        assert obs.shape == (41,) and obs.dtype == np.float64 and isinstance(total, float) and isinstance(done, bool)
+        assert list(rewards) == list(StickFigureA3.REWARD_NAMES)
+        np.testing.assert_allclose(obs, g["obs"][e, k], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(total, float(g["reward"][e, k]), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose([rewards[n] for n in StickFigureA3.REWARD_NAMES], g["rew6"][e, k], rtol=2e-6, atol=1e-7)
+        assert done == bool(g["done"][e, k])
+    # reset(): random initial state + WalkingTask.reset, obs of the un-advanced task
+    st0 = {k: v.clone() for k, v in env.vec.state.items()}
+    o = env._get_obs()
+    assert all(torch.equal(st0[k], env.vec.state[k]) for k in st0) and o.shape == (41,)
+    ob = env.reset()
+    assert ob.shape == (41,) and np.isfinite(ob).all() and int(env.vec.state["reached_frames"][0]) == 0
+    ph = int(env.vec.state["phase"][0])
+    np.testing.assert_allclose(ob[31:33], [np.sin(2 * np.pi * ph / 88), np.cos(2 * np.pi * ph / 88)], atol=1e-12)
+    # SymmetricEnv around it, as the training script builds it
+    sym = SymmetricEnv(env_fn, mirrored_obs=env.robot.mirrored_obs, mirrored_act=env.robot.mirrored_acts,
+                       clock_inds=env.robot.clock_inds)
+    assert sym.observation_space.shape[0] == 41
+    m = sym.mirror_clock_observation(torch.as_tensor(ob[None], dtype=torch.float32))
+    assert m.shape == (1, 41)
+    # registry path
+    env2 = LocoEnvBase.make("StickFigureA3.run.real", algorithm_type=AlgorithmType.REINFORCEMENT_LEARNING,
+                            physics=make_phys())
+    assert isinstance(env2, StickFigureA3)
+    with pytest.raises(NotImplementedError):
+        StickFigureA3(algorithm_type=AlgorithmType.IMITATION_LEARNING, physics=make_phys())

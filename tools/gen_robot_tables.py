@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, os.path.join(ROOT, "olympics-mujoco_amd"))
 import _ref_stubs as stubs  # noqa: E402
-from olympic_hip.mjcf_tables import geoms_from_mjcf, tables_from_mjcf  # noqa: E402
+from olympic_hip.mjcf_tables import bodies_from_mjcf, geoms_from_mjcf, tables_from_mjcf  # noqa: E402
 
 ns = stubs.load_reference()
 OT = stubs.ObservationType
@@ -68,6 +68,11 @@ def main():
                              grf_pairs=pairs if consistent else None)
         assert all((mm[3], mm[4]) == out[cls_name]["ctrlrange"] for mm in t["motors"])
         assert all(mm[0] == mm[1] + "_actuator" for mm in t["motors"])
+    # StickFigureA3 (RL mode): what MujocoRobotInterface looks up by name (mujoco_robot_interface.py:
+    # 69,250-252; body names StickFigureA3.py:88-97)
+    names, geom_body = bodies_from_mjcf(f"{DATA}/stickFigure_A3/a3.xml")
+    out["StickFigureA3"] = dict(geom_bodyid=geom_body,
+                                bodies={n: names.index(n) for n in ("world", "torso", "head", "right_foot", "left_foot")})
     path = os.path.join(ROOT, "olympics-mujoco_amd", "olympic_hip", "robot_data.py")
     with open(path, "w") as f:
         f.write('"""Joint / motor / spec-name tables of the imitation-learning robots (DATA transcribed by\n'
