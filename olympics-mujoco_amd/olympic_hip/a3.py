@@ -306,6 +306,18 @@ class StickFigureA3:
         ids = torch.nonzero(env_mask).flatten().tolist()
         return self.reset_model(ids)
 
+    def set_algorithm_type(self, algorithm_type):            # loco_env_base.py:203-204
+        self._algorithm_type = algorithm_type
+
+    def render(self, record=False):
+        raise NotImplementedError("rendering / recording is out of scope of the accelerated path")
+
+    def stop(self):
+        pass
+
+    def close(self):
+        pass
+
     def step(self, a):
         if self.num_envs > 1:
             return self.vec.step(a)

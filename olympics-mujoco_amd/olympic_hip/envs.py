@@ -506,6 +506,12 @@ class UnitreeH1(LocoEnvBase):
     def close(self):
         pass
 
+    def set_algorithm_type(self, algorithm_type):            # loco_env_base.py:203-204
+        self._algorithm_type = algorithm_type
+
+    def render(self, record=False):
+        raise NotImplementedError("rendering / recording is out of scope of the accelerated path")
+
 
 class Atlas(UnitreeH1):
     """Atlas (reference: real_humanoid_robots/atlas.py; back joints disabled by default :26)."""
