@@ -408,12 +408,26 @@ class PPO:
             del graphed
             ep_ret, ep_len = buf.episode_stats()
             mean_ret = float(np.mean(ep_ret)) if ep_ret else 0.0
-            self.highest_reward = max(self.highest_reward, mean_ret)
             with open(self.train_fn, "a") as out:
                 out.write("{},{}\n".format(mean_ret, float(np.mean(ep_len)) if ep_len else 0.0))
+            eval_rec = {}
+            if (itr + 1) % self.eval_freq == 0:               # deterministic evaluation + checkpoints (:443-477)
+                t2 = time.time()
+                test = self.sample_vec(env, self.policy, self.critic, T, self.max_traj_len, deterministic=True)
+                t_ret, t_len = test.episode_stats()
+                avg_eval_reward = float(np.mean(t_ret)) if t_ret else 0.0
+                with open(self.eval_fn, "a") as out:
+                    out.write("{},{}\n".format(avg_eval_reward, float(np.mean(t_len)) if t_len else 0.0))
+                self.save(policy, critic, "_" + repr(itr))
+                if self.highest_reward < avg_eval_reward:
+                    self.highest_reward = avg_eval_reward
+                    self.save(policy, critic)
+                eval_rec = dict(eval_return=avg_eval_reward, eval_s=time.time() - t2)
+                if verbose:
+                    print("====EVALUATE EPISODE====  (Return = {})".format(avg_eval_reward))
             rec = dict(itr=itr, ep_return=mean_ret, ep_len=float(np.mean(ep_len)) if ep_len else 0.0,
                        sample_s=sample_s, optim_s=time.time() - t1,
-                       fps=self.total_steps / (time.time() - start), losses=np.mean(stats, axis=0).tolist())
+                       fps=self.total_steps / (time.time() - start), losses=np.mean(stats, axis=0).tolist(), **eval_rec)
             history.append(rec)
             if verbose:
                 print("itr {itr}: return {ep_return:.3f} len {ep_len:.1f} sampling {sample_s:.2f}s "

@@ -276,7 +276,8 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr
                 self.state["phase"][env_mask] = 0
             return torch.zeros((N, 41), device="cuda")
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=minibatch, epochs=2,
-                max_traj_len=16, use_gae=False, num_procs=N, max_grad_norm=0.05, mirror_coeff=0.0, eval_freq=100)
+                max_traj_len=16, use_gae=False, num_procs=N, max_grad_norm=0.05, mirror_coeff=0.0,
+                eval_freq=2 if mode == "fused" else 100)
     ppo = PPO(args, str(tmp_path))
     ppo.fused_loss, ppo.use_graph = mode != "torch_losses", mode.startswith("fused_graph")
     if mode == "fused_graph_fresh":
@@ -290,6 +291,12 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr
     assert ppo.total_steps == n_itr * 16 * N
     lines = open(ppo.train_fn).read().strip().splitlines()
     assert lines[0] == "ep_returns,ep_lens" and len(lines) == n_itr + 1
+    if mode == "fused":                      # eval_freq = 2: one deterministic evaluation + checkpoints
+        ev = open(ppo.eval_fn).read().strip().splitlines()
+        assert ev[0] == "test_ep_returns,test_ep_lens" and len(ev) == 2 and "eval_return" in hist[1]
+        import os
+        assert os.path.exists(os.path.join(str(tmp_path), "actor_1.pt")) and os.path.exists(os.path.join(str(tmp_path), "critic.pt"))
+        assert ppo.highest_reward == hist[1]["eval_return"]
     # the update paths are the same algorithm: same seed -> same trained weights.  Across
     # implementations that holds to fp32 rounding for a few updates (16 at minibatch 2048; Adam
     # amplifies rounding noise over longer runs, so no bound is asserted at 128 updates).  A graph
