@@ -196,7 +196,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "il_tile_kernel<128,%s>" % args.robot if args.robot != "h1_arms" else
-                                   "il_step_kernel<64,DynDims>", "kernel_ms": kern_ms,
+                                   "il_dyn_tile_kernel (runtime shape)", "kernel_ms": kern_ms,
                          "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
         }
         if world == 1 and not args.no_cpu_baseline:
