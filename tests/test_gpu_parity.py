@@ -871,3 +871,36 @@ def test_h1_env_with_foot_forces(eng, oracle):
         assert np.array_equal(host(a), ref["absorbing"][t].astype(bool))
     with pytest.raises(NotImplementedError):
         specs.atlas("walk").with_foot_forces("Atlas")
+
+
+def test_error_paths_of_the_newer_entry_points():
+    """Misuse is reported before any launch: OLY_ENOTCONF / OLY_EINVAL with a message (C layer),
+    OlyError for shape / dtype / device mistakes (host layer)."""
+    from olympic_hip._ffi import OlyError
+    from olympic_hip.engine import Engine
+    e = Engine(0)
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device="cuda")
+    with pytest.raises(OlyError, match="before grf_configure"):
+        e.il_ground_forces(z(2, 4, dt=torch.int32), z(2, 4, 16, dt=torch.int32), z(2, 4, 16, dt=torch.int32),
+                           z(2, 4, 16, 6, dt=torch.float64))
+    with pytest.raises(OlyError, match="oly_grf_configure: bad argument"):
+        e.grf_configure(np.zeros(4, np.int32), [(0, 1)] * 5)                       # > OLY_MAX_GRF_PAIRS
+    e.grf_configure(np.array([0, 1, 2], np.int32), [(0, 1)])
+    with pytest.raises(OlyError, match="force6"):
+        e.il_ground_forces(z(2, 4, dt=torch.int32), z(2, 4, 16, dt=torch.int32), z(2, 4, 16, dt=torch.int32),
+                           z(2, 4, 16, 6))                                          # f32 instead of f64
+    with pytest.raises(OlyError, match="oly_ppo_loss: bad argument"):
+        e.ppo_loss(z(8, 65), z(1), z(8, 65), z(1), z(8, 65), z(8), z(8), z(8), 0.2)  # A > OLY_MAX_ACT
+    with pytest.raises(OlyError, match="old_mu"):
+        e.ppo_loss(z(8, 12), z(1), z(7, 12), z(1), z(8, 12), z(8), z(8), z(8), 0.2)
+    x = z(4, 6)
+    with pytest.raises(OlyError, match="oly_signed_perm: bad argument"):
+        e.signed_perm(x, z(6, dt=torch.int32), z(6), out=x)                         # in place is not allowed
+    with pytest.raises(OlyError, match="mean"):
+        e.obs_filter(x, z(6), z(6, dt=torch.float64))                               # f32 statistics
+    import ctypes as C
+    from olympic_hip import _ffi
+    L = _ffi.lib()
+    assert L.oly_mirror_loss(e.ctx.handle, 0, 12, None, None, None, None, None, None, None, None) == _abi.OLY_EINVAL
+    assert b"oly_mirror_loss" in L.oly_last_error(e.ctx.handle)
+    assert L.oly_il_ground_forces(e.ctx.handle, 0, 4, 16, None, None, None, None, None, None, None) == _abi.OLY_EINVAL
