@@ -211,6 +211,46 @@ class GraphedUpdate:
         return self.stats
 
 
+class GraphedActorCritic:
+    """mean / std of the Gaussian policy and the critic value for the N rollout environments as
+    ONE replayed HIP graph (the op-by-op forward of the two MLPs is ~40 tiny launches = ~280 us of
+    host time per vec step at N = 4096; the replay is one launch).  Forward only.  The sample
+    a = mu + (std * anneal) * eps is drawn outside the graph (torch.normal with a tensor std reads
+    a validity check back to the host and cannot be captured), which is the same arithmetic
+    Normal(mu, std * anneal).sample() performs.  Outputs live in static buffers that the next
+    replay overwrites."""
+
+    def __init__(self, policy, critic, num_envs, obs_dim, device, deterministic, anneal, warmup=2):
+        self.state = torch.zeros((num_envs, obs_dim), dtype=torch.float32, device=device)
+        self.deterministic, self.anneal = deterministic, float(anneal)
+
+        def body():
+            validate = torch.distributions.Distribution._validate_args
+            torch.distributions.Distribution.set_default_validate_args(False)
+            try:
+                pdf = policy.distribution(self.state)
+                return pdf.loc, pdf.scale, critic(self.state).reshape(num_envs)
+            finally:
+                torch.distributions.Distribution.set_default_validate_args(validate)
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    body()
+            torch.cuda.current_stream(device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.mu, self.scale, self.value = body()
+
+    def __call__(self, state):
+        self.state.copy_(state)
+        self.graph.replay()
+        if self.deterministic:
+            return self.mu, self.value
+        return self.mu + (self.scale * self.anneal) * torch.randn_like(self.mu), self.value
+
+
 class PPO:
     def __init__(self, args, save_path):
         self.gamma, self.lam = args["gamma"], args["lam"]
@@ -250,24 +290,30 @@ class PPO:
         buf = RolloutBuffer(T, N, obs_dim, act_dim, dev)
         state = env.reset().to(torch.float32)
         traj_len = torch.zeros(N, dtype=torch.int32, device=dev)
-        value = critic(state).reshape(N)
+        if getattr(self, "use_graph_rollout", False):
+            # one graph per rollout (same lifetime rule as the update graph: no eager allocations of
+            # other phases between its replays)
+            ac = GraphedActorCritic(policy, critic, N, obs_dim, dev, deterministic, anneal)
+        else:
+            def ac(s):
+                return policy(s, deterministic=deterministic, anneal=anneal), critic(s).reshape(N)
+        action, value = ac(state)
         for t in range(T):
-            action = policy(state, deterministic=deterministic, anneal=anneal)
             next_state, reward, done, _ = env.step(action)
             next_state = next_state.to(torch.float32)
             buf.store(state, action, reward.to(torch.float32), value)
             traj_len += 1
             done = done.bool()
             cut = done | (traj_len >= max_traj_len) | (t == T - 1)
-            next_value = critic(next_state).reshape(N)            # V(s_{t+1}): bootstrap now, value of step t+1 next
-            buf.next_values[t] = next_value
+            action, value = ac(next_state)                        # V(s_{t+1}): bootstrap now, and step t+1's pair
+            buf.next_values[t] = value
             buf.flags[t] = (cut.to(torch.uint8) * _abi.FLAG_LAST) | (done.to(torch.uint8) * _abi.FLAG_ABSORBING)
             if t < T - 1 and bool(cut.any()):
                 fresh = env.reset(env_mask=cut).to(torch.float32)
                 next_state = torch.where(cut.unsqueeze(1), fresh, next_state)
                 traj_len = torch.where(cut, torch.zeros_like(traj_len), traj_len)
-                next_value = critic(next_state).reshape(N)        # reset envs start from a new state
-            state, value = next_state, next_value
+                action, value = ac(next_state)                    # reset envs start from a new state
+            state = next_state
         return buf
 
     # ------------------------------------------------------------------ losses

@@ -579,3 +579,54 @@ def test_stickfigure_a3_reference_api(golden):
     assert isinstance(env2, StickFigureA3)
     with pytest.raises(NotImplementedError):
         StickFigureA3(algorithm_type=AlgorithmType.IMITATION_LEARNING, physics=make_phys())
+
+
+def test_graphed_rollout_equals_eager_rollout(golden):
+    """PPO.sample_vec with the actor/critic forward replayed as one HIP graph: a deterministic
+    rollout (no sampling noise) must fill the buffer exactly as the op-by-op rollout does; a
+    stochastic one must draw actions with the policy's mean and standard deviation."""
+    from olympic_hip.a3 import ReplayA3Physics, VecA3Env
+    from olympic_hip.engine import Engine
+    from olympic_hip.ppo import PPO, MLPCritic, MLPGaussianActor
+    sys_path = __import__("sys").path
+    import os
+    sys_path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_ppo_iter import synthetic_blocks
+    N, T = 256, 24
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    blocks = synthetic_blocks(N, 16, gen)
+    sp = specs.A3Spec(mass=41.5)
+    gb = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)
+
+    class Env(VecA3Env):
+        def __init__(self):
+            super().__init__(sp, N, Engine(0), ReplayA3Physics(blocks), gb, 0, 7, 10)
+            self.device = self.eng.device
+            self.state["seq_len"].fill_(20)
+            self.state["mode"].fill_(_abi.MODE_FORWARD)
+            self.state["t2"].fill_(1)
+
+        def reset(self, env_mask=None):
+            if env_mask is None:
+                self.state["phase"].zero_()
+                self.physics.k = 0
+            else:
+                self.state["phase"][env_mask] = 0
+            return torch.zeros((N, 41), device="cuda")
+    torch.manual_seed(0)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    ppo = PPO.__new__(PPO)
+    bufs = []
+    for graph in (False, True):
+        ppo.use_graph_rollout = graph
+        bufs.append(ppo.sample_vec(Env(), pi, vf, T, 10, deterministic=True))
+    a, b = bufs
+    for name in ("states", "actions", "rewards", "values", "next_values", "flags"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert int((a.flags & _abi.FLAG_LAST).bool().sum()) >= 2 * N           # time-limit cuts happened
+    ppo.use_graph_rollout = True
+    s = ppo.sample_vec(Env(), pi, vf, T, 10, deterministic=False, anneal=0.5)
+    mu = pi(s.states.reshape(-1, 41)).reshape(T, N, 12)
+    z = (s.actions - mu) / (float(pi.fixed_std) * 0.5)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02   # N(mu, (std * anneal)^2)
+    assert torch.equal(s.values, vf(s.states.reshape(-1, 41)).reshape(T, N))

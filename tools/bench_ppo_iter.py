@@ -75,6 +75,7 @@ def main():
               eval_freq=10 ** 9)
     ppo = PPO(hp, tempfile.mkdtemp(prefix="oly_ppo_"))
     ppo.fused_loss, ppo.use_graph = args.mode != "torch_losses", args.mode == "fused_graph"
+    ppo.use_graph_rollout = args.mode == "fused_graph"
     torch.manual_seed(0)
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
     hist = ppo.train(Env, pi, vf, n_itr=args.itr, verbose=False)
