@@ -302,6 +302,39 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void rollout_cuts_kernel(int N, int max_traj_len, int last_step,
+                                                           const uint8_t* __restrict__ done,
+                                                           int* __restrict__ traj_len,
+                                                           uint8_t* __restrict__ flags,
+                                                           int* __restrict__ n_cut) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  bool cut = false;
+  if (n < N) {
+    const int len = traj_len[n] + 1;
+    const bool d = done[n] != 0;
+    cut = d || len >= max_traj_len || last_step != 0;
+    flags[n] = (uint8_t)((cut ? OLY_FLAG_LAST : 0) | (d ? OLY_FLAG_ABSORBING : 0));
+    traj_len[n] = cut ? 0 : len;
+  }
+  const int c = __popcll(__ballot(cut));
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_cut, c);   // integer count: order-independent
+}
+}  // namespace
+
+extern "C" int oly_rollout_cuts(oly_ctx* ctx, int N, int max_traj_len, int last_step, const uint8_t* done,
+                                int32_t* traj_len, uint8_t* flags, int32_t* n_cut, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (N < 0 || !n_cut || (N > 0 && (!done || !traj_len || !flags)))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_rollout_cuts: bad argument");
+  OLY_HIP(ctx, hipMemsetAsync(n_cut, 0, sizeof(int32_t), oly_s(stream)));
+  if (N == 0) return OLY_OK;
+  hipLaunchKernelGGL(rollout_cuts_kernel, dim3((N + 255) / 256), dim3(256), 0, oly_s(stream), N, max_traj_len,
+                     last_step, done, traj_len, flags, n_cut);
+  OLY_LAUNCH_CHECK(ctx, "rollout_cuts_kernel");
+  return OLY_OK;
+}
+
 static bool wide_ok(const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
   auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
   return al(a, 15) && al(b, 15) && al(c, 15) && al(d, 3) && al(e, 15) && al(f, 15);

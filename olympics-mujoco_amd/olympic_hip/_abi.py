@@ -98,6 +98,7 @@ SIGNATURES = {
     "oly_disc_reward": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "oly_grf_configure": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     "oly_il_ground_forces": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "oly_rollout_cuts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "oly_obs_filter": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp]),
     "oly_signed_perm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "oly_mirror_loss": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),

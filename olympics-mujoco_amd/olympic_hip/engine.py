@@ -284,6 +284,17 @@ class Engine:
                       ptr(next_val), ptr(flags), ptr(ret), ptr(adv), self._s())
         return ret, adv
 
+    def rollout_cuts(self, done, traj_len, flags, n_cut, max_traj_len, last_step):
+        """PPO.sample's per-step episode-cut bookkeeping (traj_len / flags updated in place; n_cut [1] i32)."""
+        N = int(done.shape[0])
+        _req(done, "done", (N,), torch.uint8, self.device)
+        _req(traj_len, "traj_len", (N,), torch.int32, self.device)
+        _req(flags, "flags", (N,), torch.uint8, self.device)
+        _req(n_cut, "n_cut", (1,), torch.int32, self.device)
+        self.ctx.call("oly_rollout_cuts", N, int(max_traj_len), int(bool(last_step)), ptr(done), ptr(traj_len), ptr(flags),
+                      ptr(n_cut), self._s())
+        return flags
+
     # -------------------------------------------------------------- K7
     def adv_stats(self, x, stats3=None):
         _req(x, "x", x.shape, torch.float32, self.device)

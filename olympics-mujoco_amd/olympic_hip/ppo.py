@@ -298,20 +298,27 @@ class PPO:
             def ac(s):
                 return policy(s, deterministic=deterministic, anneal=anneal), critic(s).reshape(N)
         action, value = ac(state)
+        eng = getattr(env, "eng", None)
+        n_cut = torch.zeros(1, dtype=torch.int32, device=dev)
         for t in range(T):
             next_state, reward, done, _ = env.step(action)
             next_state = next_state.to(torch.float32)
             buf.store(state, action, reward.to(torch.float32), value)
-            traj_len += 1
-            done = done.bool()
-            cut = done | (traj_len >= max_traj_len) | (t == T - 1)
+            if eng is not None:                                   # one launch: traj_len, cut, flags, count
+                eng.rollout_cuts(done.to(torch.uint8), traj_len, buf.flags[t], n_cut, max_traj_len, t == T - 1)
+            else:
+                traj_len += 1
+                done = done.bool()
+                cut = done | (traj_len >= max_traj_len) | (t == T - 1)
+                buf.flags[t] = (cut.to(torch.uint8) * _abi.FLAG_LAST) | (done.to(torch.uint8) * _abi.FLAG_ABSORBING)
+                traj_len = torch.where(cut, torch.zeros_like(traj_len), traj_len)
+                n_cut = cut.sum().reshape(1)
             action, value = ac(next_state)                        # V(s_{t+1}): bootstrap now, and step t+1's pair
             buf.next_values[t] = value
-            buf.flags[t] = (cut.to(torch.uint8) * _abi.FLAG_LAST) | (done.to(torch.uint8) * _abi.FLAG_ABSORBING)
-            if t < T - 1 and bool(cut.any()):
+            if t < T - 1 and int(n_cut.item()):
+                cut = (buf.flags[t] & _abi.FLAG_LAST).bool()
                 fresh = env.reset(env_mask=cut).to(torch.float32)
                 next_state = torch.where(cut.unsqueeze(1), fresh, next_state)
-                traj_len = torch.where(cut, torch.zeros_like(traj_len), traj_len)
                 action, value = ac(next_state)                    # reset envs start from a new state
             state = next_state
         return buf

@@ -758,3 +758,19 @@ int oly_il_ground_forces_cpu(int ngeom, const int32_t* geom_group, int n_pairs, 
   }
   return OLY_OK;
 }
+
+/* PPO.sample's episode-cut bookkeeping, rl/algos/ppo.py:169-196, for N envs in lock step. */
+int oly_rollout_cuts_cpu(int N, int max_traj_len, int last_step, const uint8_t* done, int32_t* traj_len,
+                         uint8_t* flags, int32_t* n_cut) {
+  int c = 0;
+  for (int n = 0; n < N; ++n) {
+    const int len = traj_len[n] + 1;
+    const int d = done[n] != 0;
+    const int cut = d || len >= max_traj_len || last_step != 0;
+    flags[n] = (uint8_t)((cut ? OLY_FLAG_LAST : 0) | (d ? OLY_FLAG_ABSORBING : 0));
+    traj_len[n] = cut ? 0 : len;
+    c += cut;
+  }
+  *n_cut = c;
+  return OLY_OK;
+}

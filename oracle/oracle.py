@@ -308,3 +308,14 @@ def il_ground_forces(geom_group, pairs, ncon, geom1, geom2, force6):
     _chk(lib().oly_il_ground_forces_cpu(len(gg), _p(gg), len(pairs), _p(pa), _p(pb), W, N, Cc, _p(ncon), _p(geom1),
                                         _p(geom2), _p(force6), _p(step), _p(mean)), "il_ground_forces")
     return step, mean
+
+
+def rollout_cuts(done, traj_len, max_traj_len, last_step):
+    """-> (flags, new traj_len, n_cut)."""
+    done = _c(done, np.uint8)
+    tl = _c(traj_len, np.int32).copy()
+    flags = np.zeros(len(done), np.uint8)
+    nc = np.zeros(1, np.int32)
+    _chk(lib().oly_rollout_cuts_cpu(len(done), int(max_traj_len), int(bool(last_step)), _p(done), _p(tl), _p(flags),
+                                    _p(nc)), "rollout_cuts")
+    return flags, tl, int(nc[0])

@@ -904,3 +904,16 @@ def test_error_paths_of_the_newer_entry_points():
     assert L.oly_mirror_loss(e.ctx.handle, 0, 12, None, None, None, None, None, None, None, None) == _abi.OLY_EINVAL
     assert b"oly_mirror_loss" in L.oly_last_error(e.ctx.handle)
     assert L.oly_il_ground_forces(e.ctx.handle, 0, 4, 16, None, None, None, None, None, None, None) == _abi.OLY_EINVAL
+
+
+@pytest.mark.parametrize("N", [1, 63, 4096, 100001])
+def test_rollout_cuts_vs_oracle(eng, oracle, N):
+    rng = np.random.default_rng(N)
+    tl = rng.integers(0, 12, N).astype(np.int32)
+    for last in (0, 1):
+        done = (rng.uniform(size=N) < 0.1).astype(np.uint8)
+        tl_d, fl_d, nc_d = dev(tl), torch.zeros(N, dtype=torch.uint8, device="cuda"), torch.full((1,), 77, dtype=torch.int32, device="cuda")
+        eng.rollout_cuts(dev(done), tl_d, fl_d, nc_d, 10, last)
+        fl, tl2, nc = oracle.rollout_cuts(done, tl, 10, last)
+        assert np.array_equal(host(fl_d), fl) and np.array_equal(host(tl_d), tl2) and int(nc_d) == nc
+        tl = tl2

@@ -429,3 +429,12 @@ def test_robot_geom_tables():
     assert ROBOTS["Atlas"]["grf_pairs"] is None and len(ROBOTS["Talos"]["grf_pairs"]) == 2
     sp = specs.unitree_h1("walk").with_foot_forces("UnitreeH1")
     assert sp.grf_pairs == [(0, 1), (0, 2)] and sp.n_obs == 38
+
+
+def test_rollout_cuts_hand_case(oracle):
+    """PPO.sample's cut rules (rl/algos/ppo.py:169-196): done -> LAST|ABSORBING, time limit or block
+    end -> LAST only, counters restart after a cut."""
+    fl, tl, nc = oracle.rollout_cuts([0, 1, 0, 0], [3, 3, 8, 9], 10, False)
+    assert fl.tolist() == [0, 3, 0, 2] and tl.tolist() == [4, 0, 9, 0] and nc == 2
+    fl, tl, nc = oracle.rollout_cuts([0, 1, 0, 0], [3, 3, 8, 9], 10, True)
+    assert fl.tolist() == [2, 3, 2, 2] and tl.tolist() == [0, 0, 0, 0] and nc == 4
