@@ -185,7 +185,7 @@ def test_scan_random_shapes(eng, oracle):
     """Random [T,N] with N % 4 == 0 (pipelined kernel: ragged last tile, ragged last workgroup,
     1..3 tiles in flight) and random cut densities, both modes, bit-exact."""
     rng = np.random.default_rng(2024)
-    for case in range(24):
+    for case in range(2 * int(__import__("os").environ.get("OLY_FUZZ", "12"))):
         T = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 129, 200]))
         N = 4 * int(rng.integers(1, 700))
         dens = float(rng.choice([0.0, 1 / 300, 0.05, 0.5, 1.0]))
@@ -624,23 +624,30 @@ def _random_il_spec(rng, h1_shape=False):
         fall_names=[f"c{i}" for i in range(n_fall)], target_velocity=float(rng.uniform(0.5, 3)))
     sp.__class__ = type("RandSpec", (ILRobotSpec,), {"reward_idx": property(lambda self: self._ridx)})
     sp._ridx = int(rng.integers(0, n_obs))
+    if not h1_shape and rng.uniform() < 0.4:               # foot-force columns (mean_grf / 1000)
+        sp.n_grf = int(rng.choice([3, 6, 12]))
     return sp
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("OLY_FUZZ", "12"))))
 def test_random_table_driven_robots(eng, oracle, seed):
     """The IL kernel is table-driven (Atlas/Talos are data): random robots vs the oracle,
-    alternating between H1-shaped tables (fast tile kernel) and arbitrary shapes (generic)."""
+    alternating between H1-shaped tables (fast tile kernel) and arbitrary shapes (runtime-shape
+    persistent kernel + ragged tail); every third case is large enough for several tiles per
+    workgroup.  OLY_FUZZ=n runs n seeds."""
     rng = np.random.default_rng(100 + seed)
     sp = _random_il_spec(rng, h1_shape=(seed % 2 == 0))
-    T, N = int(rng.integers(1, 5)), int(rng.integers(1, 700))
+    T = int(rng.integers(1, 5))
+    N = int(rng.integers(1, 700)) if seed % 3 else int(rng.integers(5000, 40000))
     qpos = rng.uniform(-1.2, 1.2, (T, N, sp.nq))
     qvel = rng.normal(0, 1.5, (T, N, sp.nv))
     act = rng.uniform(-1.5, 1.5, (T, N, sp.n_act)).astype(np.float32)
     prev = rng.normal(1, 1, N)
+    kw = dict(grf_mean=rng.normal(0, 400, (T, N, sp.n_grf))) if sp.n_grf else {}
     for f64 in (False, True):
-        o = _run_il(eng, sp, qpos, qvel, act, prev, obs_f64=f64, ctrl_f64=f64)
-        ref = oracle.il_step(sp, qpos, qvel, act, prev, obs_f64=f64, ctrl_f64=f64)
+        o = _run_il(eng, sp, qpos, qvel, act, prev, obs_f64=f64, ctrl_f64=f64,
+                    **({"grf_mean": dev(kw["grf_mean"])} if kw else {}))
+        ref = oracle.il_step(sp, qpos, qvel, act, prev, obs_f64=f64, ctrl_f64=f64, **kw)
         _cmp_il(o, ref, f64)
     assert (np.asarray(ref["fall_code"]) > 0).any() or len(sp.fall_tests) == 0
 
