@@ -417,6 +417,27 @@ def test_contacts_shapes(eng, oracle, N, C):
         assert np.array_equal(host(o[k]), e[k]), k
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("OLY_FUZZ", "12"))))
+def test_contacts_random(eng, oracle, seed):
+    """Random slot counts and densities (none .. every slot a foot contact), valid geom ids and
+    ncon <= C (the oracle rejects malformed contact lists with OLY_ERANGE; the kernel, which
+    cannot raise, ignores such slots): all outputs bit-exact, force sums in contact order."""
+    rng = np.random.default_rng(500 + seed)
+    N, C = int(rng.integers(1, 3000)), int(rng.integers(1, 50))
+    gb = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)
+    eng.contact_configure(gb, 0, 7, 10)
+    ncon = rng.integers(0, C + 1, N).astype(np.int32)
+    p_floor = float(rng.choice([0.0, 0.3, 0.9, 1.0]))
+    g1 = np.where(rng.uniform(size=(N, C)) < p_floor, 0, rng.integers(0, 13, (N, C))).astype(np.int32)
+    g2 = rng.choice([7, 8, 11, 12, 3, 0, 5, 9], (N, C)).astype(np.int32)
+    f6 = rng.normal(0, 100, (N, C, 6))
+    pz = rng.uniform(-0.05, 0.05, (N, C))
+    o = eng.contact_reduce(dev(ncon), dev(g1), dev(g2), dev(f6), dev(pz))
+    e = oracle.contact_reduce(gb, 0, 7, 10, ncon, g1, g2, f6, pz)
+    for k in e:
+        assert np.array_equal(host(o[k]), e[k]), (k, N, C)
+
+
 # --------------------------------------------------------------------------------- K2
 def test_a3_golden_sequence(eng, golden, oracle):
     g = golden("a3_task.npz")
