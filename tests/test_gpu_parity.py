@@ -511,6 +511,53 @@ def test_a3_many_envs_vs_oracle(eng, golden, oracle):
         inp["lf_pos"] = inp["lf_pos"] + rng.normal(0, 0.02, (N, 3))
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("OLY_FUZZ", "12"))))
+def test_a3_state_machine_random(eng, golden, oracle, seed):
+    """WalkingTask's integer state machine at its edges: frame counters around the 30-frame delay,
+    target indices at the end of short sequences, all walk modes, feet inside / outside the
+    target radius; integer state and done bit-exact over several steps."""
+    g = golden("a3_task.npz")
+    spec = specs.A3Spec(mass=41.5)
+    eng.a3_configure(spec, g["clock_lut"])
+    rng = np.random.default_rng(900 + seed)
+    N = int(rng.integers(1, 600))
+    seq_len = rng.choice([1, 2, 5, 20], N).astype(np.int32)
+    t1 = (rng.integers(0, 20, N) % seq_len).astype(np.int32)
+    t2 = np.minimum(t1 + 1, seq_len - 1).astype(np.int32)
+    mode = np.where(seq_len == 1, _abi.MODE_STANDING,
+                    rng.choice([_abi.MODE_FORWARD, _abi.MODE_BACKWARD, _abi.MODE_LATERAL], N)).astype(np.int32)
+    seq = np.zeros((N, 20, 4))
+    seq[:, :, 0] = 0.3 * np.arange(20) + rng.normal(0, 0.02, (N, 20))
+    seq[:, :, 1] = 0.15 * (1 - 2 * (np.arange(20) % 2))
+    seq[:, :, 3] = rng.uniform(-0.3, 0.3, (N, 1))
+    st_h = dict(phase=rng.integers(0, 88, N).astype(np.int32), t1=t1, t2=t2,
+                reached_frames=rng.integers(0, 36, N).astype(np.int32), target_reached=rng.integers(0, 2, N).astype(np.uint8),
+                mode=mode, seq_len=seq_len, sequence=seq, goal=np.zeros((N, 8)))
+    tgt = seq[np.arange(N), t1, :3]
+    near = rng.uniform(size=(N, 1)) < 0.6
+    inp = dict(qpos=np.concatenate([rng.normal(0, 1, (N, 3)), rng.normal(0, 1, (N, 4)), rng.uniform(-1, 1, (N, 18))], 1),
+               qvel=rng.normal(0, 1, (N, 24)), act_len=rng.uniform(-1, 1, (N, 12)), act_vel=rng.normal(0, 2, (N, 12)),
+               lf_pos=tgt + np.where(near, rng.normal(0, 0.08, (N, 3)), rng.normal(0, 0.6, (N, 3))),
+               rf_pos=tgt + rng.normal(0, 0.4, (N, 3)),
+               lf_vel=rng.normal(0, 0.2, (N, 3)), rf_vel=rng.normal(0, 0.2, (N, 3)),
+               root_pos=tgt + np.array([0, 0, 0.62]) + rng.normal(0, 0.05, (N, 3)),
+               root_quat=rng.normal(0, 1, (N, 4)), head_pos=tgt + np.array([0, 0, 1.2]) + rng.normal(0, 0.1, (N, 3)),
+               grf_l=rng.uniform(0, 400, N), grf_r=rng.uniform(0, 400, N), min_z=rng.uniform(-0.01, 0.03, N),
+               n_r=rng.integers(0, 3, N).astype(np.int32), n_l=rng.integers(0, 3, N).astype(np.int32),
+               bad=(rng.uniform(size=N) < 0.1).astype(np.uint8))
+    st_d = {k: dev(v) for k, v in st_h.items()}
+    st_o = {k: v.copy() for k, v in st_h.items()}
+    for _ in range(5):
+        o = eng.a3_step({k: dev(v) for k, v in inp.items()}, st_d, obs_f64=True)
+        eo = oracle.a3_step(spec, g["clock_lut"], inp, st_o)
+        for k in ("phase", "t1", "t2", "reached_frames", "target_reached"):
+            assert np.array_equal(host(st_d[k]), st_o[k]), (k, seed)
+        assert np.array_equal(host(o["done"]), eo["done"])
+        np.testing.assert_allclose(host(st_d["goal"]), st_o["goal"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(host(o["obs"]), eo["obs"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(host(o["rew6"]), eo["rew6"], rtol=2e-6, atol=1e-7)
+
+
 def test_a3_pd(eng, golden, oracle):
     g = golden("a3_task.npz")
     spec = specs.A3Spec()
