@@ -992,3 +992,124 @@ def test_rollout_cuts_vs_oracle(eng, oracle, N):
         fl, tl2, nc = oracle.rollout_cuts(done, tl, 10, last)
         assert np.array_equal(host(fl_d), fl) and np.array_equal(host(tl_d), tl2) and int(nc_d) == nc
         tl = tl2
+
+
+# ------------------------------------------------------------------------------ memory safety
+class _Guard:
+    """Every tensor the engine allocates (and every in/out array handed to it) is carved out of a
+    larger byte buffer whose 4 KiB margins are filled with 0xA5; check() fails if any kernel
+    wrote outside its output.  (GPU AddressSanitizer is not available on this pool.)"""
+    PAD = 4096
+
+    def __init__(self, eng):
+        self.eng, self.items, self.orig = eng, [], eng._new
+        eng._new = self.new
+
+    def new(self, shape, dtype, fill=None):
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        raw = torch.full((n + 2 * self.PAD,), 0xA5, dtype=torch.uint8, device="cuda")
+        view = raw[self.PAD:self.PAD + n].view(dtype).view(shape)
+        if fill is not None:
+            view.copy_(torch.as_tensor(fill).to(dtype).reshape(shape))
+        self.items.append((raw, n))
+        return view
+
+    def check(self, what):
+        torch.cuda.synchronize()
+        for raw, n in self.items:
+            assert bool((raw[:self.PAD] == 0xA5).all()) and bool((raw[self.PAD + n:] == 0xA5).all()), what
+        self.items.clear()
+
+    def close(self):
+        self.eng._new = self.orig
+
+
+@pytest.mark.parametrize("N", [1, 63, 65, 129, 1000, 4097])
+def test_no_kernel_writes_outside_its_outputs(golden, N):
+    from olympic_hip.engine import Engine
+    eng = Engine(0)
+    gd = _Guard(eng)
+    try:
+        rng = np.random.default_rng(N)
+        # K1 / K5: every static and runtime-shape path, T = 1 and 3, f32 and f64 outputs
+        for sp in (specs.unitree_h1("walk"), specs.atlas("walk"), specs.unitree_h1("walk", disable_arms=False),
+                   specs.unitree_h1("walk").with_foot_forces("UnitreeH1")):
+            eng.il_configure(sp)
+            for T in (1, 3):
+                q, v, a = h1_synthetic_block(sp, T, N, seed=1, fall_frac="wide")
+                grf = dev(rng.normal(0, 100, (T, N, sp.n_grf))) if sp.n_grf else None
+                for f64 in (False, True):
+                    eng.il_step(dev(q), dev(v), dev(a), gd.new((N,), torch.float64, np.ones(N)), grf_mean=grf,
+                                obs_f64=f64, ctrl_f64=f64)
+                    gd.check(("il_step", sp.name, sp.n_obs, T, f64))
+        # K6 / rollout cuts / K7
+        for T in (1, 33, 100):
+            for Nn in (N, 4 * ((N + 3) // 4)):
+                r, v, vn = (dev(rng.normal(0, 1, (T, Nn)).astype(np.float32)) for _ in range(3))
+                fl = dev((rng.uniform(size=(T, Nn)) < 0.05).astype(np.uint8) * 3)
+                for mode in (_abi.SCAN_RETURN, _abi.SCAN_GAE):
+                    ret, adv = eng.return_scan(mode, 0.99, 0.97, r, v, vn, fl)
+                    gd.check(("return_scan", T, Nn, mode))
+        st = eng.adv_stats(adv)
+        eng.adv_normalize(gd.new(adv.shape, torch.float32, adv.cpu()), st, 1, 1e-5)
+        eng.col_stats(dev(rng.normal(0, 1, (N, 32)).astype(np.float32)))
+        eng.col_stats(dev(rng.normal(0, 1, (N, 41)).astype(np.float32)))
+        eng.rollout_cuts(dev((rng.uniform(size=N) < 0.2).astype(np.uint8)), gd.new((N,), torch.int32, np.zeros(N)),
+                         gd.new((N,), torch.uint8, np.zeros(N)), gd.new((1,), torch.int32, [0]), 10, False)
+        gd.check("K7 / cuts")
+        # K3 (RL + IL) and K2
+        gb = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)
+        eng.contact_configure(gb, 0, 7, 10)
+        for C in (5, 16, 40):
+            ncon = dev(rng.integers(0, C + 1, N).astype(np.int32))
+            g1, g2 = dev(np.zeros((N, C), np.int32)), dev(rng.integers(0, 13, (N, C)).astype(np.int32))
+            eng.contact_reduce(ncon, g1, g2, dev(rng.normal(0, 1, (N, C, 6))), dev(rng.normal(0, 1, (N, C))))
+            gd.check(("contact_reduce", C))
+            eng.grf_configure(np.array([0, -1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 2, 2], np.int32), [(0, 1), (0, 2)])
+            W = 3
+            eng.il_ground_forces(dev(rng.integers(0, C + 1, (W, N)).astype(np.int32)), dev(np.zeros((W, N, C), np.int32)),
+                                 dev(rng.integers(0, 13, (W, N, C)).astype(np.int32)), dev(rng.normal(0, 1, (W, N, C, 6))),
+                                 want_steps=True)
+            gd.check(("il_ground_forces", C))
+        g = golden("a3_task.npz")
+        sp3 = specs.A3Spec(mass=41.5)
+        eng.a3_configure(sp3, g["clock_lut"])
+        st_h, inp = a3_fixture_arrays(g, 0)
+        pick = rng.integers(0, g["phase"].shape[0], N)
+        st_d = {k: gd.new(v[pick].shape, torch.as_tensor(v).dtype, v[pick]) for k, v in st_h.items()}
+        inp_d = {k: dev(np.ascontiguousarray(v[pick])) for k, v in inp.items()}
+        inp_d.update(grf_l=dev(rng.uniform(0, 300, N)), grf_r=dev(rng.uniform(0, 300, N)), min_z=dev(rng.uniform(0, 0.02, N)),
+                     n_r=dev(np.ones(N, np.int32)), n_l=dev(np.ones(N, np.int32)), bad=dev(np.zeros(N, np.uint8)))
+        for f64 in (False, True):
+            eng.a3_step(inp_d, st_d, obs_f64=f64)
+        eng.a3_pd_target(dev(rng.uniform(-1, 1, (N, 12)).astype(np.float32)))
+        gd.check("a3")
+        # K8 / K9
+        x = dev(rng.normal(0, 1, (N, 32)).astype(np.float32))
+        m64, s64 = dev(np.zeros(32)), dev(np.ones(32))
+        eng.disc_standardize(x, None, m64, s64)
+        eng.disc_standardize(x, dev(np.arange(0, 32, 3, dtype=np.int32)), dev(np.zeros(11)), dev(np.ones(11)))
+        eng.obs_filter(x, m64, s64)
+        eng.disc_reward(dev(rng.normal(0, 3, N).astype(np.float32)))
+        z = dev(rng.normal(0, 1, (N, 7)).astype(np.float32))
+        eng.disc_reparam(z, z, z)
+        for A in (3, 12, 64):
+            c = _ppo_case(rng, N, A, 2)
+            eng.ppo_loss(*(dev(t) for t in c), 0.2, 0.5, want_grad=True, want_grad_std=True)
+            src = dev(rng.permutation(A).astype(np.int32))
+            sg = dev(rng.choice([-1.0, 1.0], A).astype(np.float32))
+            eng.mirror_loss(dev(c[0]), dev(c[2]), src, sg)
+            eng.signed_perm(dev(c[0]), src, sg)
+            gd.check(("K9", A))
+        # K4
+        tg = golden("trajectory.npz")
+        eng.traj_upload(tg["table"])
+        n_traj, L = tg["table"].shape[1], tg["table"].shape[2]
+        ct, cs, org, smp = eng.traj_reset(dev(rng.integers(0, n_traj, N).astype(np.int32)), dev(rng.integers(0, L, N).astype(np.int32)))
+        for _ in range(3):
+            eng.traj_next(ct, cs, org, smp)
+        eng.traj_euler(17, 0.01, dev(rng.normal(0, 1, (N, 17))), smp)
+        gd.check("traj")
+    finally:
+        gd.close()
