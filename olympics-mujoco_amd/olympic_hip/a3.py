@@ -269,6 +269,10 @@ class StickFigureA3:
     def eng(self):
         return self.vec.eng
 
+    @property
+    def device(self):
+        return self.vec.eng.device
+
     def _draw_init_state(self):
         """reset_model's draws, in the reference's order (StickFigureA3.py:213-228)."""
         rs, sp, c = self.rs, self.spec, 0.02
@@ -281,12 +285,16 @@ class StickFigureA3:
         return qpos, qvel
 
     def reset_model(self, env_ids=None):
+        """Random initial state + WalkingTask.reset for the listed envs.  For one env the draws come
+        in the reference's order (state, then task); for several the state draws of all envs come
+        first (the reference runs one env per process, so there is no cross-env order to keep)."""
         ids = list(range(self.num_envs)) if env_ids is None else list(env_ids)
-        for i in ids:          # per env: state draws, then WalkingTask.reset's draws (same stream order)
-            qpos, qvel = self._draw_init_state()
-            kin = self.physics.set_state([i], qpos[None], qvel[None])
-            self.vec.iteration_count = self.robot.iteration_count if np.isfinite(self.robot.iteration_count) else 10 ** 9
-            self.vec.reset_task([i], kin["lfoot_pos"], kin["rfoot_pos"], kin["root_quat"])
+        if not ids:
+            return self._get_obs()
+        states = [self._draw_init_state() for _ in ids]
+        kin = self.physics.set_state(ids, np.stack([q for q, _ in states]), np.stack([v for _, v in states]))
+        self.vec.iteration_count = self.robot.iteration_count if np.isfinite(self.robot.iteration_count) else 10 ** 9
+        self.vec.reset_task(ids, kin["lfoot_pos"], kin["rfoot_pos"], kin["root_quat"])
         return self._get_obs()
 
     def _get_obs(self):

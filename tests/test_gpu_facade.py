@@ -630,3 +630,20 @@ def test_graphed_rollout_equals_eager_rollout(golden):
     z = (s.actions - mu) / (float(pi.fixed_std) * 0.5)
     assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02   # N(mu, (std * anneal)^2)
     assert torch.equal(s.values, vf(s.states.reshape(-1, 41)).reshape(T, N))
+
+
+def test_examples_run(tmp_path):
+    """The two example scripts (the reference's play_walking_trajectory and train_a3_walk command
+    lines) run end to end on the GPU with small settings."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "play_walking_trajectory.py"), "UnitreeH1.walk.real",
+                        "--episodes", "1", "--steps", "50"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "replayed 50 steps" in r.stdout, r.stdout + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "train_a3_walk.py"), "train", "--num_procs", "64",
+                        "--n_itr", "2", "--max_traj_len", "20", "--minibatch_size", "256", "--input_norm_steps", "640",
+                        "--eval_freq", "2", "--logdir", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "done: 2 iterations" in r.stdout, r.stdout + r.stderr[-3000:]
+    assert os.path.exists(os.path.join(str(tmp_path), "actor.pt")) and os.path.exists(os.path.join(str(tmp_path), "eval.txt"))
