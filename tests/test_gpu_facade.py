@@ -647,3 +647,6 @@ def test_examples_run(tmp_path):
                         "--eval_freq", "2", "--logdir", str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "done: 2 iterations" in r.stdout, r.stdout + r.stderr[-3000:]
     assert os.path.exists(os.path.join(str(tmp_path), "actor.pt")) and os.path.exists(os.path.join(str(tmp_path), "eval.txt"))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "vail_discriminator_step.py"), "--num_envs", "256",
+                        "--steps", "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "discriminator reward mean" in r.stdout and " std 1.0000" in r.stdout, r.stdout + r.stderr[-3000:]
