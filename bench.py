@@ -37,7 +37,7 @@ def alg_bytes_per_row(spec, fall_code):
     qpos + qvel (f64) + action (f32) in; obs (f32) + reward (f32) + absorbing (u8) + ctrl (f32)
     out.  H1: 272 + 44 + 128 + 4 + 1 + 44 = 493 B (+1 with fall codes).  The carried reward
     state (16 B per env per LAUNCH) is not counted."""
-    return (8 * (spec.nq + spec.nv) + 4 * spec.n_act + 4 * spec.n_obs + 4 + 1 + 4 * spec.nu
+    return (8 * (spec.nq + spec.nv + spec.n_grf) + 4 * spec.n_act + 4 * spec.n_obs + 4 + 1 + 4 * spec.nu
             + (1 if fall_code else 0))
 
 
@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--N", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fall-code", action="store_true", help="also write the fall-code byte")
-    ap.add_argument("--robot", default="h1", choices=["h1", "atlas", "talos", "h1_arms"],
+    ap.add_argument("--robot", default="h1", choices=["h1", "atlas", "talos", "h1_arms", "h1_ff"],
                     help="h1 is the BASELINE config; the others exercise the same kernel on other tables")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to "
@@ -114,7 +114,8 @@ def main():
 
     spec = {"h1": lambda: specs.unitree_h1("walk"), "atlas": lambda: specs.atlas("walk"),
             "talos": lambda: specs.talos("walk"),
-            "h1_arms": lambda: specs.unitree_h1("walk", disable_arms=False)}[args.robot]()
+            "h1_arms": lambda: specs.unitree_h1("walk", disable_arms=False),
+            "h1_ff": lambda: specs.unitree_h1("walk").with_foot_forces("UnitreeH1")}[args.robot]()
     eng = Engine(local_rank).il_configure(spec)
     T, N = args.T, args.N
     qpos_h, qvel_h, act_h = h1_synthetic_block(spec, T, N, seed=1234 + 17 * rank)
@@ -130,8 +131,11 @@ def main():
     if args.fall_code:
         out["fall_code"] = torch.empty((T, N), dtype=torch.uint8, device=dev)
 
+    grf = (torch.empty((T, N, spec.n_grf), dtype=torch.float64, device=dev).normal_(0, 300) if spec.n_grf else None)
+
     def step(i):
-        eng.il_step(qpos, qvel, act, prev[i & 1], prev[(i + 1) & 1], out=out, want_fall_code=args.fall_code)
+        eng.il_step(qpos, qvel, act, prev[i & 1], prev[(i + 1) & 1], grf_mean=grf, out=out,
+                    want_fall_code=args.fall_code)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -195,7 +199,7 @@ def main():
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "il_tile_kernel<128,%s>" % args.robot if args.robot != "h1_arms" else
+                         "kernel": "il_tile_kernel<128,%s>" % args.robot if args.robot not in ("h1_arms", "h1_ff") else
                                    "il_dyn_tile_kernel (runtime shape)", "kernel_ms": kern_ms,
                          "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
         }

@@ -451,11 +451,11 @@ template <int ROWS, class D, bool OBS64, bool CTRL64>
 __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
   static_assert(D::is_static, "tile kernel needs compile-time dimensions");
   static_assert(ROWS % 64 == 0 && ROWS <= THREADS, "ROWS: whole waves, at most one row per lane");
-  constexpr int NQ = D::nq, NV = D::nv, NA = D::n_act, NU = D::nu, NO = D::n_obs;
-  static_assert(D::n_grf == 0, "fast path: no foot-force columns");
-  constexpr int CQ = ROWS * NQ / 2, CV = ROWS * NV / 2, CA = ROWS * NA / 4;  // 16-B chunks
+  constexpr int NQ = D::nq, NV = D::nv, NG = D::n_grf, NA = D::n_act, NU = D::nu, NO = D::n_obs;
+  constexpr int CQ = ROWS * NQ / 2, CV = ROWS * NV / 2, CG = ROWS * NG / 2, CA = ROWS * NA / 4;  // 16-B chunks
   constexpr int KQ = (CQ + THREADS - 1) / THREADS, KV = (CV + THREADS - 1) / THREADS,
-                KA = (CA + THREADS - 1) / THREADS;
+                KG = (CG + THREADS - 1) / THREADS, KA = (CA + THREADS - 1) / THREADS;
+  constexpr int ND = NQ + NV + NG;                  // staged doubles per row: q | v | mean_grf
   constexpr int OW = OBS64 ? 2 : 4;                 // obs values per lane store
   static_assert((ROWS * NO) % OW == 0, "observation tile must split into whole lane vectors");
   constexpr int NOV = ROWS * NO / OW;               // obs vectors per tile
@@ -467,14 +467,18 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   double* sq = reinterpret_cast<double*>(lds);                                  // [ROWS][NQ]
   double* sv = sq + ROWS * NQ;                                                  // [ROWS][NV]
-  float* sa = reinterpret_cast<float*>(lds + (size_t)ROWS * (NQ + NV) * 8);     // [ROWS][NA]
-  double* t_act = reinterpret_cast<double*>(lds + (size_t)ROWS * (NQ + NV) * 8 + (size_t)ROWS * NA * 4);
+  double* sg = sv + ROWS * NV;                                                  // [ROWS][NG] (foot forces)
+  float* sa = reinterpret_cast<float*>(lds + (size_t)ROWS * ND * 8);            // [ROWS][NA]
+  double* t_act = reinterpret_cast<double*>(lds + (size_t)ROWS * ND * 8 + (size_t)ROWS * NA * 4);
   const IlDev* __restrict__ md = p.md;
   const int tid = threadIdx.x, lane = tid & 63;
   const bool with_ctrl = p.ctrl != nullptr;
 
-  auto col_off = [&](int sidx) -> int { return sidx < NQ ? sidx : ROWS * NQ + (sidx - NQ); };
-  auto col_str = [&](int sidx) -> int { return sidx < NQ ? NQ : NV; };
+  auto col_off = [&](int sidx) -> int {
+    return sidx < NQ ? sidx : sidx < NQ + NV ? ROWS * NQ + (sidx - NQ) : ROWS * (NQ + NV) + (sidx - NQ - NV);
+  };
+  auto col_str = [&](int sidx) -> int { return sidx < NQ ? NQ : sidx < NQ + NV ? NV : NG; };
+  auto is_grf = [&](int sidx) -> bool { return NG > 0 && sidx >= NQ + NV; };   // stored as mean_grf / 1000
 
   // ---- once per workgroup
   for (int j = tid; j < NU; j += THREADS) {   // per ACTUATOR: mean | delta | lo | hi
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
   // The tile-local position of every value a lane stores is the same for every tile, so the
   // LDS element it reads (column permutation + row stride) is computed ONCE: e_off[it][k].
   int e_off[NIT][OW];
+  unsigned e_grf = 0;                         // bit it*OW+k: that value is a foot-force column
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
 #pragma unroll
@@ -498,9 +503,11 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
         const int r = e / NO, c = e - r * NO;
         const int sidx = md->src[c];
         off = col_off(sidx) + r * col_str(sidx);
+        if (is_grf(sidx)) e_grf |= 1u << (it * OW + k);
       }
       e_off[it][k] = off;
     }
+  static_assert(NIT * OW <= 32, "grf bitmask holds 32 values per lane");
   int c_aidx[NCI][CW];                        // ctrl elements of this lane: LDS index of the
   int c_j[NCI][CW];                           // action value (-1: actuator not driven), actuator
 #pragma unroll
@@ -518,17 +525,20 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
   const int nf = md->n_fall;
   int f_off[FAST_FALL], f_str[FAST_FALL];
   double f_lo[FAST_FALL], f_hi[FAST_FALL];
+  unsigned f_grf = 0;
 #pragma unroll
   for (int k = 0; k < FAST_FALL; ++k) {
     const int kk = k < nf ? k : 0;
     const int sidx = md->fall_sidx[kk];
     f_off[k] = col_off(sidx);
     f_str[k] = col_str(sidx);
+    if (is_grf(sidx)) f_grf |= 1u << k;
     f_lo[k] = k < nf ? md->fall_lo[kk] : -__builtin_huge_val();
     f_hi[k] = k < nf ? md->fall_hi[kk] : __builtin_huge_val();
   }
   const int rt = md->reward_type;
   const int rew_off = col_off(md->reward_sidx), rew_str = col_str(md->reward_sidx);
+  const bool rew_grf = is_grf(md->reward_sidx);
   const double tvel = md->target_velocity;
   const int use_abs = md->use_absorbing;
   auto rew_f = [&](double s) -> float {
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
   };
 
   const long ntiles = p.tile0;  // number of full tiles
-  u32x4 rq[KQ], rv[KV], ra[KA];
+  u32x4 rq[KQ], rv[KV], rg[KG > 0 ? KG : 1], ra[KA];
   auto issue_loads = [&](long t) {
     const long r0 = t * ROWS;
     const u32x4* gq = reinterpret_cast<const u32x4*>(p.qpos + r0 * NQ) + tid;
@@ -551,6 +561,12 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
 #pragma unroll
     for (int k = 0; k < KV; ++k)
       if (k * THREADS + THREADS <= CV || tid + k * THREADS < CV) rv[k] = ld16(gv + k * THREADS);
+    if (NG > 0) {
+      const u32x4* gg = reinterpret_cast<const u32x4*>(p.grf + r0 * NG) + tid;
+#pragma unroll
+      for (int k = 0; k < KG; ++k)
+        if (k * THREADS + THREADS <= CG || tid + k * THREADS < CG) rg[k] = ld16(gg + k * THREADS);
+    }
     if (with_ctrl) {
       const u32x4* ga = reinterpret_cast<const u32x4*>(p.action + r0 * NA) + tid;
 #pragma unroll
@@ -574,6 +590,12 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
 #pragma unroll
       for (int k = 0; k < KV; ++k)
         if (k * THREADS + THREADS <= CV || tid + k * THREADS < CV) lv[k * THREADS] = rv[k];
+      if (NG > 0) {
+        u32x4* lg = reinterpret_cast<u32x4*>(sg) + tid;
+#pragma unroll
+        for (int k = 0; k < KG; ++k)
+          if (k * THREADS + THREADS <= CG || tid + k * THREADS < CG) lg[k * THREADS] = rg[k];
+      }
       if (with_ctrl) {
 #pragma unroll
         for (int k = 0; k < KA; ++k)
@@ -591,8 +613,12 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
       const long gr = row0 + r;
       double fv[FAST_FALL];
 #pragma unroll
-      for (int k = 0; k < FAST_FALL; ++k) fv[k] = sq[f_off[k] + r * f_str[k]];
-      const double x = sq[rew_off + r * rew_str];
+      for (int k = 0; k < FAST_FALL; ++k) {
+        fv[k] = sq[f_off[k] + r * f_str[k]];
+        if (NG > 0 && ((f_grf >> k) & 1u)) fv[k] = fv[k] / 1000.0;
+      }
+      double x = sq[rew_off + r * rew_str];
+      if (NG > 0 && rew_grf) x = x / 1000.0;
       unsigned code = 0;
 #pragma unroll
       for (int k = FAST_FALL - 1; k >= 0; --k)
@@ -630,7 +656,10 @@ __global__ __launch_bounds__(THREADS) void il_tile_kernel(IlArgs p) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
 #pragma unroll
-        for (int k = 0; k < OW; ++k) v[it][k] = sq[e_off[it][k]];
+        for (int k = 0; k < OW; ++k) {
+          v[it][k] = sq[e_off[it][k]];
+          if (NG > 0 && ((e_grf >> (it * OW + k)) & 1u)) v[it][k] = v[it][k] / 1000.0;  // mean_grf / 1000.0
+        }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int i = tid + it * THREADS;
@@ -949,6 +978,8 @@ __global__ __launch_bounds__(THREADS) void il_dyn_tile_kernel(IlArgs p) {
 using H1Dims = StaticDims<17, 17, 0, 11, 11, 32>;      // UnitreeH1, arms removed
 using AtlasDims = StaticDims<16, 16, 0, 10, 10, 30>;   // Atlas, arms + back removed (default)
 using TalosDims = StaticDims<18, 18, 0, 12, 12, 34>;   // Talos, arms removed (default)
+using H1FFDims = StaticDims<17, 17, 6, 11, 11, 38>;    // UnitreeH1, use_foot_forces=True
+using TalosFFDims = StaticDims<18, 18, 6, 12, 12, 40>; // Talos, use_foot_forces=True
 
 template <int ROWS, class D>
 int launch_generic(oly_ctx* ctx, IlArgs a, long tile0, int out_flags, hipStream_t s) {
@@ -983,7 +1014,7 @@ template <int ROWS, class D>
 int launch_fast(oly_ctx* ctx, IlArgs a, int out_flags, int wg_per_cu, hipStream_t s) {
   const long nfull = a.R / ROWS;
   if (nfull > 0) {
-    const int lds = ROWS * (D::nq + D::nv) * 8 + ROWS * D::n_act * 4 + 4 * D::nu * 8;
+    const int lds = ROWS * (D::nq + D::nv + D::n_grf) * 8 + ROWS * D::n_act * 4 + 4 * D::nu * 8;
     int per_cu = (160 * 1024) / lds;
     if (per_cu > 8) per_cu = 8;
     if (wg_per_cu > 0) per_cu = wg_per_cu;
@@ -1142,14 +1173,16 @@ extern "C" int oly_il_step(oly_ctx* ctx, int T, int N, const double* qpos, const
            ((reinterpret_cast<uintptr_t>(absorbing) & 3) == 0) &&
            ((reinterpret_cast<uintptr_t>(fall_code) & 3) == 0);
   a.tile0 = 0;
-  auto shape = [&](int nq, int na, int no) {
-    return h.nq == nq && h.nv == nq && h.n_grf == 0 && h.n_act == na && h.nu == na && h.n_obs == no &&
+  auto shape = [&](int nq, int na, int no, int ng = 0) {
+    return h.nq == nq && h.nv == nq && h.n_grf == ng && h.n_act == na && h.nu == na && h.n_obs == no &&
            h.n_pos == nq && h.n_vel == nq && h.n_drop == 2;
   };
   const bool fast_ok = a.fast && h.n_fall <= FAST_FALL;
   static const int wg_env2 = [] { const char* e = getenv("OLY_K1_WG_PER_CU"); return e ? atoi(e) : 0; }();
   if (fast_ok && shape(16, 10, 30)) return launch_fast<128, AtlasDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
   if (fast_ok && shape(18, 12, 34)) return launch_fast<128, TalosDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
+  if (fast_ok && shape(17, 11, 38, 6)) return launch_fast<128, H1FFDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
+  if (fast_ok && shape(18, 12, 40, 6)) return launch_fast<128, TalosFFDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
   const bool is_h1 = shape(17, 11, 32);
   if (is_h1 && fast_ok) {
     static const int rows_env = [] { const char* e = getenv("OLY_K1_ROWS"); return e ? atoi(e) : 0; }();
