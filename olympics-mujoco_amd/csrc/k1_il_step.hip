@@ -1178,19 +1178,20 @@ extern "C" int oly_il_step(oly_ctx* ctx, int T, int N, const double* qpos, const
            h.n_pos == nq && h.n_vel == nq && h.n_drop == 2;
   };
   const bool fast_ok = a.fast && h.n_fall <= FAST_FALL;
-  static const int wg_env2 = [] { const char* e = getenv("OLY_K1_WG_PER_CU"); return e ? atoi(e) : 0; }();
-  if (fast_ok && shape(16, 10, 30)) return launch_fast<128, AtlasDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
-  if (fast_ok && shape(18, 12, 34)) return launch_fast<128, TalosDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
-  if (fast_ok && shape(17, 11, 38, 6)) return launch_fast<128, H1FFDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
-  if (fast_ok && shape(18, 12, 40, 6)) return launch_fast<128, TalosFFDims>(ctx, a, out_flags, wg_env2, oly_s(stream));
-  const bool is_h1 = shape(17, 11, 32);
-  if (is_h1 && fast_ok) {
-    static const int rows_env = [] { const char* e = getenv("OLY_K1_ROWS"); return e ? atoi(e) : 0; }();
-    static const int wg_env = [] { const char* e = getenv("OLY_K1_WG_PER_CU"); return e ? atoi(e) : 0; }();
-    if (rows_env == 64) return launch_fast<64, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
-    if (rows_env == 256) return launch_fast<256, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
-    return launch_fast<128, H1Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
-  }
+  static const int wg_env = [] { const char* e = getenv("OLY_K1_WG_PER_CU"); return e ? atoi(e) : 0; }();
+  static const int rows_env = [] { const char* e = getenv("OLY_K1_ROWS"); return e ? atoi(e) : 0; }();
+#define OLY_K1_FAST(DIMS, DEFROWS)                                                              \
+  do {                                                                                          \
+    const int rows = rows_env ? rows_env : DEFROWS;                                             \
+    if (rows == 64) return launch_fast<64, DIMS>(ctx, a, out_flags, wg_env, oly_s(stream));     \
+    return launch_fast<128, DIMS>(ctx, a, out_flags, wg_env, oly_s(stream));                    \
+  } while (0)
+  if (fast_ok && shape(17, 11, 32)) OLY_K1_FAST(H1Dims, 128);
+  if (fast_ok && shape(16, 10, 30)) OLY_K1_FAST(AtlasDims, 128);
+  if (fast_ok && shape(18, 12, 34)) OLY_K1_FAST(TalosDims, 128);
+  if (fast_ok && shape(17, 11, 38, 6)) OLY_K1_FAST(H1FFDims, 128);
+  if (fast_ok && shape(18, 12, 40, 6)) OLY_K1_FAST(TalosFFDims, 128);
+#undef OLY_K1_FAST
   static const int dyn_env = [] { const char* e = getenv("OLY_K1_DYN_TILE"); return e ? atoi(e) : 1; }();
   if (dyn_env) return launch_dyn(ctx, a, out_flags, oly_s(stream));
   return launch_generic<64, DynDims>(ctx, a, 0, out_flags, oly_s(stream));
