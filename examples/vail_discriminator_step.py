@@ -11,7 +11,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "olympics-mujoco_amd"))
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from olympic_hip.envs import LocoEnvBase  # noqa: E402

@@ -15,7 +15,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "olympics-mujoco_amd"))
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from olympic_hip import _abi, specs  # noqa: E402

@@ -5,7 +5,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "olympics-mujoco_amd"))
 import torch
-from olympic_hip import _abi
+
 from olympic_hip._ffi import HipTimer
 from olympic_hip.engine import Engine
 eng = Engine(0); dev = eng.device
