@@ -178,3 +178,198 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
   b->timing[0] = t1 - t0; b->timing[1] = t2 - t1; b->timing[2] = t3 - t2;
   return rc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// RL robot (StickFigureA3): same pool, one pinned slab holding every readback array so that the
+// whole post-physics state of N envs goes up in ONE copy.
+// ---------------------------------------------------------------------------------------------
+struct oly_a3_batcher {
+  oly_ctx* ctx;
+  int N, C, nq, nv, nu, n_threads;
+  oly_a3_physics_fn fn;
+  void* user;
+  unsigned char *h_slab, *d_slab;
+  size_t slab_bytes;
+  size_t off[16];              // byte offsets of the 16 readback arrays inside the slab
+  double *h_target, *d_target;  // [N,nu]
+  // K3 outputs (device)
+  int32_t *d_nr, *d_nl;
+  double *d_grf_r, *d_grf_l, *d_minz;
+  uint8_t* d_bad;
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  long generation;
+  int pending;
+  bool stop;
+  double timing[3];
+};
+
+namespace {
+
+enum { A_QPOS, A_QVEL, A_ALEN, A_AVEL, A_LFP, A_RFP, A_LFV, A_RFV, A_ROOTP, A_ROOTQ, A_HEAD, A_NCON, A_G1, A_G2, A_F6, A_CZ };
+
+void a3_slots(const oly_a3_batcher* b, unsigned char* base, int e, oly_a3_readback* rb) {
+  auto d = [&](int k, int w) { return reinterpret_cast<double*>(base + b->off[k]) + (size_t)e * w; };
+  auto i = [&](int k, int w) { return reinterpret_cast<int32_t*>(base + b->off[k]) + (size_t)e * w; };
+  rb->qpos = d(A_QPOS, b->nq); rb->qvel = d(A_QVEL, b->nv);
+  rb->act_len = d(A_ALEN, b->nu); rb->act_vel = d(A_AVEL, b->nu);
+  rb->lf_pos = d(A_LFP, 3); rb->rf_pos = d(A_RFP, 3); rb->lf_vel = d(A_LFV, 3); rb->rf_vel = d(A_RFV, 3);
+  rb->root_pos = d(A_ROOTP, 3); rb->root_quat = d(A_ROOTQ, 4); rb->head_pos = d(A_HEAD, 3);
+  rb->ncon = i(A_NCON, 1); rb->geom1 = i(A_G1, b->C); rb->geom2 = i(A_G2, b->C);
+  rb->force6 = d(A_F6, 6 * b->C); rb->cpos_z = d(A_CZ, b->C);
+}
+
+void a3_worker(oly_a3_batcher* b, int id) {
+  long seen = 0;
+  const int per = (b->N + b->n_threads - 1) / b->n_threads;
+  const int lo = id * per, hi = lo + per < b->N ? lo + per : b->N;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(b->mu);
+      b->cv_go.wait(lk, [&] { return b->stop || b->generation != seen; });
+      if (b->stop) return;
+      seen = b->generation;
+    }
+    for (int e = lo; e < hi; ++e) {
+      oly_a3_readback rb;
+      a3_slots(b, b->h_slab, e, &rb);
+      b->fn(e, b->h_target + (size_t)e * b->nu, &rb, b->user);
+    }
+    {
+      std::lock_guard<std::mutex> lk(b->mu);
+      if (--b->pending == 0) b->cv_done.notify_one();
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int oly_a3_batcher_create(oly_a3_batcher** out, oly_ctx* ctx, int N, int C, int n_threads,
+                                     oly_a3_physics_fn physics, void* user) {
+  if (!out || !ctx) return OLY_EINVAL;
+  *out = nullptr;
+  if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_batcher_create before oly_a3_configure");
+  if (!ctx->contact_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_batcher_create before oly_contact_configure");
+  if (N <= 0 || C <= 0 || n_threads < 0 || !physics)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_batcher_create: bad N, C, n_threads or NULL physics");
+  OLY_HIP(ctx, hipSetDevice(ctx->device));
+  oly_a3_batcher* b = new (std::nothrow) oly_a3_batcher();
+  if (!b) return OLY_ENOMEM;
+  const A3Dev& h = ctx->a3_host;
+  b->ctx = ctx; b->N = N; b->C = C; b->nq = h.nq; b->nv = h.nv; b->nu = h.nu; b->fn = physics; b->user = user;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (n_threads == 0) n_threads = hw ? (int)hw : 1;
+  if (n_threads > N) n_threads = N;
+  b->n_threads = n_threads;
+  b->generation = 0; b->pending = 0; b->stop = false;
+  const size_t w8[11] = {(size_t)h.nq, (size_t)h.nv, (size_t)h.nu, (size_t)h.nu, 3, 3, 3, 3, 3, 4, 3};
+  size_t o = 0;
+  auto put = [&](int k, size_t bytes) { b->off[k] = o; o = (o + bytes + 15) & ~(size_t)15; };
+  for (int k = 0; k < 11; ++k) put(k, sizeof(double) * N * w8[k]);
+  put(A_NCON, sizeof(int32_t) * N);
+  put(A_G1, sizeof(int32_t) * N * C);
+  put(A_G2, sizeof(int32_t) * N * C);
+  put(A_F6, sizeof(double) * N * C * 6);
+  put(A_CZ, sizeof(double) * N * C);
+  b->slab_bytes = o;
+  b->h_slab = b->d_slab = nullptr; b->h_target = b->d_target = nullptr;
+  b->d_nr = b->d_nl = nullptr; b->d_grf_r = b->d_grf_l = b->d_minz = nullptr; b->d_bad = nullptr;
+  bool ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_slab), o, hipHostMallocDefault) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&b->d_slab), o) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&b->h_target), sizeof(double) * N * h.nu, hipHostMallocDefault) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&b->d_target), sizeof(double) * N * h.nu) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&b->d_nr), sizeof(int32_t) * N) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&b->d_nl), sizeof(int32_t) * N) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&b->d_grf_r), sizeof(double) * N) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&b->d_grf_l), sizeof(double) * N) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&b->d_minz), sizeof(double) * N) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&b->d_bad), N) == hipSuccess;
+  if (!ok) {
+    oly_a3_batcher_destroy(b);
+    OLY_FAIL(ctx, OLY_ENOMEM, "oly_a3_batcher_create: allocation failed (N=%d C=%d)", N, C);
+  }
+  memset(b->h_slab, 0, o);
+  memset(b->h_target, 0, sizeof(double) * N * h.nu);
+  for (int i = 0; i < n_threads; ++i) b->workers.emplace_back(a3_worker, b, i);
+  *out = b;
+  return OLY_OK;
+}
+
+extern "C" void oly_a3_batcher_destroy(oly_a3_batcher* b) {
+  if (!b) return;
+  {
+    std::lock_guard<std::mutex> lk(b->mu);
+    b->stop = true;
+  }
+  b->cv_go.notify_all();
+  for (auto& t : b->workers) t.join();
+  if (b->h_slab) (void)hipHostFree(b->h_slab);
+  if (b->d_slab) (void)hipFree(b->d_slab);
+  if (b->h_target) (void)hipHostFree(b->h_target);
+  if (b->d_target) (void)hipFree(b->d_target);
+  for (void* p : {(void*)b->d_nr, (void*)b->d_nl, (void*)b->d_grf_r, (void*)b->d_grf_l, (void*)b->d_minz, (void*)b->d_bad})
+    if (p) (void)hipFree(p);
+  delete b;
+}
+
+extern "C" int oly_a3_batcher_slots(oly_a3_batcher* b, int env, oly_a3_readback* rb) {
+  if (!b || !rb || env < 0 || env >= b->N) return OLY_EINVAL;
+  a3_slots(b, b->h_slab, env, rb);
+  return OLY_OK;
+}
+
+extern "C" int oly_a3_batcher_upload(oly_a3_batcher* b, oly_stream stream) {
+  if (!b) return OLY_EINVAL;
+  OLY_HIP(b->ctx, hipMemcpyAsync(b->d_slab, b->h_slab, b->slab_bytes, hipMemcpyHostToDevice, oly_s(stream)));
+  return OLY_OK;
+}
+
+extern "C" int oly_a3_batcher_last_timing(const oly_a3_batcher* b, double out3[3]) {
+  if (!b || !out3) return OLY_EINVAL;
+  for (int i = 0; i < 3; ++i) out3[i] = b->timing[i];
+  return OLY_OK;
+}
+
+extern "C" int oly_a3_batcher_step(oly_a3_batcher* b, const float* action, const oly_a3_state* st, void* obs,
+                                   float* rew6, float* reward, uint8_t* done, int out_flags, int with_physics,
+                                   oly_stream stream) {
+  if (!b) return OLY_EINVAL;
+  oly_ctx* ctx = b->ctx;
+  if (!st || !obs || !rew6 || !reward || !done || (with_physics && !action))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_batcher_step: NULL pointer");
+  hipStream_t s = oly_s(stream);
+  const double t0 = now_s();
+  double t1 = t0, t2 = t0;
+  if (with_physics) {
+    int rc = oly_a3_pd_target(ctx, b->N, action, b->d_target, stream);
+    if (rc) return rc;
+    OLY_HIP(ctx, hipMemcpyAsync(b->h_target, b->d_target, sizeof(double) * b->N * b->nu, hipMemcpyDeviceToHost, s));
+    OLY_HIP(ctx, hipStreamSynchronize(s));
+    t1 = now_s();
+    {
+      std::unique_lock<std::mutex> lk(b->mu);
+      b->pending = b->n_threads;
+      ++b->generation;
+      b->cv_go.notify_all();
+      b->cv_done.wait(lk, [&] { return b->pending == 0; });
+    }
+    t2 = now_s();
+  }
+  OLY_HIP(ctx, hipMemcpyAsync(b->d_slab, b->h_slab, b->slab_bytes, hipMemcpyHostToDevice, s));
+  oly_a3_readback rb;
+  a3_slots(b, b->d_slab, 0, &rb);  // device addresses of the arrays (env 0 = base)
+  int rc = oly_contact_reduce(ctx, b->N, b->C, rb.ncon, rb.geom1, rb.geom2, rb.force6, rb.cpos_z, b->d_nr, b->d_nl,
+                              nullptr, nullptr, b->d_grf_r, b->d_grf_l, b->d_minz, b->d_bad, stream);
+  if (rc) return rc;
+  oly_a3_inputs in;
+  in.qpos = rb.qpos; in.qvel = rb.qvel; in.act_len = rb.act_len; in.act_vel = rb.act_vel;
+  in.lf_pos = rb.lf_pos; in.rf_pos = rb.rf_pos; in.lf_vel = rb.lf_vel; in.rf_vel = rb.rf_vel;
+  in.root_pos = rb.root_pos; in.root_quat = rb.root_quat; in.head_pos = rb.head_pos;
+  in.grf_l = b->d_grf_l; in.grf_r = b->d_grf_r; in.min_z = b->d_minz; in.n_r = b->d_nr; in.n_l = b->d_nl;
+  in.bad = b->d_bad;
+  rc = oly_a3_step(ctx, b->N, &in, st, obs, rew6, reward, done, out_flags, stream);
+  const double t3 = now_s();
+  b->timing[0] = t1 - t0; b->timing[1] = t2 - t1; b->timing[2] = t3 - t2;
+  return rc;
+}

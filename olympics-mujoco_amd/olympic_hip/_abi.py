@@ -55,6 +55,21 @@ class A3State(C.Structure):
     _fields_ = [(n, vp) for n in A3_STATE_FIELDS]
 
 
+# oly_a3_readback: per-env slots of the pinned staging (11 double arrays, ncon/geom1/geom2 int32, force6, cpos_z)
+A3_READBACK_FIELDS = (("qpos", C.c_double), ("qvel", C.c_double), ("act_len", C.c_double), ("act_vel", C.c_double),
+                      ("lf_pos", C.c_double), ("rf_pos", C.c_double), ("lf_vel", C.c_double), ("rf_vel", C.c_double),
+                      ("root_pos", C.c_double), ("root_quat", C.c_double), ("head_pos", C.c_double),
+                      ("ncon", C.c_int32), ("geom1", C.c_int32), ("geom2", C.c_int32), ("force6", C.c_double),
+                      ("cpos_z", C.c_double))
+
+
+class A3Readback(C.Structure):
+    _fields_ = [(n, C.POINTER(t)) for n, t in A3_READBACK_FIELDS]
+
+
+A3_PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(A3Readback), vp)
+
+
 # name -> (restype, argtypes); device/host pointers are void*.
 STD_SCALAR, STD_PER_DIM, STD_FULL = 0, 1, 2
 
@@ -77,6 +92,12 @@ SIGNATURES = {
     "oly_batcher_set_prev": (C.c_int, [vp, vp, vp]),
     "oly_batcher_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "oly_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "oly_a3_batcher_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "oly_a3_batcher_destroy": (None, [vp]),
+    "oly_a3_batcher_slots": (C.c_int, [vp, C.c_int, C.POINTER(A3Readback)]),
+    "oly_a3_batcher_upload": (C.c_int, [vp, vp]),
+    "oly_a3_batcher_step": (C.c_int, [vp, vp, C.POINTER(A3State), vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "oly_a3_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "oly_traj_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "oly_traj_reset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "oly_traj_next": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),

@@ -78,3 +78,84 @@ class HostBatcher:
             self.close()
         except Exception:
             pass
+
+
+class A3HostBatcher:
+    """C++ batcher of the RL robot (oly_a3_batcher_*): N StickFigureA3 environments whose physics
+    (frame_skip PD substeps + readback) runs in a host thread pool and whose post-physics path
+    (oly_contact_reduce -> oly_a3_step) runs on the device, one H2D copy per step.
+
+    `physics(env, target [nu], slots)` fills `slots` - a dict of numpy views of that env's pinned
+    staging rows (qpos, qvel, act_len, act_vel, lf_pos, rf_pos, lf_vel, rf_vel, root_pos, root_quat,
+    head_pos, ncon [1], geom1 [C], geom2 [C], force6 [C,6], cpos_z [C]).  A MuJoCo build passes a C
+    function pointer instead."""
+
+    def __init__(self, engine, num_envs, max_contacts, physics, n_threads=0, obs_f64=False):
+        if engine.a3_spec is None:
+            raise OlyError("A3HostBatcher needs an engine with a3_configure() and contact_configure() done")
+        self.eng, self.N, self.C, self.obs_f64 = engine, int(num_envs), int(max_contacts), obs_f64
+        sp = engine.a3_spec
+        self.spec = sp
+        widths = dict(qpos=sp.nq, qvel=sp.nv, act_len=sp.nu, act_vel=sp.nu, lf_pos=3, rf_pos=3, lf_vel=3, rf_vel=3,
+                      root_pos=3, root_quat=4, head_pos=3, ncon=1, geom1=self.C, geom2=self.C, force6=6 * self.C,
+                      cpos_z=self.C)
+        self._widths = widths
+
+        def views(rb):
+            out = {n: np.ctypeslib.as_array(getattr(rb, n), (widths[n],)) for n, _ in _abi.A3_READBACK_FIELDS}
+            out["force6"] = out["force6"].reshape(self.C, 6)
+            return out
+
+        def tramp(env, target, rb, user):
+            physics(env, np.ctypeslib.as_array(target, (sp.nu,)), views(rb.contents))
+        self._views = views
+        self._cb = _abi.A3_PHYSICS_FN(tramp)
+        self._h = C.c_void_p()
+        check(engine.ctx.handle, lib().oly_a3_batcher_create(C.byref(self._h), engine.ctx.handle, self.N, self.C,
+                                                             int(n_threads), C.cast(self._cb, C.c_void_p), None),
+              "oly_a3_batcher_create")
+        dev = engine.device
+        self.obs = torch.empty((self.N, sp.n_obs), dtype=torch.float64 if obs_f64 else torch.float32, device=dev)
+        self.rew6 = torch.empty((self.N, 6), dtype=torch.float32, device=dev)
+        self.reward = torch.empty(self.N, dtype=torch.float32, device=dev)
+        self.done = torch.empty(self.N, dtype=torch.uint8, device=dev)
+
+    def slots(self, env):
+        """numpy views of env's pinned staging rows (write a reset state here, then upload())."""
+        rb = _abi.A3Readback()
+        check(self.eng.ctx.handle, lib().oly_a3_batcher_slots(self._h, int(env), C.byref(rb)), "oly_a3_batcher_slots")
+        return self._views(rb)
+
+    def upload(self):
+        check(self.eng.ctx.handle, lib().oly_a3_batcher_upload(self._h, self.eng._s()), "oly_a3_batcher_upload")
+
+    def step(self, action, state, with_physics=True):
+        """state: dict of device tensors named as oly_a3_state (updated in place).
+        -> (obs, reward, done, rew6) device tensors owned by the batcher."""
+        sp = self.spec
+        if with_physics and (not isinstance(action, torch.Tensor) or action.device != self.eng.device
+                             or action.dtype != torch.float32 or tuple(action.shape) != (self.N, sp.nu)
+                             or not action.is_contiguous()):
+            raise OlyError("action must be a contiguous float32 device tensor of shape [N, nu]")
+        st = self.eng.a3_state_struct(state, self.N)
+        rc = lib().oly_a3_batcher_step(self._h, ptr(action) if with_physics else None, C.byref(st), ptr(self.obs),
+                                       ptr(self.rew6), ptr(self.reward), ptr(self.done),
+                                       _abi.OUT_OBS_F64 if self.obs_f64 else 0, int(bool(with_physics)), self.eng._s())
+        check(self.eng.ctx.handle, rc, "oly_a3_batcher_step")
+        return self.obs, self.reward, self.done, self.rew6
+
+    def last_timing(self):
+        t = (C.c_double * 3)()
+        lib().oly_a3_batcher_last_timing(self._h, t)
+        return dict(target_d2h_s=t[0], physics_s=t[1], h2d_kernels_enqueue_s=t[2])
+
+    def close(self):
+        if self._h:
+            lib().oly_a3_batcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -231,6 +231,12 @@ class Engine:
             setattr(st, name, t.data_ptr())
         return st
 
+    def a3_state_struct(self, state, N):
+        """oly_a3_state filled with the (validated) device tensors of `state`."""
+        if self.a3_spec is None:
+            raise OlyError("a3 state before a3_configure")
+        return self._a3_struct(_abi.A3State, self._A3_ST, state, N)
+
     def a3_step(self, inputs, state, obs_f64=False, out=None):
         sp = self.a3_spec
         if sp is None:

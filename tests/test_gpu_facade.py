@@ -650,3 +650,58 @@ def test_examples_run(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "examples", "vail_discriminator_step.py"), "--num_envs", "256",
                         "--steps", "20"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "discriminator reward mean" in r.stdout and " std 1.0000" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_a3_host_batcher_replays_golden_sequence(golden):
+    """oly_a3_batcher_*: host thread pool + pinned staging + one H2D copy + K3 + K2 per step.  A
+    Python physics callback plays the fixture's recorded readback (what a MuJoCo callback would
+    write after its PD substeps) and checks the PD targets it receives; results equal the
+    reference's WalkingTask / get_obs outputs."""
+    from olympic_hip.a3 import VecA3Env, ReplayA3Physics
+    from olympic_hip.batcher import A3HostBatcher
+    from olympic_hip.engine import Engine
+    g = golden("a3_task.npz")
+    E, K = g["phase"].shape
+    sp = specs.A3Spec(mass=float(g["mass"]))
+    eng = Engine(0)
+    env = VecA3Env(sp, E, eng, ReplayA3Physics({"qpos": torch.zeros((1, E, 25), dtype=torch.float64, device="cuda")}),
+                   g["geom_bodyid"], int(g["floor_body"]), int(g["rfoot_body"]), int(g["lfoot_body"]))
+    for e in range(E):
+        np.random.seed(1000 + e)
+        env.iteration_count = int(g["iter_count"][e])
+        env.reset_task([e], g["reset_lfoot"][e:e + 1], g["reset_rfoot"][e:e + 1], g["reset_root_quat"][e:e + 1])
+    C_ = g["geom1"].shape[-1]
+    step_no = {"k": 0}
+    seen_targets = np.zeros((E, 12))
+
+    def physics(e, target, slots):
+        k = step_no["k"]
+        seen_targets[e] = target
+        for n in ("qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel", "rf_vel", "root_pos", "root_quat",
+                  "head_pos", "geom1", "geom2", "force6", "cpos_z"):
+            slots[n][...] = g[n][e, k]
+        slots["ncon"][0] = g["ncon"][e, k]
+    b = A3HostBatcher(eng, E, C_, physics, n_threads=2, obs_f64=True)
+    act = torch.zeros((E, 12), device="cuda")
+    for k in range(K):
+        step_no["k"] = k
+        obs, rew, done, rew6 = b.step(act, env.state)
+        torch.cuda.synchronize()
+        assert np.array_equal(seen_targets, np.tile(sp.motor_offset, (E, 1)))        # zero action -> offsets
+        assert np.array_equal(env.state["phase"].cpu().numpy(), g["phase"][:, k])
+        assert np.array_equal(done.cpu().numpy().astype(bool), g["done"][:, k])
+        np.testing.assert_allclose(obs.cpu().numpy(), g["obs"][:, k], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(rew.cpu().numpy(), g["reward"][:, k], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(rew6.cpu().numpy(), g["rew6"][:, k], rtol=2e-6, atol=1e-7)
+    t = b.last_timing()
+    assert t["physics_s"] > 0 and t["h2d_kernels_enqueue_s"] > 0
+    # slots() / upload() / with_physics=False: evaluate a hand-written state without stepping the physics
+    s0 = b.slots(0)
+    assert s0["qpos"].shape == (25,) and s0["force6"].shape == (C_, 6)
+    keep = {k2: v.clone() for k2, v in env.state.items()}
+    b.upload()
+    o2, *_ = b.step(None, env.state, with_physics=False)
+    assert np.isfinite(o2.cpu().numpy()).all()
+    for k2, v in keep.items():
+        env.state[k2].copy_(v)
+    b.close()
