@@ -220,6 +220,8 @@ void a3_slots(const oly_a3_batcher* b, unsigned char* base, int e, oly_a3_readba
   rb->force6 = d(A_F6, 6 * b->C); rb->cpos_z = d(A_CZ, b->C);
 }
 
+void a3_hold_state(int, const double*, const oly_a3_readback*, void*) {}
+
 void a3_worker(oly_a3_batcher* b, int id) {
   long seen = 0;
   const int per = (b->N + b->n_threads - 1) / b->n_threads;
@@ -251,13 +253,14 @@ extern "C" int oly_a3_batcher_create(oly_a3_batcher** out, oly_ctx* ctx, int N, 
   *out = nullptr;
   if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_batcher_create before oly_a3_configure");
   if (!ctx->contact_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_batcher_create before oly_contact_configure");
-  if (N <= 0 || C <= 0 || n_threads < 0 || !physics)
-    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_batcher_create: bad N, C, n_threads or NULL physics");
+  if (N <= 0 || C <= 0 || n_threads < 0)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_batcher_create: bad N, C or n_threads");
   OLY_HIP(ctx, hipSetDevice(ctx->device));
   oly_a3_batcher* b = new (std::nothrow) oly_a3_batcher();
   if (!b) return OLY_ENOMEM;
   const A3Dev& h = ctx->a3_host;
-  b->ctx = ctx; b->N = N; b->C = C; b->nq = h.nq; b->nv = h.nv; b->nu = h.nu; b->fn = physics; b->user = user;
+  b->ctx = ctx; b->N = N; b->C = C; b->nq = h.nq; b->nv = h.nv; b->nu = h.nu; b->user = user;
+  b->fn = physics ? physics : a3_hold_state;   // NULL: the staging is left as written (framework-overhead runs)
   unsigned hw = std::thread::hardware_concurrency();
   if (n_threads == 0) n_threads = hw ? (int)hw : 1;
   if (n_threads > N) n_threads = N;

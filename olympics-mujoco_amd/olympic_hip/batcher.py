@@ -109,10 +109,11 @@ class A3HostBatcher:
         def tramp(env, target, rb, user):
             physics(env, np.ctypeslib.as_array(target, (sp.nu,)), views(rb.contents))
         self._views = views
-        self._cb = _abi.A3_PHYSICS_FN(tramp)
+        self._cb = _abi.A3_PHYSICS_FN(tramp) if physics is not None else None
         self._h = C.c_void_p()
         check(engine.ctx.handle, lib().oly_a3_batcher_create(C.byref(self._h), engine.ctx.handle, self.N, self.C,
-                                                             int(n_threads), C.cast(self._cb, C.c_void_p), None),
+                                                             int(n_threads),
+                                                             C.cast(self._cb, C.c_void_p) if self._cb else None, None),
               "oly_a3_batcher_create")
         dev = engine.device
         self.obs = torch.empty((self.N, sp.n_obs), dtype=torch.float64 if obs_f64 else torch.float32, device=dev)

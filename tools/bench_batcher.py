@@ -43,6 +43,42 @@ def main():
                                             split_us={k: v / K * 1e6 for k, v in acc.items()},
                                             pcie_bytes_per_step=N * (8 * 11 + 8 * 34))
             b.close()
+    # RL robot: PD target down, the whole StickFigureA3 readback (1788 B per env at C = 16) up, K3 + K2
+    import numpy as np
+    from olympic_hip.batcher import A3HostBatcher
+    a3 = specs.A3Spec(mass=41.5)
+    eng.a3_configure(a3, np.zeros((4, a3.period)))
+    eng.contact_configure(np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32), 0, 7, 10)
+    for N in (4096, 32768):
+        b = A3HostBatcher(eng, N, 16, None, n_threads=16)
+        rng = np.random.default_rng(0)
+        for e in range(0, N, max(1, N // 64)):                  # a few populated envs; the rest stay zero
+            sl = b.slots(e)
+            sl["root_quat"][:] = [1, 0, 0, 0]
+            sl["ncon"][0] = 3
+            sl["geom2"][:3] = [7, 11, 8]
+            sl["force6"][:3] = rng.normal(0, 100, (3, 6))
+        z = lambda dt, *sh: torch.zeros((N,) + sh, dtype=dt, device="cuda")
+        st = dict(phase=z(torch.int32), t1=z(torch.int32), t2=z(torch.int32) + 1, reached_frames=z(torch.int32),
+                  target_reached=z(torch.uint8), mode=z(torch.int32) + 2, seq_len=z(torch.int32) + 20,
+                  sequence=z(torch.float64, 20, 4), goal=z(torch.float64, 8))
+        a = torch.zeros((N, 12), device="cuda")
+        for _ in range(20):
+            b.step(a, st)
+        torch.cuda.synchronize()
+        K = 300
+        t0 = time.perf_counter()
+        acc = dict(target_d2h_s=0.0, physics_s=0.0, h2d_kernels_enqueue_s=0.0)
+        for _ in range(K):
+            b.step(a, st)
+            for k, v in b.last_timing().items():
+                acc[k] += v
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"A3_N{N}_threads16"] = dict(us_per_vec_step=dt / K * 1e6, env_steps_per_s=N * K / dt,
+                                         split_us={k: v / K * 1e6 for k, v in acc.items()},
+                                         pcie_bytes_per_step=N * (8 * 12 + 1788))
+        b.close()
     print(json.dumps(out, indent=1))
 
 
