@@ -25,6 +25,13 @@ struct oly_batcher {
   void* user;
   double *h_qpos, *h_qvel, *h_ctrl;        // pinned host
   double *d_qpos, *d_qvel, *d_ctrl, *d_prev;  // device
+  // use_foot_forces: W substep contact snapshots per env
+  int W, C;
+  oly_physics_contacts_fn cfn;
+  void* cuser;
+  unsigned char *h_con, *d_con;            // one slab: ncon [W,N] | geom1 [W,N,C] | geom2 | force6 [W,N,C,6]
+  size_t con_bytes, off_g1, off_g2, off_f6;
+  double* d_grf;                           // [N, n_grf] window mean
   // thread pool
   std::vector<std::thread> workers;
   std::mutex mu;
@@ -44,6 +51,22 @@ void kinematic_step(int, const double*, double* qpos, double* qvel, void* user) 
 }
 
 void run_range(oly_batcher* b, int lo, int hi) {
+  if (b->cfn) {
+    const size_t N = (size_t)b->N, C = (size_t)b->C;
+    for (int e = lo; e < hi; ++e) {
+      oly_il_contacts oc;
+      oc.W = b->W; oc.C = b->C;
+      oc.ncon = reinterpret_cast<int32_t*>(b->h_con) + e; oc.ncon_stride = (long)N;
+      oc.geom1 = reinterpret_cast<int32_t*>(b->h_con + b->off_g1) + (size_t)e * C;
+      oc.geom2 = reinterpret_cast<int32_t*>(b->h_con + b->off_g2) + (size_t)e * C;
+      oc.geom_stride = (long)(N * C);
+      oc.force6 = reinterpret_cast<double*>(b->h_con + b->off_f6) + (size_t)e * C * 6;
+      oc.force_stride = (long)(N * C * 6);
+      b->cfn(e, b->h_ctrl + (size_t)e * b->nu, b->h_qpos + (size_t)e * b->nq, b->h_qvel + (size_t)e * b->nv, &oc,
+             b->cuser);
+    }
+    return;
+  }
   void* user = b->fn == kinematic_step ? static_cast<void*>(b) : b->user;
   for (int e = lo; e < hi; ++e)
     b->fn(e, b->h_ctrl + (size_t)e * b->nu, b->h_qpos + (size_t)e * b->nq, b->h_qvel + (size_t)e * b->nv, user);
@@ -94,6 +117,7 @@ extern "C" int oly_batcher_create(oly_batcher** out, oly_ctx* ctx, int N, int n_
   b->generation = 0; b->pending = 0; b->stop = false;
   b->h_qpos = b->h_qvel = b->h_ctrl = nullptr;
   b->d_qpos = b->d_qvel = b->d_ctrl = b->d_prev = nullptr;
+  b->W = b->C = 0; b->cfn = nullptr; b->cuser = nullptr; b->h_con = b->d_con = nullptr; b->d_grf = nullptr;
   const size_t sq = sizeof(double) * N * b->nq, sv = sizeof(double) * N * b->nv, sc = sizeof(double) * N * b->nu;
   bool ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_qpos), sq, hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc(reinterpret_cast<void**>(&b->h_qvel), sv, hipHostMallocDefault) == hipSuccess &&
@@ -128,7 +152,36 @@ extern "C" void oly_batcher_destroy(oly_batcher* b) {
   if (b->d_qvel) (void)hipFree(b->d_qvel);
   if (b->d_ctrl) (void)hipFree(b->d_ctrl);
   if (b->d_prev) (void)hipFree(b->d_prev);
+  if (b->h_con) (void)hipHostFree(b->h_con);
+  if (b->d_con) (void)hipFree(b->d_con);
+  if (b->d_grf) (void)hipFree(b->d_grf);
   delete b;
+}
+
+extern "C" int oly_batcher_enable_contacts(oly_batcher* b, int W, int C, oly_physics_contacts_fn physics, void* user) {
+  if (!b) return OLY_EINVAL;
+  oly_ctx* ctx = b->ctx;
+  if (W <= 0 || C <= 0 || !physics) OLY_FAIL(ctx, OLY_EINVAL, "oly_batcher_enable_contacts: bad W, C or NULL physics");
+  if (!ctx->grf_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_batcher_enable_contacts before oly_grf_configure");
+  if (ctx->il_host.n_grf != 3 * ctx->grf.n_pairs)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_batcher_enable_contacts: model n_grf=%d but %d sensor pairs", ctx->il_host.n_grf,
+             ctx->grf.n_pairs);
+  if (b->h_con) OLY_FAIL(ctx, OLY_EINVAL, "oly_batcher_enable_contacts: already enabled");
+  OLY_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)b->N;
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  b->off_g1 = al(sizeof(int32_t) * W * N);
+  b->off_g2 = al(b->off_g1 + sizeof(int32_t) * W * N * C);
+  b->off_f6 = al(b->off_g2 + sizeof(int32_t) * W * N * C);
+  b->con_bytes = al(b->off_f6 + sizeof(double) * W * N * C * 6);
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_con), b->con_bytes, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_con), b->con_bytes) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_grf), sizeof(double) * N * ctx->il_host.n_grf) != hipSuccess)
+    OLY_FAIL(ctx, OLY_ENOMEM, "oly_batcher_enable_contacts: allocation failed");
+  memset(b->h_con, 0, b->con_bytes);
+  b->W = W; b->C = C; b->cuser = user;
+  b->cfn = physics;   // workers read cfn under the step's generation hand-shake only
+  return OLY_OK;
 }
 
 extern "C" double* oly_batcher_qpos(oly_batcher* b) { return b ? b->h_qpos : nullptr; }
@@ -172,7 +225,19 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
   // (3) state rows up, post-physics path on the device
   OLY_HIP(ctx, hipMemcpyAsync(b->d_qpos, b->h_qpos, sizeof(double) * b->N * b->nq, hipMemcpyHostToDevice, s));
   OLY_HIP(ctx, hipMemcpyAsync(b->d_qvel, b->h_qvel, sizeof(double) * b->N * b->nv, hipMemcpyHostToDevice, s));
-  rc = oly_il_step(ctx, 1, b->N, b->d_qpos, b->d_qvel, nullptr, nullptr, b->d_prev, b->d_prev, obs, reward,
+  const double* grf = nullptr;
+  if (b->cfn) {
+    OLY_HIP(ctx, hipMemcpyAsync(b->d_con, b->h_con, b->con_bytes, hipMemcpyHostToDevice, s));
+    rc = oly_il_ground_forces(ctx, b->W, b->N, b->C, reinterpret_cast<const int32_t*>(b->d_con),
+                              reinterpret_cast<const int32_t*>(b->d_con + b->off_g1),
+                              reinterpret_cast<const int32_t*>(b->d_con + b->off_g2),
+                              reinterpret_cast<const double*>(b->d_con + b->off_f6), nullptr, b->d_grf, stream);
+    if (rc) return rc;
+    grf = b->d_grf;
+  } else if (ctx->il_host.n_grf > 0) {
+    OLY_FAIL(ctx, OLY_ENOTCONF, "oly_batcher_step: the model has foot-force columns; call oly_batcher_enable_contacts");
+  }
+  rc = oly_il_step(ctx, 1, b->N, b->d_qpos, b->d_qvel, nullptr, grf, b->d_prev, b->d_prev, obs, reward,
                    absorbing, fall_code, nullptr, out_flags & ~OLY_OUT_CTRL_F64, stream);
   const double t3 = now_s();
   b->timing[0] = t1 - t0; b->timing[1] = t2 - t1; b->timing[2] = t3 - t2;

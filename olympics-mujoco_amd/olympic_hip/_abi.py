@@ -67,6 +67,14 @@ class A3Readback(C.Structure):
     _fields_ = [(n, C.POINTER(t)) for n, t in A3_READBACK_FIELDS]
 
 
+class IlContacts(C.Structure):
+    _fields_ = [("W", C.c_int), ("C", C.c_int), ("ncon", C.POINTER(C.c_int32)), ("ncon_stride", C.c_long),
+                ("geom1", C.POINTER(C.c_int32)), ("geom2", C.POINTER(C.c_int32)), ("geom_stride", C.c_long),
+                ("force6", C.POINTER(C.c_double)), ("force_stride", C.c_long)]
+
+
+PHYSICS_CONTACTS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(IlContacts), vp)
 A3_PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(A3Readback), vp)
 
 
@@ -92,6 +100,7 @@ SIGNATURES = {
     "oly_batcher_set_prev": (C.c_int, [vp, vp, vp]),
     "oly_batcher_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "oly_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "oly_batcher_enable_contacts": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "oly_a3_batcher_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "oly_a3_batcher_destroy": (None, [vp]),
     "oly_a3_batcher_slots": (C.c_int, [vp, C.c_int, C.POINTER(A3Readback)]),

@@ -44,6 +44,31 @@ class HostBatcher:
         self.absorbing = torch.empty(self.N, dtype=torch.uint8, device=dev)
         self.fall_code = torch.empty(self.N, dtype=torch.uint8, device=dev)
 
+    def enable_contacts(self, n_intermediate, max_contacts, physics):
+        """use_foot_forces: `physics(env, ctrl, qpos, qvel, con)` performs the control step's W
+        intermediate steps and writes contact snapshot w into con["ncon"][w], con["geom1"][w, i],
+        con["geom2"][w, i], con["force6"][w, i, :] (numpy views of the pinned staging)."""
+        sp = self.spec
+        nq, nv, nu = sp.nq, sp.nv, sp.nu
+        W, Cc = int(n_intermediate), int(max_contacts)
+        ast = np.lib.stride_tricks.as_strided
+
+        def tramp(env, ctrl, qpos, qvel, oc, user):
+            o = oc.contents
+            n = np.ctypeslib.as_array(o.ncon, ((W - 1) * o.ncon_stride + 1,))
+            g1 = np.ctypeslib.as_array(o.geom1, ((W - 1) * o.geom_stride + Cc,))
+            g2 = np.ctypeslib.as_array(o.geom2, ((W - 1) * o.geom_stride + Cc,))
+            f6 = np.ctypeslib.as_array(o.force6, ((W - 1) * o.force_stride + 6 * Cc,))
+            con = dict(ncon=ast(n, (W,), (4 * o.ncon_stride,)), geom1=ast(g1, (W, Cc), (4 * o.geom_stride, 4)),
+                       geom2=ast(g2, (W, Cc), (4 * o.geom_stride, 4)),
+                       force6=ast(f6, (W, Cc, 6), (8 * o.force_stride, 48, 8)))
+            physics(env, np.ctypeslib.as_array(ctrl, (nu,)), np.ctypeslib.as_array(qpos, (nq,)),
+                    np.ctypeslib.as_array(qvel, (nv,)), con)
+        self._ccb = _abi.PHYSICS_CONTACTS_FN(tramp)
+        rc = lib().oly_batcher_enable_contacts(self._h, W, Cc, C.cast(self._ccb, C.c_void_p), None)
+        check(self.eng.ctx.handle, rc, "oly_batcher_enable_contacts")
+        return self
+
     def set_prev(self, prev):
         """Write the carried reward state (the reset observation's value) for every env."""
         t = torch.as_tensor(prev, dtype=torch.float64, device=self.eng.device).contiguous()

@@ -705,3 +705,46 @@ def test_a3_host_batcher_replays_golden_sequence(golden):
     for k2, v in keep.items():
         env.state[k2].copy_(v)
     b.close()
+
+
+def test_host_batcher_with_foot_force_contacts(oracle):
+    """IL batcher with use_foot_forces: the physics callback writes W = 10 contact snapshots per
+    env and control step; obs = [joint obs, window-mean ground forces / 1000]."""
+    from olympic_hip.batcher import HostBatcher
+    from olympic_hip.engine import Engine
+    sp = specs.unitree_h1("walk").with_foot_forces("UnitreeH1")
+    eng = Engine(0).il_configure(sp)
+    N, W, Cc, K = 96, 10, 8, 4
+    rng = np.random.default_rng(6)
+    qpos, qvel, act = h1_synthetic_block(sp, K, N, seed=2, fall_frac="wide")
+    con = dict(ncon=rng.integers(0, Cc + 1, (K, W, N)).astype(np.int32),
+               geom1=np.zeros((K, W, N, Cc), np.int32),
+               geom2=rng.choice([12, 22, 5, 30], size=(K, W, N, Cc)).astype(np.int32),
+               force6=rng.normal(0, 300, (K, W, N, Cc, 6)))
+    step = {"k": 0}
+
+    def physics(e, ctrl, q, v, c):
+        k = step["k"]
+        q[:], v[:] = qpos[k, e], qvel[k, e]
+        c["ncon"][:] = con["ncon"][k, :, e]
+        c["geom1"][:] = con["geom1"][k, :, e]
+        c["geom2"][:] = con["geom2"][k, :, e]
+        c["force6"][:] = con["force6"][k, :, e]
+    b = HostBatcher(eng, N, n_threads=2, obs_f64=True)
+    with pytest.raises(Exception, match="oly_batcher_enable_contacts"):
+        b.step(torch.zeros((N, sp.n_act), device="cuda"))           # foot-force model without contact staging
+    eng.grf_configure(sp.geom_group, sp.grf_pairs)
+    b.enable_contacts(W, Cc, physics)
+    prev = rng.normal(1.25, 0.3, N)
+    b.set_prev(prev)
+    means = np.stack([oracle.il_ground_forces(sp.geom_group, sp.grf_pairs, con["ncon"][k], con["geom1"][k],
+                                              con["geom2"][k], con["force6"][k])[1] for k in range(K)])
+    ref = oracle.il_step(sp, qpos, qvel, None, prev, grf_mean=means, obs_f64=True)
+    for k in range(K):
+        step["k"] = k
+        obs, rew, ab = b.step(torch.as_tensor(act[k]).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(obs.cpu().numpy(), ref["obs"][k])
+        assert np.array_equal(ab.cpu().numpy(), ref["absorbing"][k])
+        assert ulp_diff(rew.cpu().numpy(), ref["reward"][k]).max() <= 1
+    b.close()

@@ -212,7 +212,7 @@ def test_struct_layouts_match_the_header():
     """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
     import tempfile
     fields = {"oly_il_model": _abi.IlModel, "oly_a3_model": _abi.A3Model, "oly_a3_inputs": _abi.A3Inputs,
-              "oly_a3_state": _abi.A3State, "oly_a3_readback": _abi.A3Readback}
+              "oly_a3_state": _abi.A3State, "oly_a3_readback": _abi.A3Readback, "oly_il_contacts": _abi.IlContacts}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/olympic_hip.h"', "int main(){"]
     for cname, cls in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
