@@ -199,7 +199,7 @@ def main():
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "il_tile_kernel<128,%s>" % args.robot if args.robot not in ("h1_arms", "h1_ff") else
+                         "kernel": "il_tile_kernel<128,%s>" % args.robot if args.robot != "__dyn__" else
                                    "il_dyn_tile_kernel (runtime shape)", "kernel_ms": kern_ms,
                          "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
         }

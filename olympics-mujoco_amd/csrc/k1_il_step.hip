@@ -980,6 +980,7 @@ using AtlasDims = StaticDims<16, 16, 0, 10, 10, 30>;   // Atlas, arms + back rem
 using TalosDims = StaticDims<18, 18, 0, 12, 12, 34>;   // Talos, arms removed (default)
 using H1FFDims = StaticDims<17, 17, 6, 11, 11, 38>;    // UnitreeH1, use_foot_forces=True
 using TalosFFDims = StaticDims<18, 18, 6, 12, 12, 40>; // Talos, use_foot_forces=True
+using H1ArmsDims = StaticDims<25, 25, 0, 19, 19, 48>;  // UnitreeH1, disable_arms=False
 
 template <int ROWS, class D>
 int launch_generic(oly_ctx* ctx, IlArgs a, long tile0, int out_flags, hipStream_t s) {
@@ -1191,6 +1192,7 @@ extern "C" int oly_il_step(oly_ctx* ctx, int T, int N, const double* qpos, const
   if (fast_ok && shape(18, 12, 34)) OLY_K1_FAST(TalosDims, 128);
   if (fast_ok && shape(17, 11, 38, 6)) OLY_K1_FAST(H1FFDims, 128);
   if (fast_ok && shape(18, 12, 40, 6)) OLY_K1_FAST(TalosFFDims, 128);
+  if (fast_ok && shape(25, 19, 48)) OLY_K1_FAST(H1ArmsDims, 128);
 #undef OLY_K1_FAST
   static const int dyn_env = [] { const char* e = getenv("OLY_K1_DYN_TILE"); return e ? atoi(e) : 1; }();
   if (dyn_env) return launch_dyn(ctx, a, out_flags, oly_s(stream));

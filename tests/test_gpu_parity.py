@@ -1115,18 +1115,25 @@ def test_no_kernel_writes_outside_its_outputs(golden, N):
         gd.close()
 
 
-@pytest.mark.parametrize("robot", ["UnitreeH1", "Talos"])
-def test_foot_force_robots_static_fast_path(eng, oracle, robot):
-    """use_foot_forces=True H1 / Talos take the compile-time-shape tile kernel: obs (incl. the
-    mean_grf / 1000 columns), flags, ctrl bit-exact over several tiles per workgroup."""
-    sp = (specs.unitree_h1("walk") if robot == "UnitreeH1" else specs.talos("walk")).with_foot_forces(robot)
+@pytest.mark.parametrize("robot", ["UnitreeH1+ff", "Talos+ff", "UnitreeH1+arms"])
+def test_other_static_fast_paths(eng, oracle, robot):
+    """use_foot_forces=True H1 / Talos and H1 with arms take compile-time-shape instantiations of
+    the tile kernel: obs (incl. the mean_grf / 1000 columns), flags, ctrl bit-exact over several
+    tiles per workgroup."""
+    if robot == "UnitreeH1+arms":
+        sp = specs.unitree_h1("walk", disable_arms=False)
+        assert (sp.nq, sp.n_act, sp.n_obs) == (25, 19, 48)
+    else:
+        name = robot.split("+")[0]
+        sp = (specs.unitree_h1("walk") if name == "UnitreeH1" else specs.talos("walk")).with_foot_forces(name)
     T, N = 5, 3000
     rng = np.random.default_rng(8)
     q, v, a = h1_synthetic_block(sp, T, N, seed=21, fall_frac="wide")
-    grf = rng.normal(0, 400, (T, N, sp.n_grf))
+    grf = rng.normal(0, 400, (T, N, sp.n_grf)) if sp.n_grf else None
     prev = rng.normal(1.25, 0.3, N)
     for f64 in (False, True):
-        o = _run_il(eng, sp, q, v, a, prev, grf_mean=dev(grf), obs_f64=f64, ctrl_f64=f64)
+        o = _run_il(eng, sp, q, v, a, prev, obs_f64=f64, ctrl_f64=f64, **({"grf_mean": dev(grf)} if sp.n_grf else {}))
         ref = oracle.il_step(sp, q, v, a, prev, grf_mean=grf, obs_f64=f64, ctrl_f64=f64)
         _cmp_il(o, ref, f64)
-    assert np.array_equal(o["obs"][..., -sp.n_grf:], grf / 1000.0)
+    if sp.n_grf:
+        assert np.array_equal(o["obs"][..., -sp.n_grf:], grf / 1000.0)
