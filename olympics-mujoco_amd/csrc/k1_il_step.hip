@@ -981,6 +981,12 @@ using TalosDims = StaticDims<18, 18, 0, 12, 12, 34>;   // Talos, arms removed (d
 using H1FFDims = StaticDims<17, 17, 6, 11, 11, 38>;    // UnitreeH1, use_foot_forces=True
 using TalosFFDims = StaticDims<18, 18, 6, 12, 12, 40>; // Talos, use_foot_forces=True
 using H1ArmsDims = StaticDims<25, 25, 0, 19, 19, 48>;  // UnitreeH1, disable_arms=False
+// the remaining (disable_arms, disable_back_joint) combinations of the three robots
+using H1ArmsNoBackDims = StaticDims<24, 24, 0, 18, 18, 46>;
+using AtlasBackDims = StaticDims<19, 19, 0, 13, 13, 36>;
+using ArmsNoBack28Dims = StaticDims<28, 28, 0, 22, 22, 54>;   // Atlas / Talos with arms, back removed
+using AtlasFullDims = StaticDims<31, 31, 0, 25, 25, 60>;
+using TalosFullDims = StaticDims<30, 30, 0, 24, 24, 58>;
 
 template <int ROWS, class D>
 int launch_generic(oly_ctx* ctx, IlArgs a, long tile0, int out_flags, hipStream_t s) {
@@ -1193,6 +1199,11 @@ extern "C" int oly_il_step(oly_ctx* ctx, int T, int N, const double* qpos, const
   if (fast_ok && shape(17, 11, 38, 6)) OLY_K1_FAST(H1FFDims, 128);
   if (fast_ok && shape(18, 12, 40, 6)) OLY_K1_FAST(TalosFFDims, 128);
   if (fast_ok && shape(25, 19, 48)) OLY_K1_FAST(H1ArmsDims, 128);
+  if (fast_ok && shape(24, 18, 46)) return launch_fast<128, H1ArmsNoBackDims>(ctx, a, out_flags, wg_env, oly_s(stream));
+  if (fast_ok && shape(19, 13, 36)) return launch_fast<128, AtlasBackDims>(ctx, a, out_flags, wg_env, oly_s(stream));
+  if (fast_ok && shape(28, 22, 54)) return launch_fast<128, ArmsNoBack28Dims>(ctx, a, out_flags, wg_env, oly_s(stream));
+  if (fast_ok && shape(31, 25, 60)) return launch_fast<128, AtlasFullDims>(ctx, a, out_flags, wg_env, oly_s(stream));
+  if (fast_ok && shape(30, 24, 58)) return launch_fast<128, TalosFullDims>(ctx, a, out_flags, wg_env, oly_s(stream));
 #undef OLY_K1_FAST
   static const int dyn_env = [] { const char* e = getenv("OLY_K1_DYN_TILE"); return e ? atoi(e) : 1; }();
   if (dyn_env) return launch_dyn(ctx, a, out_flags, oly_s(stream));

@@ -1137,3 +1137,17 @@ def test_other_static_fast_paths(eng, oracle, robot):
         _cmp_il(o, ref, f64)
     if sp.n_grf:
         assert np.array_equal(o["obs"][..., -sp.n_grf:], grf / 1000.0)
+
+
+@pytest.mark.parametrize("robot", ["unitree_h1", "atlas", "talos"])
+@pytest.mark.parametrize("arms,back", [(True, True), (True, False), (False, True), (False, False)])
+def test_every_robot_configuration(eng, oracle, robot, arms, back):
+    """All (disable_arms, disable_back_joint) combinations of the three robots have their own
+    compile-time-shape instantiation of the tile kernel: each against the oracle."""
+    sp = getattr(specs, robot)("walk", disable_arms=arms, disable_back_joint=back)
+    T, N = 3, 1500
+    q, v, a = h1_synthetic_block(sp, T, N, seed=31, fall_frac="wide")
+    prev = np.random.default_rng(1).normal(1.25, 0.3, N)
+    for f64 in (False, True):
+        o = _run_il(eng, sp, q, v, a, prev, obs_f64=f64, ctrl_f64=f64)
+        _cmp_il(o, oracle.il_step(sp, q, v, a, prev, obs_f64=f64, ctrl_f64=f64), f64)
