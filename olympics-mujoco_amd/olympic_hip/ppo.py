@@ -137,6 +137,19 @@ class FusedMirrorLoss(torch.autograd.Function):
         return None, g * gd, g * gm, None, None
 
 
+_GRAPH_STREAMS = {}
+
+
+def _graph_streams(device):
+    """One warm-up stream and one capture stream per device, reused by every capture: PyTorch keeps a
+    BLAS workspace per (handle, stream) for the life of the process, so a fresh stream per capture
+    (the default of torch.cuda.graph) leaks ~76 MB each time."""
+    key = torch.device(device).index or 0
+    if key not in _GRAPH_STREAMS:
+        _GRAPH_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _GRAPH_STREAMS[key]
+
+
 class GraphedUpdate:
     """One PPO minibatch update (fused losses -> backward -> grad clip -> Adam on actor and
     critic) captured once as a HIP graph and replayed per minibatch: at the reference's
@@ -182,14 +195,14 @@ class GraphedUpdate:
             opts[1].step()
             return torch.stack([a_l.detach(), ent.detach(), c_l.detach(), kl.detach(), m_l.detach().reshape(()),
                                 clipf.detach()])
-        side = torch.cuda.Stream(device=dev)
+        side, cap = _graph_streams(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 body()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=cap):
             self.stats = body()
         for m, sd in zip(nets, keep):                         # warm-up steps must not count as training
             m.load_state_dict(sd)
@@ -201,6 +214,13 @@ class GraphedUpdate:
                             v.copy_(saved[p][k])
                         else:
                             v.zero_()
+
+    def close(self):
+        """Release the captured graph and its private memory pool now (not at the next GC pass)."""
+        if self.graph is not None:
+            self.graph.reset()
+            self.graph = None
+        self.stats = None
 
     def __call__(self, observations, actions, returns, advantages, idx):
         torch.index_select(observations, 0, idx, out=self.obs)
@@ -233,15 +253,21 @@ class GraphedActorCritic:
             finally:
                 torch.distributions.Distribution.set_default_validate_args(validate)
         with torch.no_grad():
-            side = torch.cuda.Stream(device=device)
+            side, cap = _graph_streams(device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
                 for _ in range(warmup):
                     body()
             torch.cuda.current_stream(device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=cap):
                 self.mu, self.scale, self.value = body()
+
+    def close(self):
+        if self.graph is not None:
+            self.graph.reset()
+            self.graph = None
+        self.mu = self.scale = self.value = None
 
     def __call__(self, state):
         self.state.copy_(state)
@@ -321,6 +347,8 @@ class PPO:
                 next_state = torch.where(cut.unsqueeze(1), fresh, next_state)
                 action, value = ac(next_state)                    # reset envs start from a new state
             state = next_state
+        if hasattr(ac, "close"):
+            ac.close()
         return buf
 
     # ------------------------------------------------------------------ losses
@@ -431,8 +459,9 @@ class PPO:
                     if graphed is not None:
                         every = getattr(self, "graph_recapture_every", None)     # test hook: fresh graph every k replays
                         if every and len(stats) and len(stats) % every == 0:
-                            graphed = GraphedUpdate(self, env.eng, minibatch, observations.shape[1], actions.shape[1],
-                                                    obs_mirr, act_src, act_sign)
+                            old, graphed = graphed, GraphedUpdate(self, env.eng, minibatch, observations.shape[1],
+                                                                  actions.shape[1], obs_mirr, act_src, act_sign)
+                            old.close()
                         stats.append(graphed(observations, actions, returns, advantages, idx).clone())
                         continue
                     if fused:
@@ -458,6 +487,10 @@ class PPO:
                     stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), float(clipf)))
             if stats and torch.is_tensor(stats[0]):
                 stats = torch.stack(stats).cpu().tolist()      # one device->host copy per iteration
+            if graphed is not None:
+                for p_ in list(policy.parameters()) + list(critic.parameters()):
+                    p_.grad = None                             # gradients live in the graph's pool
+                graphed.close()
             del graphed
             ep_ret, ep_len = buf.episode_stats()
             mean_ret = float(np.mean(ep_ret)) if ep_ret else 0.0
