@@ -184,6 +184,81 @@ __global__ __launch_bounds__(THREADS) void ppo_loss_kernel(PpoArgs p, int RB) {
   block_partials<5>(v, p.ws);
 }
 
+// A % 4 == 0, A <= 16, 16-B aligned rows: one lane owns one row in REGISTERS (A4 float4 loads per
+// array, float4 gradient stores), no LDS staging, no barriers in the row loop.  Same arithmetic in
+// the same order as ppo_loss_kernel.
+template <int A4>
+__global__ __launch_bounds__(THREADS) void ppo_loss_rows_kernel(PpoArgs p) {
+  constexpr int A = 4 * A4;
+  const float lo = 1.0f - p.clip, hi = 1.0f + p.clip;
+  const float invB = 1.0f / (float)p.B;
+  double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const bool sc = p.sd_mode == OLY_STD_SCALAR, osc = p.old_sd_mode == OLY_STD_SCALAR;
+  const float sd0 = sc ? p.sd[0] : 1.0f, osd0 = osc ? p.old_sd[0] : 1.0f;
+  const float lsd0 = logf(sd0), losd0 = logf(osd0), v20 = 2.0f * (sd0 * sd0), ov20 = 2.0f * (osd0 * osd0);
+  const long stride = (long)gridDim.x * THREADS;
+  for (long row = (long)blockIdx.x * THREADS + threadIdx.x; row < p.B; row += stride) {
+    float m[A], om[A], ac[A];
+    const float4* m4 = reinterpret_cast<const float4*>(p.mu) + row * A4;
+    const float4* o4 = reinterpret_cast<const float4*>(p.old_mu) + row * A4;
+    const float4* a4 = reinterpret_cast<const float4*>(p.action) + row * A4;
+#pragma unroll
+    for (int q = 0; q < A4; ++q) {
+      const float4 x = m4[q], y = o4[q], z = a4[q];
+      m[4 * q] = x.x; m[4 * q + 1] = x.y; m[4 * q + 2] = x.z; m[4 * q + 3] = x.w;
+      om[4 * q] = y.x; om[4 * q + 1] = y.y; om[4 * q + 2] = y.z; om[4 * q + 3] = y.w;
+      ac[4 * q] = z.x; ac[4 * q + 1] = z.y; ac[4 * q + 2] = z.z; ac[4 * q + 3] = z.w;
+    }
+    float lp = 0.0f, olp = 0.0f, ent = 0.0f;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      const float sd = sc ? sd0 : sd_at(p.sd, p.sd_mode, row, A, j);
+      const float osd = osc ? osd0 : sd_at(p.old_sd, p.old_sd_mode, row, A, j);
+      const float lsd = sc ? lsd0 : logf(sd), losd = osc ? losd0 : logf(osd);
+      const float v2 = sc ? v20 : 2.0f * (sd * sd), ov2 = osc ? ov20 : 2.0f * (osd * osd);
+      const float t = ac[j] - m[j], ot = ac[j] - om[j];
+      lp += -(t * t) / v2 - lsd - LOG_SQRT_2PI;
+      olp += -(ot * ot) / ov2 - losd - LOG_SQRT_2PI;
+      ent += ENTROPY_CONST + lsd;
+    }
+    const float log_ratio = lp - olp;
+    const float ratio = expf(log_ratio);
+    const float adv = p.adv[row];
+    const float cpi = ratio * adv;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float cl = rc * adv;
+    v[0] += (double)fminf(cpi, cl);
+    v[1] += (double)ent;
+    const float rt = p.ret[row], vl = p.value[row];
+    const float dv = rt - vl;
+    v[2] += (double)(dv * dv);
+    v[3] += (double)((ratio - 1.0f) - log_ratio);
+    v[4] += (fabsf(ratio - 1.0f) > p.clip) ? 1.0 : 0.0;
+    if (p.grad_value) p.grad_value[row] = p.vf_coeff * 2.0f * (vl - rt) * invB;
+    const float inr = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    const float w = cpi < cl ? 1.0f : (cpi == cl ? 0.5f + 0.5f * inr : inr);
+    const float g_lp = -invB * adv * w * ratio;
+    if (p.grad_mu || p.grad_sd) {
+      float gm[A], gs[A];
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        const float sd = sc ? sd0 : sd_at(p.sd, p.sd_mode, row, A, j);
+        const float t = ac[j] - m[j];
+        gm[j] = g_lp * t / (sd * sd);
+        gs[j] = g_lp * (t * t / (sd * sd * sd) - 1.0f / sd);
+      }
+#pragma unroll
+      for (int q = 0; q < A4; ++q) {
+        if (p.grad_mu)
+          reinterpret_cast<float4*>(p.grad_mu)[row * A4 + q] = make_float4(gm[4 * q], gm[4 * q + 1], gm[4 * q + 2], gm[4 * q + 3]);
+        if (p.grad_sd)
+          reinterpret_cast<float4*>(p.grad_sd)[row * A4 + q] = make_float4(gs[4 * q], gs[4 * q + 1], gs[4 * q + 2], gs[4 * q + 3]);
+      }
+    }
+  }
+  block_partials<5>(v, p.ws);
+}
+
 inline int blocks_for(long n, int cap) {
   long b = (n + THREADS - 1) / THREADS;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -239,6 +314,21 @@ extern "C" int oly_ppo_loss(oly_ctx* ctx, int B, int A, const float* mu, const f
   const int nb = (int)(ntiles > OLY_STATS_MAX_BLOCKS ? OLY_STATS_MAX_BLOCKS : ntiles);
   PpoArgs p{B, A, mu, sd, old_mu, old_sd, action, adv, ret, value, sd_mode, old_sd_mode, clip, vf_coeff,
             grad_mu, grad_sd, grad_value, ctx->stats_ws};
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if ((A & 3) == 0 && A <= 16 && al16(mu) && al16(old_mu) && al16(action) && al16(grad_mu) && al16(grad_sd)) {
+    const int nbr = blocks_for(B, OLY_STATS_MAX_BLOCKS);
+    switch (A / 4) {
+      case 1: hipLaunchKernelGGL(ppo_loss_rows_kernel<1>, dim3(nbr), dim3(THREADS), 0, oly_s(stream), p); break;
+      case 2: hipLaunchKernelGGL(ppo_loss_rows_kernel<2>, dim3(nbr), dim3(THREADS), 0, oly_s(stream), p); break;
+      case 3: hipLaunchKernelGGL(ppo_loss_rows_kernel<3>, dim3(nbr), dim3(THREADS), 0, oly_s(stream), p); break;
+      default: hipLaunchKernelGGL(ppo_loss_rows_kernel<4>, dim3(nbr), dim3(THREADS), 0, oly_s(stream), p); break;
+    }
+    const double invBr = 1.0 / (double)B, invBAr = 1.0 / ((double)B * A);
+    hipLaunchKernelGGL(finish_kernel<5>, dim3(1), dim3(64), 0, oly_s(stream), nbr, ctx->stats_ws, scal_out,
+                       -invBr, -invBAr, (double)vf_coeff * invBr, invBr, invBr);
+    OLY_LAUNCH_CHECK(ctx, "ppo loss kernels");
+    return OLY_OK;
+  }
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nb), dim3(THREADS), need, oly_s(stream), p, rb);
   const double invB = 1.0 / (double)B, invBA = 1.0 / ((double)B * A);
   hipLaunchKernelGGL(finish_kernel<5>, dim3(1), dim3(64), 0, oly_s(stream), nb, ctx->stats_ws, scal_out,

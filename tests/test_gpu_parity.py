@@ -761,7 +761,8 @@ def _ppo_case(rng, B, A, mode):
     return mu, std, old_mu, old_std, action, adv, ret, value
 
 
-@pytest.mark.parametrize("B,A,mode", [(64, 12, 0), (1, 3, 1), (5000, 12, 2), (777, 64, 1), (300000, 11, 0)])
+@pytest.mark.parametrize("B,A,mode", [(64, 12, 0), (1, 3, 1), (5000, 12, 2), (777, 64, 1), (300000, 11, 0),
+                                      (4097, 16, 1), (100, 4, 0), (1000, 8, 2), (300001, 12, 0)])
 def test_ppo_loss_vs_oracle(eng, oracle, B, A, mode):
     """Tolerance: device expf/logf vs libm are within 1-2 ulp per element; the sums are fp64 on
     both sides -> 2e-5 relative on the loss terms, 1e-4 relative (1e-9 absolute) on gradients."""
