@@ -56,6 +56,12 @@ __global__ __launch_bounds__(THREADS) void obs_filter4_kernel(long total4, int D
                                                               const double* __restrict__ mean,
                                                               const double* __restrict__ var, double eps,
                                                               double clip, float4* __restrict__ out) {
+  __shared__ double s_den[OLY_MAX_OBS], s_mean[OLY_MAX_OBS];   // sqrt(var + eps) once per column, not per element
+  for (int j = threadIdx.x; j < 4 * D4; j += THREADS) {
+    s_den[j] = sqrt(var[j] + eps);
+    s_mean[j] = mean[j];
+  }
+  __syncthreads();
   const long stride = (long)gridDim.x * THREADS;
   long e = (long)blockIdx.x * THREADS + threadIdx.x;
   if (e >= total4) return;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(THREADS) void obs_filter4_kernel(long total4, int D
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      double t = ((double)in[k] - mean[j + k]) / sqrt(var[j + k] + eps);
+      double t = ((double)in[k] - s_mean[j + k]) / s_den[j + k];
       if (clip > 0.0) t = fmin(fmax(t, -clip), clip);
       o[k] = (float)t;
     }
@@ -148,7 +154,7 @@ extern "C" int oly_obs_filter(oly_ctx* ctx, int B, int D, const float* x, const 
   if (B < 0 || D <= 0 || !mean || !var || (B > 0 && (!x || !out)))
     OLY_FAIL(ctx, OLY_EINVAL, "oly_obs_filter: bad argument");
   if (B == 0) return OLY_OK;
-  if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+  if ((D & 3) == 0 && D <= OLY_MAX_OBS && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
     const long total4 = (long)B * (D / 4);
     hipLaunchKernelGGL(obs_filter4_kernel, dim3(blocks_for(total4)), dim3(THREADS), 0, oly_s(stream), total4, D / 4,
                        reinterpret_cast<const float4*>(x), mean, var, eps, clip, reinterpret_cast<float4*>(out));
