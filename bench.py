@@ -168,6 +168,24 @@ def main():
     rows = T * N
     fallen = float(out["absorbing"].float().mean().item())
 
+    # "also report against a measured device-copy bandwidth on the box": a plain
+    # device-to-device copy of a buffer the size of this launch's traffic (read + write counted),
+    # outside the timed region, on the same stream with the same timer
+    copy_gbps = None
+    if rank == 0:
+        nbytes = 404 * 1024 * 1024
+        src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        ctimer = HipTimer()
+        ctimer.start(stream)
+        for _ in range(20):
+            dst.copy_(src)
+        ctimer.stop(stream)
+        copy_gbps = 2 * nbytes * 20 / (ctimer.elapsed_ms() * 1e-3) / 1e9
+        del src, dst
+
     if rank == 0:
         bpr = alg_bytes_per_row(spec, args.fall_code)
         achieved = bpr * rows / (kern_ms * 1e-3) / 1e9
@@ -199,6 +217,7 @@ def main():
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
                          "kernel": "il_tile_kernel<128,%s>" % args.robot if args.robot != "__dyn__" else
                                    "il_dyn_tile_kernel (runtime shape)", "kernel_ms": kern_ms,
                          "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
