@@ -257,7 +257,10 @@ def test_adv_stats_allgather_two_ranks_gloo(tmp_path):
     all-gather, both ranks normalise with the same global statistics = the single-process
     result (PPO ddof 1 / 1e-5 and GAIL ddof 0 / 1e-8)."""
     script = os.path.join(ROOT, "tests", "_dist_worker.py")
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:                      # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(tmp_path)],
                          capture_output=True, text=True, timeout=300)
