@@ -2,21 +2,28 @@
 """Headline benchmark: env-steps/sec of the post-physics hot path for 4096 UnitreeH1.walk
 environments per GPU (BASELINE.json configs[1]).
 
-One "step" = one launch of the fused K1+K5 kernel (obs build + has-fallen + previous-obs
-reward + action scale/clamp) over one [T=400, N=4096] block of synthetic qpos/qvel/action
-already resident in HBM = 1 638 400 env-steps.  Launch regime: [T,N] block per launch (a
-single vec step at N=4096 moves 2 MB and is launch-latency-bound).
-
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|5]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  Environments shard across ranks with no data-path
-collective (weak scaling: every rank owns its own 4096 envs); the barriers bracketing the
-timed region are the only communication.
+--config 2 (default, the BASELINE metric): one "step" = one launch of the fused K1+K5 kernel (obs
+    build + has-fallen + previous-obs reward + action scale/clamp) over one [T=400, N=4096] block of
+    synthetic qpos/qvel/action already resident in HBM = 1 638 400 env-steps.  Launch regime: [T,N]
+    block per launch.  Environments shard across ranks with no data-path collective (weak scaling);
+    the barriers bracketing the timed region are the only communication.  The line also carries a
+    `per_step` block: the single-vec-step regime (one launch / one HIP graph per env.step()).
+--config 5 (BASELINE.json configs[4]): one "step" = one PPO iteration tail per rank on a
+    [T=400, N=4096] shard: K6 return scan (advantage statistics fused into the same pass) -> ONE
+    all-gather of (count, sum, sumsq) = 24 B per rank (RCCL over xGMI) -> K7 normalisation that adds
+    the rank triples on the device (rl/algos/ppo.py:200-230 merge + :335-336).
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this script starts the N rank processes
+itself (the parent never touches a GPU), relays rank 0's JSON line and fails if any rank fails.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,12 +33,149 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5])
+    ap.add_argument("--T", type=int, default=400)
+    ap.add_argument("--N", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-per-step", action="store_true", help="skip the single-vec-step block of config 2")
+    ap.add_argument("--fall-code", action="store_true", help="also write the fall-code byte")
+    ap.add_argument("--robot", default="h1", choices=["h1", "atlas", "talos", "h1_arms", "h1_ff"],
+                    help="h1 is the BASELINE config; the others exercise the same kernel on other tables")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to "
+                         "rehearse the multi-rank path on a one-GPU box)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------ launcher
+def spawn_ranks(args):
+    """Parent of a multi-rank run: starts `--gpus` children of this same script, one per GPU, with the
+    torch.distributed environment set; never initialises a GPU itself and never exec()s."""
+    import socket
+    if args.share_device and args.backend != "gloo":
+        print("--share-device needs --backend gloo (RCCL refuses two ranks on one GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    if any(rcs):
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    return 0
+
+
+class Ranks:
+    """torch.distributed plumbing of one rank (world 1: no process group at all)."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = args.backend
+        self.dist = None
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group("gloo")
+            self.dist = dist
+        if self.world != args.gpus and self.rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={self.world}", file=sys.stderr)
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        w = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(w, op=self.dist.ReduceOp.MAX)
+        return float(w.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_region(rk, stream, warmup, steps, step):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides.
+    Returns (wall seconds, max over ranks; HIP-event ms per step on the kernels' stream)."""
+    from olympic_hip._ffi import HipTimer
+    torch = rk.torch
+    for i in range(warmup):
+        step(i)
+    timer = HipTimer()
+    rk.barrier()
+    t0 = time.perf_counter()
+    timer.start(stream())
+    for i in range(steps):
+        step(i)
+    timer.stop(stream())
+    torch.cuda.synchronize(rk.dev)
+    rk.barrier()
+    wall = time.perf_counter() - t0
+    return rk.max_over_ranks(wall), timer.elapsed_ms() / max(steps, 1)
+
+
+def event_ms(stream, reps, fn):
+    """Average HIP-event time of `fn()` over `reps` back-to-back calls on `stream()`."""
+    from olympic_hip._ffi import HipTimer
+    for _ in range(3):
+        fn()
+    t = HipTimer()
+    t.start(stream())
+    for _ in range(reps):
+        fn()
+    t.stop(stream())
+    return t.elapsed_ms() / reps
+
+
+def copy_bandwidth(rk, stream):
+    """"also report against a measured device-copy bandwidth on the box": a plain
+    device-to-device copy of a buffer the size of the headline launch's traffic (read + write counted)."""
+    torch = rk.torch
+    nbytes = 404 * 1024 * 1024
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=rk.dev).normal_()
+    dst = torch.empty_like(src)
+    ms = event_ms(stream, 20, lambda: dst.copy_(src))
+    return 2 * nbytes / (ms * 1e-3) / 1e9
+
+
+# ------------------------------------------------------------------------------------ config 2
 def alg_bytes_per_row(spec, fall_code):
     """Algorithmic HBM bytes per (step, env) row of K1+K5, each array counted once:
     qpos + qvel (f64) + action (f32) in; obs (f32) + reward (f32) + absorbing (u8) + ctrl (f32)
@@ -41,9 +185,10 @@ def alg_bytes_per_row(spec, fall_code):
             + (1 if fall_code else 0))
 
 
-def cpu_baseline(spec, seconds=12.0):
+def cpu_baseline_config2(spec, seconds=12.0):
     """The CPU oracle (C port of the reference path, parity-pinned to golden vectors) on a
     bounded sample of the same workload, all host cores."""
+    import numpy as np
     from oracle import oracle as orc
     from olympic_hip.synthetic import h1_synthetic_block
     T, N = 50, 4096
@@ -69,54 +214,64 @@ def cpu_baseline(spec, seconds=12.0):
                       f"H1 block, repeated for ~{seconds:.0f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--T", type=int, default=400)
-    ap.add_argument("--N", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fall-code", action="store_true", help="also write the fall-code byte")
-    ap.add_argument("--robot", default="h1", choices=["h1", "atlas", "talos", "h1_arms", "h1_ff"],
-                    help="h1 is the BASELINE config; the others exercise the same kernel on other tables")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to "
-                         "rehearse the multi-rank path on a one-GPU box)")
-    ap.add_argument("--share-device", action="store_true",
-                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
-    args = ap.parse_args()
+def per_step_block(rk, eng, spec, N):
+    """The regime the reference API runs: ONE vec step per policy forward (rl/algos/ppo.py:169-196).
+    (a) H1: one K1+K5 launch over [1,N] per env.step(), eager and replayed from a HIP graph;
+    (b) config 3 (StickFigureA3 PPO sampling): everything between two policy forwards as ONE fused
+        launch, the whole vec step (actor + critic forward, Gaussian sample from pre-drawn noise,
+        env kernel, buffer stores, device-side resets) as ONE HIP graph replay.
+    Wall clock over back-to-back steps, HIP-synchronised at both ends."""
+    import torch
+    from olympic_hip.synthetic import h1_synthetic_block
+    out = {}
+    qpos_h, qvel_h, act_h = h1_synthetic_block(spec, 1, N, seed=99)
+    qpos, qvel, act = (torch.as_tensor(a).to(rk.dev) for a in (qpos_h, qvel_h, act_h))
+    prev = torch.full((N,), 1.25, dtype=torch.float64, device=rk.dev)
+    call, _ = eng.il_step_prepare(qpos, qvel, act, prev, want_fall_code=False)
+    reps = 2000
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.share_device:
-        local_rank = 0
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
-    else:
-        dist = None
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    def wall_us(fn):
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize(rk.dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(rk.dev)
+        return 1e6 * (time.perf_counter() - t0) / reps
+    us = wall_us(call)
+    out["h1_eager_launch"] = {"us_per_vec_step": us, "env_steps_per_s": N / (us * 1e-6), "launches_per_step": 1}
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=rk.dev)
+    side.wait_stream(torch.cuda.current_stream(rk.dev))
+    with torch.cuda.stream(side):
+        call()
+    torch.cuda.current_stream(rk.dev).wait_stream(side)
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(10):
+            call()
+    us10 = wall_us(g.replay) / 10
+    out["h1_graph_of_10_steps"] = {"us_per_vec_step": us10, "env_steps_per_s": N / (us10 * 1e-6),
+                                   "launches_per_step": 1, "note": "ten consecutive vec steps per graph replay"}
+    try:
+        from olympic_hip.vecstep import bench_config3_sampling
+        out["config3_a3_ppo_sampling"] = bench_config3_sampling(eng, N, rk.dev)
+    except ImportError:
+        pass
+    return out
 
+
+def bench_config2(args, rk):
+    import torch
     from olympic_hip import specs
-    from olympic_hip._ffi import HipTimer
     from olympic_hip.engine import Engine
     from olympic_hip.synthetic import h1_synthetic_block
-
+    dev, rank, world = rk.dev, rk.rank, rk.world
     spec = {"h1": lambda: specs.unitree_h1("walk"), "atlas": lambda: specs.atlas("walk"),
             "talos": lambda: specs.talos("walk"),
             "h1_arms": lambda: specs.unitree_h1("walk", disable_arms=False),
             "h1_ff": lambda: specs.unitree_h1("walk").with_foot_forces("UnitreeH1")}[args.robot]()
-    eng = Engine(local_rank).il_configure(spec)
+    eng = Engine(rk.local_rank).il_configure(spec)
     T, N = args.T, args.N
     qpos_h, qvel_h, act_h = h1_synthetic_block(spec, T, N, seed=1234 + 17 * rank)
     qpos = torch.as_tensor(qpos_h).to(dev)
@@ -130,104 +285,175 @@ def main():
                ctrl=torch.empty((T, N, spec.nu), dtype=torch.float32, device=dev))
     if args.fall_code:
         out["fall_code"] = torch.empty((T, N), dtype=torch.uint8, device=dev)
-
     grf = (torch.empty((T, N, spec.n_grf), dtype=torch.float64, device=dev).normal_(0, 300) if spec.n_grf else None)
 
     def step(i):
         eng.il_step(qpos, qvel, act, prev[i & 1], prev[(i + 1) & 1], grf_mean=grf, out=out,
                     want_fall_code=args.fall_code)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            if args.backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for i in range(args.warmup):
-        step(i)
-    timer = HipTimer()
-    stream = eng.ctx.stream()
-    barrier()
-    t0 = time.perf_counter()
-    timer.start(stream)
-    for i in range(args.steps):
-        step(i)
-    timer.stop(stream)
-    torch.cuda.synchronize(dev)
-    barrier()
-    wall = time.perf_counter() - t0
-    kern_ms = timer.elapsed_ms() / max(args.steps, 1)
-
-    if dist is not None:
-        w = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
+    wall, kern_ms = timed_region(rk, eng.ctx.stream, args.warmup, args.steps, step)
     rows = T * N
     fallen = float(out["absorbing"].float().mean().item())
+    if rank != 0:
+        return None
+    copy_gbps = copy_bandwidth(rk, eng.ctx.stream)
+    bpr = alg_bytes_per_row(spec, args.fall_code)
+    achieved = bpr * rows / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_k1.json")
+    if os.path.exists(tpath) and (T, N) == (400, 4096) and not args.fall_code and args.robot == "h1":
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "env-steps/sec, 4096 UnitreeH1.walk envs per GPU, obs+reward+done+ctrl HIP kernel",
+        "value": world * rows * args.steps / wall,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * wall / max(args.steps, 1),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": ("UnitreeH1.walk config-2" if args.robot == "h1" else args.robot + ".walk") +
+                               ": fused K1+K5 over one [T,N] block per step",
+                   "T": T, "envs_per_gpu": N, "env_steps_per_step": rows * world,
+                   "launch_regime": "[T,N] block per launch", "fallen_fraction": fallen,
+                   "io": "qpos/qvel f64 + action f32 in; obs/reward/ctrl f32 + absorbing u8 out",
+                   "parallelism": f"env-sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
+                     "kernel": "il_tile_kernel<128,%s>" % args.robot, "kernel_ms": kern_ms,
+                     "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
+    }
+    if world == 1 and not args.no_per_step and args.robot == "h1":
+        line["per_step"] = per_step_block(rk, eng, spec, N)
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_config2(spec)
+    return line
 
-    # "also report against a measured device-copy bandwidth on the box": a plain
-    # device-to-device copy of a buffer the size of this launch's traffic (read + write counted),
-    # outside the timed region, on the same stream with the same timer
-    copy_gbps = None
-    if rank == 0:
-        nbytes = 404 * 1024 * 1024
-        src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
-        dst = torch.empty_like(src)
-        for _ in range(3):
-            dst.copy_(src)
-        ctimer = HipTimer()
-        ctimer.start(stream)
-        for _ in range(20):
-            dst.copy_(src)
-        ctimer.stop(stream)
-        copy_gbps = 2 * nbytes * 20 / (ctimer.elapsed_ms() * 1e-3) / 1e9
-        del src, dst
 
-    if rank == 0:
-        bpr = alg_bytes_per_row(spec, args.fall_code)
-        achieved = bpr * rows / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_k1.json")
-        if os.path.exists(tpath) and (T, N) == (400, 4096) and not args.fall_code and args.robot == "h1":
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "env-steps/sec, 4096 UnitreeH1.walk envs per GPU, obs+reward+done+ctrl HIP kernel",
-            "value": world * rows * args.steps / wall,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * wall / max(args.steps, 1),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": ("UnitreeH1.walk config-2" if args.robot == "h1" else args.robot + ".walk") +
-                                   ": fused K1+K5 over one [T,N] block per step",
-                       "T": T, "envs_per_gpu": N, "env_steps_per_step": rows * world,
-                       "launch_regime": "[T,N] block per launch", "fallen_fraction": fallen,
-                       "io": "qpos/qvel f64 + action f32 in; obs/reward/ctrl f32 + absorbing u8 out",
-                       "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
-                         "kernel": "il_tile_kernel<128,%s>" % args.robot if args.robot != "__dyn__" else
-                                   "il_dyn_tile_kernel (runtime shape)", "kernel_ms": kern_ms,
-                         "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(spec)
+# ------------------------------------------------------------------------------------ config 5
+def cpu_baseline_config5(T, N, seconds=10.0):
+    import numpy as np
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    r = rng.uniform(-0.3, 1.0, (T, N))
+    v, nv = (rng.normal(0, 1, (T, N)).astype(np.float32) for _ in range(2))
+    fl = ((rng.uniform(size=(T, N)) < 1 / 300) * 2).astype(np.uint8)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        _, adv = orc.return_scan_r64(0.99, r, v, nv, fl)
+        orc.adv_normalize(adv, orc.adv_stats(adv), 1, 1e-5)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": reps * T * N / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle return scan (f64 rewards) + statistics + normalisation on one [T={T},N={N}] shard, "
+                      f"1 thread, repeated for ~{seconds:.0f} s"}
+
+
+def bench_config5(args, rk):
+    """K6 (+ fused statistics) -> all-gather of 3 doubles per rank -> K7 normalise, per rank on its own
+    [T,N] shard of the N*world environments (rl/algos/ppo.py:200-230,335-336)."""
+    import torch
+    from olympic_hip import _abi, dist as odist
+    from olympic_hip.engine import Engine
+    dev, rank, world = rk.dev, rk.rank, rk.world
+    eng = Engine(rk.local_rank)
+    T, N = args.T, args.N
+    g = torch.Generator(device=dev).manual_seed(500 + rank)
+    rew = torch.empty((T, N), dtype=torch.float64, device=dev).uniform_(-0.3, 1.0, generator=g)
+    val = torch.empty((T, N), dtype=torch.float32, device=dev).normal_(0, 1, generator=g)
+    nval = torch.empty((T, N), dtype=torch.float32, device=dev).normal_(0, 1, generator=g)
+    last = torch.rand((T, N), device=dev, generator=g) < 1 / 300
+    absorb = last & (torch.rand((T, N), device=dev, generator=g) < 0.5)
+    flags = (last.to(torch.uint8) * _abi.FLAG_LAST) | (absorb.to(torch.uint8) * _abi.FLAG_ABSORBING)
+    ret = torch.empty((T, N), dtype=torch.float32, device=dev)
+    adv = torch.empty((T, N), dtype=torch.float32, device=dev)
+    st = torch.zeros(3, dtype=torch.float64, device=dev)
+
+    def scan():
+        eng.return_scan(_abi.SCAN_RETURN, 0.99, 0.95, rew, val, nval, flags, ret, adv, stats3=st)
+
+    def gather():
+        return odist.gather_stats(st)
+
+    def step(i):
+        scan()
+        eng.adv_normalize(adv, gather(), 1, 1e-5)
+
+    wall, ms_step = timed_region(rk, eng.ctx.stream, args.warmup, args.steps, step)
+    # stage breakdown, outside the timed region: each stage alone, back to back, HIP events
+    reps = max(20, min(args.steps, 200))
+    ms_scan = event_ms(eng.ctx.stream, reps, scan)
+    parts = gather()
+    ms_norm = event_ms(eng.ctx.stream, reps, lambda: eng.adv_normalize(adv, parts, 1, 1e-5))
+    rk.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gather()
+    torch.cuda.synchronize(dev)
+    ms_gather = 1e3 * (time.perf_counter() - t0) / reps
+    ms_gather = rk.max_over_ranks(ms_gather)
+    # the all-gathered triples are identical on every rank, their tree sum is the global statistic
+    tot = odist.tree_sum(parts)
+    assert float(tot[0]) == float(T * N * world), (float(tot[0]), T * N * world)
+    if rank != 0:
+        return None
+    elems = T * N
+    b_scan, b_norm = 21, 8         # f64 reward 8 + value 4 + next value 4 + flag 1 in, ret 4 + adv 4 out | adv in + out
+    line = {
+        "metric": "env-steps/sec through the PPO iteration tail (return scan + advantage statistics + "
+                  "all-gather + normalisation), 4096 envs x 400 steps per GPU",
+        "value": world * elems * args.steps / wall,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * wall / max(args.steps, 1),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "config-5: K6 scan (statistics fused) -> all-gather 24 B/rank -> K7 normalise, "
+                               "one [T,N] shard per rank",
+                   "T": T, "envs_per_gpu": N, "envs_total": N * world, "backend": rk.backend if world > 1 else None,
+                   "rewards": "f64 (un-narrowed, as env.step returns them)",
+                   "parallelism": f"env-sharded x{world}, one all-gather of 3 doubles per rank per step"},
+        "stages_ms": {"scan_with_fused_stats": ms_scan, "all_gather_host_wall": ms_gather, "normalise": ms_norm,
+                      "whole_step_hip_events": ms_step},
+        "roofline": {"bound": "hbm", "achieved": (b_scan + b_norm) * elems / ((ms_scan + ms_norm) * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (b_scan + b_norm) * elems / ((ms_scan + ms_norm) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "scan_pipe_kernel + normalize_kernel",
+                     "alg_bytes_per_element": {"scan": b_scan, "normalise": b_norm,
+                                               "note": "SURVEY 8(d) prices K6 at 17 B (f32 rewards) and K7 at 12 B (a "
+                                                       "separate statistics pass, 4 B, which the fused scan no longer makes)"},
+                     "scan_GBps": b_scan * elems / (ms_scan * 1e-3) / 1e9,
+                     "normalise_GBps": b_norm * elems / (ms_norm * 1e-3) / 1e9,
+                     "elements_per_launch": elems},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_config5(T, N)
+    return line
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    rk = Ranks(args)
+    line = (bench_config5 if args.config == 5 else bench_config2)(args, rk)
+    if rk.rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        barrier()
-        dist.destroy_process_group()
+    rk.close()
 
 
 if __name__ == "__main__":

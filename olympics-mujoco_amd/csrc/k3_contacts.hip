@@ -38,7 +38,8 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
   for (long base = wave * 4; base < N; base += nwaves * 4) {
     const long n = base + grp;
     const bool env_ok = n < N;
-    const int nc = env_ok ? min(max(ncon[n], 0), C) : 0;
+    const int nc_raw = env_ok ? ncon[n] : 0;
+    const int nc = min(max(nc_raw, 0), C);
     int cnt_r = 0, cnt_l = 0;
     double sum_r = 0.0, sum_l = 0.0, mz = 0.0;
     bool have = false;
@@ -101,7 +102,10 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
         grf_r[n] = sum_r;
         grf_l[n] = sum_l;
         min_z[n] = have ? mz : 0.0;
-        bad[n] = (uint8_t)((cnt_r + cnt_l) != nc);
+        // against the RAW count: an environment with more contacts than the C staged slots (or a
+        // negative count) cannot be reduced faithfully, so it is reported as a bad collision
+        // instead of silently dropping the surplus (check_bad_collisions iterates all data.ncon)
+        bad[n] = (uint8_t)((cnt_r + cnt_l) != nc_raw);
       }
     }
   }

@@ -24,21 +24,25 @@ namespace {
 constexpr int TT = 64;          // time steps per tile
 constexpr int SCAN_THREADS = 256;
 
-template <int MODE>
+template <int MODE, bool REW64>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(int T, int N, double gamma, double lam,
-                                                                 const float* __restrict__ rew,
+                                                                 const void* __restrict__ rew_,
                                                                  const float* __restrict__ val,
                                                                  const float* __restrict__ next_val,
                                                                  const uint8_t* __restrict__ flags,
                                                                  float* __restrict__ ret,
                                                                  float* __restrict__ adv) {
-  __shared__ float s_r[TT][64], s_v[TT][64], s_nv[TT][64];
+  using rew_t = typename std::conditional<REW64, double, float>::type;
+  const rew_t* __restrict__ rew = static_cast<const rew_t*>(rew_);
+  __shared__ rew_t s_r[TT][64];
+  __shared__ float s_v[TT][64], s_nv[TT][64];
   __shared__ uint8_t s_f[TT][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
   const bool env_ok = n < N;
   constexpr int RPW = TT / 4;  // rows per wave per tile
-  float pr[RPW], pv[RPW], pnv[RPW];
+  rew_t pr[RPW];
+  float pv[RPW], pnv[RPW];
   uint8_t pf[RPW];
   const int ntiles = (T + TT - 1) / TT;
 
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(int T, int N, d
         const int t = t_top - tt;
         if (t < 0) break;
         const size_t e = (size_t)t * N + n;
-        const float r = s_r[tt][lane], v = s_v[tt][lane], nv = s_nv[tt][lane];
+        const rew_t r = s_r[tt][lane];
+        const float v = s_v[tt][lane], nv = s_nv[tt][lane];
         const uint8_t f = s_f[tt][lane];
         if (MODE == OLY_SCAN_RETURN) {
           if (f & OLY_FLAG_LAST) {
@@ -100,10 +105,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(int T, int N, d
         } else {
           float a;
           if (f & OLY_FLAG_LAST) {
-            a = r - v;
+            a = (float)r - v;
             if (!(f & OLY_FLAG_ABSORBING)) a += g32 * nv;
           } else {
-            a = r + g32 * nv - v + gl32 * a_next;
+            a = (float)r + g32 * nv - v + gl32 * a_next;
           }
           adv[e] = a;
           ret[e] = a + v;
@@ -121,15 +126,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(int T, int N, d
 // and store ret/adv of tile k-1, all while wave 0 runs the chain of tile k.  Three LDS buffers,
 // one barrier per tile.  Same arithmetic and order as scan_lean_kernel (bit-exact).
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int NTHREADS, int DEPTH, int EPW, int PT>   // EPW envs per workgroup, PT steps per tile
+// REW64: rewards arrive as float64 (what env.step returns in the reference; RETURN mode only).
+// stats_ws != NULL: the movers also accumulate sum / sum of squares of the advantages they store
+// (fp64, fixed order) and the workgroup leaves one partial pair at stats_ws[2 * env_block].
+template <int MODE, bool REW64, int NTHREADS, int DEPTH, int EPW, int PT>   // EPW envs per workgroup, PT steps per tile
 __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, double gamma, double lam,
-                                                                 const float* __restrict__ rew,
+                                                                 const void* __restrict__ rew_,
                                                                  const float* __restrict__ val,
                                                                  const float* __restrict__ next_val,
                                                                  const uint8_t* __restrict__ flags,
                                                                  float* __restrict__ ret,
-                                                                 float* __restrict__ adv) {
+                                                                 float* __restrict__ adv,
+                                                                 double* __restrict__ stats_ws) {
   using carry_t = typename std::conditional<MODE == OLY_SCAN_RETURN, double, float>::type;
+  using rew_t = typename std::conditional<REW64, double, float>::type;
+  const rew_t* __restrict__ rew = static_cast<const rew_t*>(rew_);
   constexpr int GPR = EPW / 4;               // float4 groups per tile row
   constexpr int PIPE_GROUPS = PT * GPR;
   constexpr int PIPE_MOVERS = NTHREADS - 64;
@@ -145,13 +156,18 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
   const int tid = threadIdx.x, lane = tid & 63;
   const bool chain_wave = tid < 64;
   const int m = tid - 64;                    // mover index
-  const int n0 = blockIdx.x * EPW;
+  // XCD-aware placement: workgroups b and b + 8 share an XCD (and its L2), so give each XCD a
+  // contiguous range of environment blocks: the 64-B flag sectors that 16-env neighbours share are
+  // then fetched once per XCD instead of once per workgroup.  Speed only, any placement is correct.
+  const int nblk = gridDim.x;
+  const int eb = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int n0 = eb * EPW;
   const bool env_ok = lane < EPW && n0 + lane < N;
   const int ntiles = (T + PT - 1) / PT;
   const float g32 = (float)gamma;
   const float gl32 = (float)(gamma * lam);
 
-  struct Regs { float4 r[PIPE_SL], v[PIPE_SL], nv[PIPE_SL]; uchar4 f[PIPE_SL]; };
+  struct Regs { rew_t r[PIPE_SL][4]; float4 v[PIPE_SL], nv[PIPE_SL]; uchar4 f[PIPE_SL]; };
   Regs R[DEPTH];   // tile k travels in R[k % DEPTH]; statically indexed everywhere
 
   auto load = [&](int k, Regs& R) {
@@ -163,14 +179,21 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
       const int t = t_top - tt;
       if (g < PIPE_GROUPS && t >= 0 && n0 + 4 * c4 < N) {
         const size_t e = (size_t)t * N + n0 + 4 * c4;
-        R.r[j] = *reinterpret_cast<const float4*>(rew + e);
+        if (REW64) {
+          const double2 lo = *reinterpret_cast<const double2*>(rew + e);
+          const double2 hi = *reinterpret_cast<const double2*>(rew + e + 2);
+          R.r[j][0] = (rew_t)lo.x; R.r[j][1] = (rew_t)lo.y; R.r[j][2] = (rew_t)hi.x; R.r[j][3] = (rew_t)hi.y;
+        } else {
+          const float4 r4 = *reinterpret_cast<const float4*>(rew + e);
+          R.r[j][0] = (rew_t)r4.x; R.r[j][1] = (rew_t)r4.y; R.r[j][2] = (rew_t)r4.z; R.r[j][3] = (rew_t)r4.w;
+        }
         R.v[j] = *reinterpret_cast<const float4*>(val + e);
         R.nv[j] = *reinterpret_cast<const float4*>(next_val + e);
         R.f[j] = *reinterpret_cast<const uchar4*>(flags + e);
       }
     }
   };
-  auto konst = [&](float r, float v, float nv, uint8_t f, bool top) -> carry_t {
+  auto konst = [&](rew_t r, float v, float nv, uint8_t f, bool top) -> carry_t {
     const bool last = (f & OLY_FLAG_LAST) || top, ab = f & OLY_FLAG_ABSORBING;
     if (MODE == OLY_SCAN_RETURN) {
       if (last) {
@@ -180,11 +203,11 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
       return (carry_t)(double)r;
     }
     if (last) {
-      float a = r - v;
+      float a = (float)r - v;
       if (!ab) a += g32 * nv;
       return (carry_t)a;
     }
-    return (carry_t)(r + g32 * nv - v);
+    return (carry_t)((float)r + g32 * nv - v);
   };
   auto precompute = [&](int k, const Regs& R) {
     const int buf = k % 3;
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
       const int tt = g / GPR, c4 = g % GPR;
       if (g >= PIPE_GROUPS) continue;
       const bool top = (t_top - tt) == T - 1;
-      const float rv[4] = {R.r[j].x, R.r[j].y, R.r[j].z, R.r[j].w};
+      const rew_t rv[4] = {R.r[j][0], R.r[j][1], R.r[j][2], R.r[j][3]};
       const float vv[4] = {R.v[j].x, R.v[j].y, R.v[j].z, R.v[j].w};
       const float nn[4] = {R.nv[j].x, R.nv[j].y, R.nv[j].z, R.nv[j].w};
       const uint8_t ff[4] = {R.f[j].x, R.f[j].y, R.f[j].z, R.f[j].w};
@@ -213,6 +236,7 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
       *reinterpret_cast<float4*>(&s_v[buf][tt][4 * c4]) = R.v[j];
     }
   };
+  double acc_s = 0.0, acc_ss = 0.0;
   auto store = [&](int k) {
     const int buf = k % 3;
     const int t_top = T - 1 - k * PT;
@@ -239,6 +263,14 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
         }
         *reinterpret_cast<float4*>(ret + e) = make_float4(ro[0], ro[1], ro[2], ro[3]);
         *reinterpret_cast<float4*>(adv + e) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+        if (stats_ws) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double a = (double)ao[q];
+            acc_s += a;
+            acc_ss += a * a;
+          }
+        }
       }
     }
   };
@@ -298,6 +330,20 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
       if (i + d < ntiles) iter(i + d, R[(d + 1) % DEPTH]);
   }
   if (!chain_wave) store(ntiles - 1);
+  if (stats_ws) {
+    // fixed order: lane tree inside each wave, then waves 0..3 in order (the chain wave adds zeros)
+    double* sh = reinterpret_cast<double*>(pipe_lds);
+    __syncthreads();   // LDS tiles are dead from here on
+    const double ws_ = wave_sum(acc_s), wss_ = wave_sum(acc_ss);
+    if (lane == 0) { sh[2 * (tid >> 6)] = ws_; sh[2 * (tid >> 6) + 1] = wss_; }
+    __syncthreads();
+    if (tid == 0) {
+      double ts = 0.0, tss = 0.0;
+      for (int i = 0; i < NTHREADS / 64; ++i) { ts += sh[2 * i]; tss += sh[2 * i + 1]; }
+      stats_ws[2 * eb] = ts;
+      stats_ws[2 * eb + 1] = tss;
+    }
+  }
 }
 
 }  // namespace
@@ -340,41 +386,58 @@ static bool wide_ok(const void* a, const void* b, const void* c, const void* d, 
   return al(a, 15) && al(b, 15) && al(c, 15) && al(d, 3) && al(e, 15) && al(f, 15);
 }
 
-extern "C" int oly_return_scan(oly_ctx* ctx, int mode, int T, int N, double gamma, double lam,
-                               const float* rew, const float* val, const float* next_val,
-                               const uint8_t* flags, float* ret, float* adv, oly_stream stream) {
+extern "C" int oly_return_scan_stats(oly_ctx* ctx, int mode_flags, int T, int N, double gamma, double lam,
+                                     const void* rew, const float* val, const float* next_val,
+                                     const uint8_t* flags, float* ret, float* adv, double* stats3_out,
+                                     oly_stream stream) {
   if (!ctx) return OLY_EINVAL;
   if (T < 0 || N < 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: negative T or N");
-  if (T == 0 || N == 0) return OLY_OK;
+  const int mode = mode_flags & 0xff;
+  const bool rew64 = (mode_flags & OLY_SCAN_REW_F64) != 0;
+  if (mode != OLY_SCAN_RETURN && mode != OLY_SCAN_GAE)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: unknown mode %d", mode);
+  if (rew64 && mode != OLY_SCAN_RETURN)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: OLY_SCAN_REW_F64 is defined for OLY_SCAN_RETURN only");
+  if (T == 0 || N == 0) {
+    if (stats3_out) return oly_adv_stats(ctx, 0, nullptr, stats3_out, stream);
+    return OLY_OK;
+  }
   if (!rew || !val || !next_val || !flags || !ret || !adv)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: NULL pointer");
   static const int variant = [] { const char* e = getenv("OLY_K6_VARIANT"); return e ? atoi(e) : 1; }();  // 1 auto, 3 force the fallback
-  dim3 grid((N + 63) / 64);
-  if (mode != OLY_SCAN_RETURN && mode != OLY_SCAN_GAE)
-    OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: unknown mode %d", mode);
   if (variant == 1 && N % 4 == 0 && wide_ok(rew, val, next_val, flags, ret, adv)) {
     // three LDS buffers of [PT][EPW] (constant fp64/fp32 + value f32 + select u8)
     static const int pipe_cfg = [] { const char* e = getenv("OLY_K6_PIPE"); return e ? atoi(e) : 0; }();
+    int nblocks = 0;
+    double* ws = nullptr;
 #define OLY_PIPE_LAUNCH(ID, NT, DP, EPW, PTT)                                                            \
   do {                                                                                                   \
-    auto kr = scan_pipe_kernel<OLY_SCAN_RETURN, NT, DP, EPW, PTT>;                                       \
-    auto kg = scan_pipe_kernel<OLY_SCAN_GAE, NT, DP, EPW, PTT>;                                          \
+    auto kr = scan_pipe_kernel<OLY_SCAN_RETURN, false, NT, DP, EPW, PTT>;                                \
+    auto kd = scan_pipe_kernel<OLY_SCAN_RETURN, true, NT, DP, EPW, PTT>;                                 \
+    auto kg = scan_pipe_kernel<OLY_SCAN_GAE, false, NT, DP, EPW, PTT>;                                   \
     const size_t lds_r = 3 * (sizeof(double) + sizeof(float) + 1) * PTT * EPW;                           \
     const size_t lds_g = 3 * (sizeof(float) + sizeof(float) + 1) * PTT * EPW;                            \
     if (!(ctx->scan_attr_done & (1u << ID))) {                                                           \
       OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kr),                                \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));         \
+      OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kd),                                \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));         \
       OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kg),                                \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));         \
       ctx->scan_attr_done |= (1u << ID);                                                                 \
     }                                                                                                    \
     dim3 g((N + EPW - 1) / EPW);                                                                         \
-    if (mode == OLY_SCAN_RETURN)                                                                         \
+    nblocks = (int)g.x;                                                                                  \
+    if (stats3_out && (size_t)nblocks * 2 * sizeof(double) <= ctx->stats_ws_bytes) ws = ctx->stats_ws;   \
+    if (mode == OLY_SCAN_RETURN && rew64)                                                                \
+      hipLaunchKernelGGL(kd, g, dim3(NT), lds_r, oly_s(stream), T, N, gamma, lam, rew, val, next_val,    \
+                         flags, ret, adv, ws);                                                           \
+    else if (mode == OLY_SCAN_RETURN)                                                                    \
       hipLaunchKernelGGL(kr, g, dim3(NT), lds_r, oly_s(stream), T, N, gamma, lam, rew, val, next_val,    \
-                         flags, ret, adv);                                                               \
+                         flags, ret, adv, ws);                                                           \
     else                                                                                                 \
       hipLaunchKernelGGL(kg, g, dim3(NT), lds_g, oly_s(stream), T, N, gamma, lam, rew, val, next_val,    \
-                         flags, ret, adv);                                                               \
+                         flags, ret, adv, ws);                                                           \
   } while (0)
     // few environments: small workgroups so that every CU runs a chain; many: wide rows
     int cfg = pipe_cfg;
@@ -385,14 +448,31 @@ extern "C" int oly_return_scan(oly_ctx* ctx, int mode, int T, int N, double gamm
       default: OLY_PIPE_LAUNCH(3, 256, 2, 16, 32); break;  // [400,4096]: 16 / 14 us
     }
 #undef OLY_PIPE_LAUNCH
-  } else {
-    if (mode == OLY_SCAN_RETURN)
-      hipLaunchKernelGGL(scan_tile_kernel<OLY_SCAN_RETURN>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
-                         gamma, lam, rew, val, next_val, flags, ret, adv);
-    else
-      hipLaunchKernelGGL(scan_tile_kernel<OLY_SCAN_GAE>, grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
-                         gamma, lam, rew, val, next_val, flags, ret, adv);
+    OLY_LAUNCH_CHECK(ctx, "scan_pipe_kernel");
+    if (stats3_out) {
+      if (ws) return oly_stats_finish(ctx, nblocks, (int64_t)T * N, stats3_out, stream);
+      return oly_adv_stats(ctx, (int64_t)T * N, adv, stats3_out, stream);
+    }
+    return OLY_OK;
   }
-  OLY_LAUNCH_CHECK(ctx, "scan_kernel");
+  dim3 grid((N + 63) / 64);
+  if (mode == OLY_SCAN_RETURN && rew64)
+    hipLaunchKernelGGL((scan_tile_kernel<OLY_SCAN_RETURN, true>), grid, dim3(SCAN_THREADS), 0, oly_s(stream), T,
+                       N, gamma, lam, rew, val, next_val, flags, ret, adv);
+  else if (mode == OLY_SCAN_RETURN)
+    hipLaunchKernelGGL((scan_tile_kernel<OLY_SCAN_RETURN, false>), grid, dim3(SCAN_THREADS), 0, oly_s(stream), T,
+                       N, gamma, lam, rew, val, next_val, flags, ret, adv);
+  else
+    hipLaunchKernelGGL((scan_tile_kernel<OLY_SCAN_GAE, false>), grid, dim3(SCAN_THREADS), 0, oly_s(stream), T, N,
+                       gamma, lam, rew, val, next_val, flags, ret, adv);
+  OLY_LAUNCH_CHECK(ctx, "scan_tile_kernel");
+  if (stats3_out) return oly_adv_stats(ctx, (int64_t)T * N, adv, stats3_out, stream);
   return OLY_OK;
+}
+
+extern "C" int oly_return_scan(oly_ctx* ctx, int mode, int T, int N, double gamma, double lam,
+                               const float* rew, const float* val, const float* next_val,
+                               const uint8_t* flags, float* ret, float* adv, oly_stream stream) {
+  return oly_return_scan_stats(ctx, mode, T, N, gamma, lam, rew, val, next_val, flags, ret, adv, nullptr,
+                               stream);
 }

@@ -64,9 +64,28 @@ __global__ __launch_bounds__(64) void stats_finish_kernel(int nblocks, long n,
   if (threadIdx.x == 0) { out[0] = (double)n; out[1] = s; out[2] = ss; }
 }
 
+// st: [parts][3] (count, sum, sumsq) triples, one per rank; combined by a balanced pairwise tree
+// in rank order ((r0 + r1) + (r2 + r3)) + ... : the same on every rank, and equal to what one rank
+// holding all shards as aligned sub-trees would form.
+__device__ __forceinline__ void combine_parts(const double* __restrict__ st, int parts, double out[3]) {
+  double a[OLY_MAX_STAT_PARTS];
+#pragma unroll 1
+  for (int k = 0; k < 3; ++k) {
+    int m = 1;
+    while (m < parts) m <<= 1;
+    for (int i = 0; i < m; ++i) a[i] = (i < parts) ? st[3 * i + k] : 0.0;
+    for (int h = 1; h < m; h <<= 1)
+      for (int i = 0; i + h < m; i += 2 * h) a[i] += a[i + h];
+    out[k] = a[0];
+  }
+}
+
 __global__ __launch_bounds__(THREADS) void normalize_kernel(long n, float* __restrict__ x,
-                                                            const double* __restrict__ st, int ddof,
-                                                            double eps) {
+                                                            const double* __restrict__ st_, int parts,
+                                                            int ddof, double eps) {
+  double st[3];
+  if (parts == 1) { st[0] = st_[0]; st[1] = st_[1]; st[2] = st_[2]; }
+  else combine_parts(st_, parts, st);
   const double cnt = st[0], mean = st[1] / cnt;
   double var = (st[2] - cnt * mean * mean) / (cnt - (double)ddof);
   if (var < 0.0) var = 0.0;
@@ -190,18 +209,30 @@ extern "C" int oly_adv_stats(oly_ctx* ctx, int64_t n, const float* x, double* st
   return OLY_OK;
 }
 
-extern "C" int oly_adv_normalize(oly_ctx* ctx, int64_t n, float* x, const double* stats3, int ddof,
-                                 double eps, oly_stream stream) {
+int oly_stats_finish(oly_ctx* ctx, int nblocks, int64_t n, double* stats3_out, oly_stream stream) {
+  hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, oly_s(stream), nblocks, (long)n,
+                     ctx->stats_ws, stats3_out);
+  OLY_LAUNCH_CHECK(ctx, "stats_finish_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_adv_normalize_parts(oly_ctx* ctx, int64_t n, float* x, const double* stats3_parts,
+                                       int parts, int ddof, double eps, oly_stream stream) {
   if (!ctx) return OLY_EINVAL;
-  if (n < 0 || !stats3 || (n > 0 && !x) || ddof < 0)
-    OLY_FAIL(ctx, OLY_EINVAL, "oly_adv_normalize: bad argument");
+  if (n < 0 || !stats3_parts || (n > 0 && !x) || ddof < 0 || parts < 1 || parts > OLY_MAX_STAT_PARTS)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_adv_normalize: bad argument (parts=%d)", parts);
   if (n == 0) return OLY_OK;
   long want = (n / 4 + THREADS - 1) / THREADS;
   int nb = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
-  hipLaunchKernelGGL(normalize_kernel, dim3(nb), dim3(THREADS), 0, oly_s(stream), (long)n, x, stats3,
-                     ddof, eps);
+  hipLaunchKernelGGL(normalize_kernel, dim3(nb), dim3(THREADS), 0, oly_s(stream), (long)n, x, stats3_parts,
+                     parts, ddof, eps);
   OLY_LAUNCH_CHECK(ctx, "normalize_kernel");
   return OLY_OK;
+}
+
+extern "C" int oly_adv_normalize(oly_ctx* ctx, int64_t n, float* x, const double* stats3, int ddof,
+                                 double eps, oly_stream stream) {
+  return oly_adv_normalize_parts(ctx, n, x, stats3, 1, ddof, eps, stream);
 }
 
 extern "C" int oly_col_stats(oly_ctx* ctx, int B, int D, const float* x, double* colstats,

@@ -93,6 +93,9 @@ struct oly_ctx {
       OLY_FAIL(ctx, OLY_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e__));       \
   } while (0)
 
+// K7's finishing step over ctx->stats_ws[0 .. 2*nblocks) -> (n, sum, sumsq); used by K6's fused statistics
+int oly_stats_finish(oly_ctx* ctx, int nblocks, int64_t n, double* stats3_out, oly_stream stream);
+
 static inline hipStream_t oly_s(oly_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
 // 64-wide wavefront helpers (gfx950).

@@ -12,6 +12,8 @@ REWARD_NONE, REWARD_TARGET_VELOCITY, REWARD_X_POS = 0, 1, 2
 OUT_OBS_F64, OUT_CTRL_F64 = 1, 2
 MODE_STANDING, MODE_FORWARD, MODE_BACKWARD, MODE_LATERAL = 1, 2, 3, 4
 SCAN_RETURN, SCAN_GAE = 0, 1
+SCAN_REW_F64 = 0x100
+OLY_MAX_STAT_PARTS = 64
 FLAG_ABSORBING, FLAG_LAST = 1, 2
 
 i32p = C.POINTER(C.c_int32)
@@ -120,7 +122,10 @@ SIGNATURES = {
     "oly_a3_pd_torque": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "oly_return_scan": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                   vp, vp, vp, vp, vp, vp, vp]),
+    "oly_return_scan_stats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        vp, vp, vp, vp, vp, vp, vp, vp]),
     "oly_adv_stats": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    "oly_adv_normalize_parts": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_double, vp]),
     "oly_adv_normalize": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int, C.c_double, vp]),
     "oly_col_stats": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "oly_disc_standardize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),

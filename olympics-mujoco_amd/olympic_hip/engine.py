@@ -49,6 +49,14 @@ class Engine:
     def _s(self):
         return self.ctx.stream()
 
+    def _out(self, out, key, shape, dtype):
+        """Caller-supplied output buffer `out[key]` (validated) or a fresh one; nothing is allocated
+        when the caller passes its own buffers."""
+        t = out.get(key) if out else None
+        if t is None:
+            t = self._new(shape, dtype)
+        return _req(t, key, shape, dtype, self.device)
+
     # -------------------------------------------------------------- K1 / K5
     def il_configure(self, spec):
         self.ctx.call("oly_il_configure", C.byref(spec.to_c()))
@@ -80,15 +88,11 @@ class Engine:
         out = out or {}
         od = torch.float64 if obs_f64 else torch.float32
         cd = torch.float64 if ctrl_f64 else torch.float32
-        obs = _req(out.get("obs", self._new((T, N, sp.n_obs), od)), "obs", (T, N, sp.n_obs), od, dv)
-        reward = _req(out.get("reward", self._new((T, N), torch.float32)), "reward", (T, N), torch.float32, dv)
-        absorbing = _req(out.get("absorbing", self._new((T, N), torch.uint8)), "absorbing", (T, N), torch.uint8, dv)
-        code = None
-        if want_fall_code:
-            code = _req(out.get("fall_code", self._new((T, N), torch.uint8)), "fall_code", (T, N), torch.uint8, dv)
-        ctrl = None
-        if want_ctrl:
-            ctrl = _req(out.get("ctrl", self._new((T, N, sp.nu), cd)), "ctrl", (T, N, sp.nu), cd, dv)
+        obs = self._out(out, "obs", (T, N, sp.n_obs), od)
+        reward = self._out(out, "reward", (T, N), torch.float32)
+        absorbing = self._out(out, "absorbing", (T, N), torch.uint8)
+        code = self._out(out, "fall_code", (T, N), torch.uint8) if want_fall_code else None
+        ctrl = self._out(out, "ctrl", (T, N, sp.nu), cd) if want_ctrl else None
         flags = (_abi.OUT_OBS_F64 if obs_f64 else 0) | (_abi.OUT_CTRL_F64 if ctrl_f64 else 0)
         self.ctx.call("oly_il_step", T, N, ptr(qpos), ptr(qvel), ptr(action), ptr(grf_mean), ptr(prev_in),
                       ptr(prev_out), ptr(obs), ptr(reward), ptr(absorbing), ptr(code), ptr(ctrl), flags,
@@ -246,10 +250,10 @@ class Engine:
         cst = self._a3_struct(_abi.A3State, self._A3_ST, state, N)
         out = out or {}
         od = torch.float64 if obs_f64 else torch.float32
-        obs = _req(out.get("obs", self._new((N, sp.n_obs), od)), "obs", (N, sp.n_obs), od, self.device)
-        rew6 = _req(out.get("rew6", self._new((N, 6), torch.float32)), "rew6", (N, 6), torch.float32, self.device)
-        reward = _req(out.get("reward", self._new((N,), torch.float32)), "reward", (N,), torch.float32, self.device)
-        done = _req(out.get("done", self._new((N,), torch.uint8)), "done", (N,), torch.uint8, self.device)
+        obs = self._out(out, "obs", (N, sp.n_obs), od)
+        rew6 = self._out(out, "rew6", (N, 6), torch.float32)
+        reward = self._out(out, "reward", (N,), torch.float32)
+        done = self._out(out, "done", (N,), torch.uint8)
         self.ctx.call("oly_a3_step", N, C.byref(cin), C.byref(cst), ptr(obs), ptr(rew6), ptr(reward), ptr(done),
                       _abi.OUT_OBS_F64 if obs_f64 else 0, self._s())
         return dict(obs=obs, rew6=rew6, reward=reward, done=done)
@@ -275,19 +279,26 @@ class Engine:
         return tau
 
     # -------------------------------------------------------------- K6
-    def return_scan(self, mode, gamma, lam, rew, val, next_val, flags, ret=None, adv=None):
+    def return_scan(self, mode, gamma, lam, rew, val, next_val, flags, ret=None, adv=None, stats3=None):
+        """rew [T,N] float32, or float64 (RETURN mode: the un-narrowed reward of env.step).  With
+        `stats3` ([3] f64 device tensor) the same pass also leaves (T*N, sum adv, sum adv^2) there."""
         if rew.dim() != 2:
             raise OlyError(f"rew: expected [T,N], got {tuple(rew.shape)}")
         T, N = int(rew.shape[0]), int(rew.shape[1])
         dv = self.device
-        _req(rew, "rew", (T, N), torch.float32, dv)
+        r64 = rew.dtype == torch.float64
+        if r64 and int(mode) != _abi.SCAN_RETURN:
+            raise OlyError("float64 rewards are defined for SCAN_RETURN only")
+        _req(rew, "rew", (T, N), torch.float64 if r64 else torch.float32, dv)
         _req(val, "val", (T, N), torch.float32, dv)
         _req(next_val, "next_val", (T, N), torch.float32, dv)
         _req(flags, "flags", (T, N), torch.uint8, dv)
+        _req(stats3, "stats3", (3,), torch.float64, dv, optional=True)
         ret = _req(ret if ret is not None else self._new((T, N), torch.float32), "ret", (T, N), torch.float32, dv)
         adv = _req(adv if adv is not None else self._new((T, N), torch.float32), "adv", (T, N), torch.float32, dv)
-        self.ctx.call("oly_return_scan", int(mode), T, N, C.c_double(gamma), C.c_double(lam), ptr(rew), ptr(val),
-                      ptr(next_val), ptr(flags), ptr(ret), ptr(adv), self._s())
+        self.ctx.call("oly_return_scan_stats", int(mode) | (_abi.SCAN_REW_F64 if r64 else 0), T, N, C.c_double(gamma),
+                      C.c_double(lam), ptr(rew), ptr(val), ptr(next_val), ptr(flags), ptr(ret), ptr(adv), ptr(stats3),
+                      self._s())
         return ret, adv
 
     def rollout_cuts(self, done, traj_len, flags, n_cut, max_traj_len, last_step):
@@ -309,10 +320,14 @@ class Engine:
         return stats3
 
     def adv_normalize(self, x, stats3, ddof, eps):
+        """stats3: [3] (one triple) or [parts,3] (one triple per rank, as all-gathered)."""
         _req(x, "x", x.shape, torch.float32, self.device)
-        _req(stats3, "stats3", (3,), torch.float64, self.device)
-        self.ctx.call("oly_adv_normalize", C.c_int64(x.numel()), ptr(x), ptr(stats3), int(ddof), C.c_double(eps),
-                      self._s())
+        parts = 1 if stats3.dim() == 1 else int(stats3.shape[0])
+        if not 1 <= parts <= _abi.OLY_MAX_STAT_PARTS:
+            raise OlyError(f"stats3: {parts} parts, at most {_abi.OLY_MAX_STAT_PARTS}")
+        _req(stats3, "stats3", (3,) if stats3.dim() == 1 else (parts, 3), torch.float64, self.device)
+        self.ctx.call("oly_adv_normalize_parts", C.c_int64(x.numel()), ptr(x), ptr(stats3), parts, int(ddof),
+                      C.c_double(eps), self._s())
         return x
 
     def col_stats(self, x, colstats=None):

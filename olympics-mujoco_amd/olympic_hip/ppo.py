@@ -10,7 +10,7 @@ Reference: rl/algos/ppo.py
 Where the reference fans n_proc single-env workers out over ray, here `env_fn()` returns ONE
 vectorised env and `num_procs` maps to its num_envs; the optimiser side is PyTorch (MFMA GEMMs)
 with the loss terms and their gradients evaluated by one HIP kernel (update_policy_fused;
-update_policy keeps the reference's op-by-op form).  Actor / critic modules are the reference's own (anything with
+update_policy is the plain-torch evaluation of the same terms).  Actor / critic modules are the reference's own (anything with
 `forward(state, deterministic, anneal)`, `distribution(obs)` and a critic `forward(obs)`).
 """
 import os
@@ -376,29 +376,30 @@ class PPO:
 
     def update_policy(self, obs_batch, action_batch, return_batch, advantage_batch, mask,
                       mirror_observation=None, mirror_action=None):
-        policy, critic, old_policy = self.policy, self.critic, self.old_policy
-        values = critic(obs_batch)
-        pdf = policy.distribution(obs_batch)
-        log_probs = pdf.log_prob(action_batch).sum(-1, keepdim=True)
+        """The same six quantities as update_policy_fused (rl/algos/ppo.py:232-282) evaluated with
+        plain torch ops and autograd: the path for mirrors given as functions and for policies that
+        are not diagonal Gaussians, and the checker the fused kernel is tested against."""
+        new_pdf = self.policy.distribution(obs_batch)
         with torch.no_grad():
-            old_log_probs = old_policy.distribution(obs_batch).log_prob(action_batch).sum(-1, keepdim=True)
-        ratio = (log_probs - old_log_probs).exp()
-        cpi_loss = ratio * advantage_batch * mask
-        clip_loss = ratio.clamp(1.0 - self.clip, 1.0 + self.clip) * advantage_batch * mask
-        actor_loss = -torch.min(cpi_loss, clip_loss).mean()
-        clip_fraction = torch.mean((torch.abs(ratio - 1) > self.clip).float()).item()
-        critic_loss = self.vf_coeff * F.mse_loss(return_batch, values)
-        entropy_penalty = -(pdf.entropy() * mask).mean()
-        if mirror_observation is not None and mirror_action is not None:
-            deterministic_actions = policy(obs_batch)
-            mirror_actions = mirror_action(policy(mirror_observation(obs_batch)))
-            mirror_loss = (deterministic_actions - mirror_actions).pow(2).mean()
+            old_pdf = self.old_policy.distribution(obs_batch)
+            logp_old = old_pdf.log_prob(action_batch).sum(-1, keepdim=True)
+        log_ratio = new_pdf.log_prob(action_batch).sum(-1, keepdim=True) - logp_old
+        ratio = torch.exp(log_ratio)
+        lo, hi = 1.0 - self.clip, 1.0 + self.clip
+        weighted = advantage_batch * mask
+        surrogate = torch.minimum(ratio * weighted, torch.clamp(ratio, lo, hi) * weighted)
+        terms = dict(
+            actor=-surrogate.mean(),
+            entropy=-(new_pdf.entropy() * mask).mean(),
+            critic=self.vf_coeff * F.mse_loss(return_batch, self.critic(obs_batch)),
+            kl=((ratio - 1.0) - log_ratio).detach().mean(),                    # the k3 estimator
+            clipped=((ratio.detach() - 1.0).abs() > self.clip).float().mean().item())
+        if mirror_observation is None or mirror_action is None:
+            mirror = torch.zeros(1, device=obs_batch.device)
         else:
-            mirror_loss = torch.zeros(1, device=obs_batch.device)
-        with torch.no_grad():
-            log_ratio = log_probs - old_log_probs
-            approx_kl_div = torch.mean((ratio - 1) - log_ratio)
-        return actor_loss, entropy_penalty, critic_loss, approx_kl_div, mirror_loss, clip_fraction
+            mirrored = mirror_action(self.policy(mirror_observation(obs_batch)))
+            mirror = torch.square(self.policy(obs_batch) - mirrored).mean()
+        return terms["actor"], terms["entropy"], terms["critic"], terms["kl"], mirror, terms["clipped"]
 
     # ------------------------------------------------------------------ training loop
     def train(self, env_fn, policy, critic, n_itr, anneal_rate=1.0, verbose=True):

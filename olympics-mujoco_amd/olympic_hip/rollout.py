@@ -20,12 +20,14 @@ from . import _abi, dist as odist
 class RolloutBuffer:
     """[T,N] device storage of one rollout block (what PPOBuffer keeps as python lists)."""
 
-    def __init__(self, T, N, obs_dim, act_dim, device):
+    def __init__(self, T, N, obs_dim, act_dim, device, reward_dtype=torch.float32):
+        """reward_dtype float64 keeps env.step's reward un-narrowed, as PPOBuffer does (the return
+        scan is then bit-exact for any reward, rl/algos/ppo.py:74-76)."""
         f32 = dict(dtype=torch.float32, device=device)
         self.T, self.N = T, N
         self.states = torch.empty((T, N, obs_dim), **f32)
         self.actions = torch.empty((T, N, act_dim), **f32)
-        self.rewards = torch.empty((T, N), **f32)
+        self.rewards = torch.empty((T, N), dtype=reward_dtype, device=device)
         self.values = torch.empty((T, N), **f32)
         self.next_values = torch.zeros((T, N), **f32)
         self.flags = torch.zeros((T, N), dtype=torch.uint8, device=device)
@@ -63,30 +65,39 @@ class PPORollout:
         self.eng, self.gamma, self.lam, self.eps = engine, gamma, lam, eps
         self._stats = torch.empty(3, dtype=torch.float64, device=engine.device)
 
+    MODE, DDOF = _abi.SCAN_RETURN, 1
+
     def finish(self, buf, normalize=True):
-        """returns, advantages (normalised in place when `normalize`)."""
-        self.eng.return_scan(_abi.SCAN_RETURN, self.gamma, self.lam, buf.rewards, buf.values,
-                             buf.next_values, buf.flags, buf.returns, buf.advantages)
+        """returns, advantages (normalised in place when `normalize`): the scan leaves the
+        advantage statistics of its own shard behind (same pass), ONE all-gather of 24 B per rank,
+        then the normalisation adds the rank triples on the device."""
+        self.eng.return_scan(self.MODE, self.gamma, self.lam, buf.rewards, buf.values, buf.next_values,
+                             buf.flags, buf.returns, buf.advantages, stats3=self._stats if normalize else None)
         if normalize:
-            self.normalize(buf.advantages, ddof=1, eps=self.eps)
+            self._normalize_with(buf.advantages, self._stats, self.DDOF, self._eps())
         return buf.returns, buf.advantages
 
-    def normalize(self, adv, ddof, eps):
-        self.eng.adv_stats(adv, self._stats)
-        total = odist.global_stats(self._stats)          # 24 B per rank over RCCL / xGMI
-        self.eng.adv_normalize(adv, total.contiguous(), ddof, eps)
+    def _eps(self):
+        return self.eps
+
+    def _normalize_with(self, adv, stats3, ddof, eps):
+        parts = odist.gather_stats(stats3)               # [world,3]: 24 B per rank over RCCL / xGMI
+        self.eng.adv_normalize(adv, parts, ddof, eps)
         return adv
+
+    def normalize(self, adv, ddof, eps):
+        """Statistics + normalisation of an advantage tensor that did not come out of finish()."""
+        self.eng.adv_stats(adv, self._stats)
+        return self._normalize_with(adv, self._stats, ddof, eps)
 
 
 class GAERollout(PPORollout):
     """compute_gae(V, x, xn, r, absorbing, last, gamma, lam) + GAIL's normalisation."""
 
-    def finish(self, buf, normalize=True):
-        self.eng.return_scan(_abi.SCAN_GAE, self.gamma, self.lam, buf.rewards, buf.values,
-                             buf.next_values, buf.flags, buf.returns, buf.advantages)
-        if normalize:
-            self.normalize(buf.advantages, ddof=0, eps=1e-8)
-        return buf.returns, buf.advantages
+    MODE, DDOF = _abi.SCAN_GAE, 0
+
+    def _eps(self):
+        return 1e-8
 
 
 @torch.no_grad()

@@ -26,8 +26,8 @@ def h1_synthetic_block(spec, T, N, seed=1234, fall_frac="bench"):
     full = np.empty((R, n_pos + spec.n_vel))
     full[:, 0:2] = rng.uniform(-5, 5, (R, 2))
     if fall_frac == "bench":
-        full[:, 2] = rng.normal(-0.1, 0.06, R)
-        full[:, 3:6] = rng.normal(0, 0.08, (R, 3))
+        full[:, 2] = rng.normal(-0.1, 0.085, R)          # with the eulers below: ~3 % fallen rows
+        full[:, 3:6] = rng.normal(0, 0.105, (R, 3))
     else:
         full[:, 2] = rng.uniform(-0.4, 0.2, R)
         full[:, 3:6] = rng.uniform(-0.6, 0.6, (R, 3))

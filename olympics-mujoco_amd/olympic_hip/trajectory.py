@@ -148,31 +148,38 @@ class Trajectory:
     def _get_subtraj(self, i):
         return [obs[i].copy() for obs in self.trajectories]
 
+    def _pick(self, given, upper):
+        """Caller's index (the reference only bounds it by <=, trajectory.py:307,314) or one draw from
+        numpy's global stream."""
+        if given is None:
+            return np.random.randint(0, upper)
+        if not 0 <= given <= upper:
+            raise AssertionError(f"index {given} outside [0, {upper}]")
+        return given
+
     def reset_trajectory(self, substep_no=None, traj_no=None):
-        """(:289-323) random indices come from numpy's global stream, like the reference."""
-        if traj_no is None:
-            self.traj_no = np.random.randint(0, self.number_of_trajectories)
-        else:
-            assert 0 <= traj_no <= self.number_of_trajectories
-            self.traj_no = traj_no
-        if substep_no is None:
-            self.subtraj_step_no = np.random.randint(0, self.trajectory_length)
-        else:
-            assert 0 <= substep_no <= self.trajectory_length
-            self.subtraj_step_no = substep_no
+        """Select (trajectory, step), drawing whichever is None (trajectory first, then step: the
+        reference's draw order), and re-zero x / y at that step on a copy of the sub-trajectory
+        (:289-323).  Returns the sample at the cursor."""
+        self.traj_no = self._pick(traj_no, self.number_of_trajectories)
+        self.subtraj_step_no = self._pick(substep_no, self.trajectory_length)
         self.subtraj = self._get_subtraj(self.traj_no)
-        self.subtraj[0] -= self.subtraj[0][self.subtraj_step_no]
-        self.subtraj[1] -= self.subtraj[1][self.subtraj_step_no]
-        return [obs[self.subtraj_step_no] for obs in self.subtraj]
+        for planar in (0, 1):                                  # keys 0 and 1 are the pelvis x and y
+            self.subtraj[planar] -= self.subtraj[planar][self.subtraj_step_no]
+        return self._row(self.subtraj_step_no, copy=False)
+
+    def _row(self, k, copy=True):
+        if copy:
+            return [np.array(col[k].copy()).flatten() for col in self.subtraj]
+        return [col[k] for col in self.subtraj]
 
     def get_current_sample(self):
-        return [np.array(obs[self.subtraj_step_no].copy()).flatten() for obs in self.subtraj]
+        return self._row(self.subtraj_step_no)
 
     def get_next_sample(self):
+        """Advance the cursor; None once it has walked off the end (:389-401)."""
         self.subtraj_step_no += 1
-        if self.subtraj_step_no == self.trajectory_length:
-            return None
-        return [np.array(obs[self.subtraj_step_no].copy()).flatten() for obs in self.subtraj]
+        return None if self.subtraj_step_no == self.trajectory_length else self._row(self.subtraj_step_no)
 
     def get_idx(self, key):
         return self.keys.index(key)

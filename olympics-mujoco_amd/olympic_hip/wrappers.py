@@ -12,66 +12,78 @@ import numpy as np
 import torch
 
 
+def _signed_perm(mirrored):
+    """(src, sign) of a mirror table: out[:, j] = sign[j] * x[:, src[j]], i.e. x @ M with
+    M[i, |mirrored[i]|] = sign(mirrored[i]).  Index 0 arrives encoded as 0.1 so that its sign is +1
+    (StickFigureA3.py:118,128-129): truncation towards zero recovers the index."""
+    table = np.asarray(mirrored, dtype=np.float64)
+    dest = np.trunc(np.abs(table)).astype(np.int64)          # column each input feeds
+    if not np.array_equal(np.sort(dest), np.arange(table.size)):
+        raise ValueError("mirror table is not a permutation")
+    src = np.empty(table.size, dtype=np.int64)
+    src[dest] = np.arange(table.size)
+    return src, np.sign(table)[src].astype(np.float32)
+
+
+def _get_symmetry_matrix(mirrored):
+    """Dense [n,n] form of the same signed permutation (what rl/envs/wrappers.py:75-82 returns),
+    scattered from the (src, sign) pair."""
+    src, sign = _signed_perm(mirrored)
+    dense = np.zeros((src.size, src.size))
+    dense[src, np.arange(src.size)] = sign
+    return dense
+
+
 class WrapEnv:
-    """Gives a vectorized interface to a single environment."""
+    """Batch-of-one facade over one scalar environment (rl/envs/wrappers.py:5-22): every result of
+    step() / reset() gains a leading axis of length 1, attribute access falls through to the env."""
 
     def __init__(self, env_fn):
         self.env = env_fn()
 
-    def __getattr__(self, attr):
-        return getattr(self.env, attr)
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    @staticmethod
+    def _batched(x):
+        return np.array([x])
+
+    def reset(self):
+        return self._batched(self.env.reset())
 
     def step(self, action):
-        state, reward, done, info = self.env.step(action[0])
-        return np.array([state]), np.array([reward]), np.array([done]), np.array([info])
+        return tuple(self._batched(part) for part in self.env.step(action[0]))
 
     def render(self):
         self.env.render()
 
-    def reset(self):
-        return np.array([self.env.reset()])
-
-
-def _get_symmetry_matrix(mirrored):
-    numel = len(mirrored)
-    mat = np.zeros((numel, numel))
-    for i, j in zip(np.arange(numel), np.abs(np.array(mirrored).astype(int))):
-        mat[i, j] = np.sign(mirrored[i])
-    return mat
-
-
-def _signed_perm(mirrored):
-    """out[:, j] = sign[i] * x[:, i] for the single i with |mirrored[i]| == j  (x @ M)."""
-    m = np.asarray(mirrored, dtype=np.float64)
-    src = np.empty(len(m), dtype=np.int64)
-    sgn = np.empty(len(m), dtype=np.float32)
-    cols = np.abs(m).astype(int)
-    if sorted(cols.tolist()) != list(range(len(m))):
-        raise ValueError("mirror table is not a permutation")
-    for i, j in enumerate(cols):
-        src[j] = i
-        sgn[j] = np.sign(m[i])
-    return src, sgn
-
 
 class SymmetricEnv:
+    """Mirror-symmetry view of an env (rl/envs/wrappers.py:24-72).  Each of observation / action is
+    mirrored EITHER by an index table (signed permutation) OR by a caller-supplied function."""
+
     def __init__(self, env_fn, mirrored_obs=None, mirrored_act=None, clock_inds=None, obs_fn=None, act_fn=None):
-        assert (bool(mirrored_act) ^ bool(act_fn)) and (bool(mirrored_obs) ^ bool(obs_fn)), \
-            "You must provide either mirror indices or a mirror function, but not both, for observation and action."
+        for what, table, fn in (("action", mirrored_act, act_fn), ("observation", mirrored_obs, obs_fn)):
+            if bool(table) == bool(fn):
+                raise AssertionError(f"{what}: give mirror indices or a mirror function, exactly one of them")
+            if fn is not None and not callable(fn):
+                raise AssertionError(f"{what} mirror function must be callable")
         if mirrored_act:
-            self.act_mirror_matrix = torch.Tensor(_get_symmetry_matrix(mirrored_act))
-            self._act_src, self._act_sgn = (torch.as_tensor(a) for a in _signed_perm(mirrored_act))
-        elif act_fn:
-            assert callable(act_fn), "Action mirror function must be callable"
+            self._install_table("act", mirrored_act)
+        else:
             self.mirror_action = act_fn
         if mirrored_obs:
-            self.obs_mirror_matrix = torch.Tensor(_get_symmetry_matrix(mirrored_obs))
-            self._obs_src, self._obs_sgn = (torch.as_tensor(a) for a in _signed_perm(mirrored_obs))
-        elif obs_fn:
-            assert callable(obs_fn), "Observation mirror function must be callable"
+            self._install_table("obs", mirrored_obs)
+        else:
             self.mirror_observation = obs_fn
         self.clock_inds = clock_inds
         self.env = env_fn()
+
+    def _install_table(self, kind, table):
+        src, sign = _signed_perm(table)
+        setattr(self, f"_{kind}_src", torch.as_tensor(src))
+        setattr(self, f"_{kind}_sgn", torch.as_tensor(sign))
+        setattr(self, f"{kind}_mirror_matrix", torch.Tensor(_get_symmetry_matrix(table)))   # reference attribute
 
     def __getattr__(self, attr):
         return getattr(self.env, attr)

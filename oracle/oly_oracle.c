@@ -549,6 +549,30 @@ int oly_return_scan_cpu(int mode, int T, int N, double gamma, double lam, const 
   return OLY_EINVAL;
 }
 
+/* finish_path with the float64 reward un-narrowed (WrapEnv.step hands np.array([reward]), a
+   float64 array, to PPOBuffer.store: rl/envs/wrappers.py:14, rl/algos/ppo.py:56-66,74-76). */
+int oly_return_scan_r64_cpu(int T, int N, double gamma, const double* rew, const float* val,
+                            const float* next_val, const uint8_t* flags, float* ret, float* adv) {
+  float g32 = (float)gamma;
+  for (int n = 0; n < N; ++n) {
+    double R = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+      size_t e = (size_t)t * N + n;
+      uint8_t f = flags[e];
+      if ((f & OLY_FLAG_LAST) || t == T - 1) {
+        float r0 = (f & OLY_FLAG_ABSORBING) ? 0.0f : next_val[e];
+        float p = g32 * r0;
+        R = (double)p + rew[e];
+      } else {
+        R = gamma * R + rew[e];
+      }
+      ret[e] = (float)R;
+      adv[e] = ret[e] - val[e];
+    }
+  }
+  return OLY_OK;
+}
+
 /* ============================================================================== K7 */
 
 int oly_adv_stats_cpu(int64_t n, const float* x, double* stats3_out) {
@@ -572,6 +596,22 @@ int oly_adv_normalize_cpu(int64_t n, float* x, const double* stats3, int ddof, d
   double denom = sqrt(var) + eps;
   for (int64_t i = 0; i < n; ++i) x[i] = (float)(((double)x[i] - mean) / denom);
   return OLY_OK;
+}
+
+/* The sharded form: one (count, sum, sumsq) triple per rank, added by a balanced pairwise tree in
+   rank order (what every rank does after the all-gather), then the normalisation above. */
+int oly_adv_normalize_parts_cpu(int64_t n, float* x, const double* parts3, int parts, int ddof, double eps) {
+  double tot[3], a[64];
+  if (parts < 1 || parts > 64) return OLY_EINVAL;
+  for (int k = 0; k < 3; ++k) {
+    int m = 1;
+    while (m < parts) m <<= 1;
+    for (int i = 0; i < m; ++i) a[i] = (i < parts) ? parts3[3 * i + k] : 0.0;
+    for (int h = 1; h < m; h <<= 1)
+      for (int i = 0; i + h < m; i += 2 * h) a[i] += a[i + h];
+    tot[k] = a[0];
+  }
+  return oly_adv_normalize_cpu(n, x, tot, ddof, eps);
 }
 
 /* Standardizer.update_mean_std sums, imitation_lib/utils/networks.py:76-79. */

@@ -64,7 +64,11 @@ int oly_return_scan_cpu(int mode, int T, int N, double gamma, double lam, const 
                         const float* val, const float* next_val, const uint8_t* flags, float* ret,
                         float* adv);
 
+int oly_return_scan_r64_cpu(int T, int N, double gamma, const double* rew, const float* val,
+                            const float* next_val, const uint8_t* flags, float* ret, float* adv);
+
 int oly_adv_stats_cpu(int64_t n, const float* x, double* stats3_out);
+int oly_adv_normalize_parts_cpu(int64_t n, float* x, const double* parts3, int parts, int ddof, double eps);
 int oly_adv_normalize_cpu(int64_t n, float* x, const double* stats3, int ddof, double eps);
 int oly_col_stats_cpu(int B, int D, const float* x, double* colstats, int accumulate);
 

@@ -196,6 +196,26 @@ def return_scan(mode, gamma, lam, rew, val, next_val, flags):
     return ret, adv
 
 
+def return_scan_r64(gamma, rew, val, next_val, flags):
+    """PPOBuffer.finish_path with float64 rewards (RETURN mode)."""
+    rew = _c(rew, np.float64)
+    val, next_val = (_c(a, np.float32) for a in (val, next_val))
+    flags = _c(flags, np.uint8)
+    T, N = rew.shape
+    ret, adv = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    _chk(lib().oly_return_scan_r64_cpu(T, N, C.c_double(gamma), _p(rew), _p(val), _p(next_val), _p(flags),
+                                       _p(ret), _p(adv)), "return_scan_r64")
+    return ret, adv
+
+
+def adv_normalize_parts(x, parts3, ddof, eps):
+    x = np.array(x, dtype=np.float32, copy=True)
+    parts3 = _c(parts3, np.float64).reshape(-1, 3)
+    _chk(lib().oly_adv_normalize_parts_cpu(C.c_int64(x.size), _p(x), _p(parts3), int(parts3.shape[0]), int(ddof),
+                                           C.c_double(eps)), "adv_normalize_parts")
+    return x
+
+
 def adv_stats(x):
     x = _c(x, np.float32).reshape(-1)
     s = np.empty(3)

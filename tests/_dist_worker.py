@@ -23,8 +23,10 @@ def main():
     lo, hi = odist.shard_range(N)
     mine = torch.as_tensor(adv[:, lo:hi]).double()
     stats = torch.tensor([mine.numel(), mine.sum().item(), (mine * mine).sum().item()], dtype=torch.float64)
+    parts = odist.gather_stats(stats)                         # [world,3], the product's one collective
     total = odist.global_stats(stats)
-    res = {"total": total.numpy()}
+    assert torch.equal(total, odist.tree_sum(parts))
+    res = {"total": total.numpy(), "parts": parts.numpy()}
     for ddof, eps, key in ((1, 1e-5, "ppo"), (0, 1e-8, "gail")):
         mean, std = odist.mean_std_from_stats(total, ddof)
         res[key] = ((mine - mean) / (std + eps)).float().numpy()

@@ -20,6 +20,7 @@ fixtures do.  Fixture -> reference function map (file:line in /root/reference):
                   LocoEnvBase._preprocess_action (loco_env_base.py:1050)
   ppo_returns.npz PPOBuffer.store/finish_path (rl/algos/ppo.py:56-84) and the
                   advantage normalisation of PPO.train (:335-336)
+  ppo_returns_f64.npz the same scan with float64 rewards that float32 cannot represent
   running_stats.npz RunningMeanStd.update (rl/envs/normalize.py:182-208),
                   Standardizer.update_mean_std (imitation_lib/utils/networks.py:76-81)
   normalize.npz   Normalize._obfilt (rl/envs/normalize.py:139-147) online + frozen
@@ -268,6 +269,37 @@ def gen_ppo():
          returns=returns_t.numpy().reshape(-1), adv=adv.numpy().reshape(-1),
          adv_norm=adv_n.numpy().reshape(-1), ep_returns=np.array(buf.ep_returns, np.float64),
          ep_lens=np.array(buf.ep_lens), traj_idx=np.array(buf.traj_idx))
+
+
+def gen_ppo_f64():
+    """finish_path with rewards that are NOT float32-representable: WrapEnv.step returns
+    np.array([reward]) (float64, rl/envs/wrappers.py:14) and PPOBuffer keeps it float64, so the
+    scan adds the un-narrowed reward (rl/algos/ppo.py:74-76)."""
+    rng = np.random.default_rng(71)
+    gamma = 0.99
+    buf = ns.ppo.PPOBuffer(gamma, 0.95)
+    ep_len = [400, 3, 1, 55, 400, 17, 230, 9]
+    done_tail = [False, True, False, True, True, False, False, True]
+    rewards, values, last_vals = [], [], []
+    for L, dn in zip(ep_len, done_tail):
+        for _ in range(L):
+            r = float(rng.uniform(-0.3, 1.0))                  # a python float, as sum([float(i) ...]) gives
+            v = np.float32(rng.normal())
+            buf.store(np.zeros((1, 4), np.float32), np.zeros((1, 2), np.float32),
+                      np.array([r]), np.array([[v]], dtype=np.float32))
+            rewards.append(r)
+            values.append(v)
+        lv = np.array([[np.float32(rng.normal())]], dtype=np.float32)
+        last_vals.append(lv[0, 0])
+        buf.finish_path(last_val=(not dn) * lv)
+    _, _, returns, vals = buf.get()
+    returns_t = torch.Tensor(np.array(returns))
+    adv = returns_t - torch.Tensor(np.array(vals))
+    assert np.any(np.array(rewards, np.float32).astype(np.float64) != np.array(rewards))
+    save("ppo_returns_f64.npz", gamma=gamma, ep_len=np.array(ep_len), done_tail=np.array(done_tail),
+         rewards=np.array(rewards, np.float64), values=np.array(values, np.float32),
+         last_val=np.array(last_vals, np.float32), returns=returns_t.numpy().reshape(-1),
+         adv=adv.numpy().reshape(-1), ep_returns=np.array(buf.ep_returns, np.float64))
 
 
 # ------------------------------------------------------------ G3 running stats
@@ -901,12 +933,14 @@ def gen_il_robot(cls_name, mod, xml, defaults):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd", "robots", "norm"]
+    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd", "robots", "norm", "ppo64"]
     tab = gen_h1_tables() if any(w in which for w in ("tables", "h1", "traj")) else None
     if "h1" in which:
         gen_h1_step(tab)
     if "ppo" in which:
         gen_ppo()
+    if "ppo64" in which:
+        gen_ppo_f64()
     if "stats" in which:
         gen_running_stats()
     if "norm" in which:

@@ -51,3 +51,69 @@ def ppo_update_arrays(g):
                 std=np.float32(g["fixed_std"]), action=g["act"].astype(np.float32),
                 adv=g["adv"].reshape(-1).astype(np.float32), ret=g["ret"].reshape(-1).astype(np.float32),
                 clip=float(g["clip"]))
+
+
+def euler2quat_sxyz(r, p, y):
+    """transforms3d.euler.euler2quat (static xyz, w first) written out from its definition."""
+    ci, si, cj, sj, ck, sk = np.cos(r / 2), np.sin(r / 2), np.cos(p / 2), np.sin(p / 2), np.cos(y / 2), np.sin(y / 2)
+    return np.stack([cj * ci * ck + sj * si * sk, cj * si * ck - sj * ci * sk, cj * si * sk + sj * ci * ck,
+                     cj * ci * sk - sj * si * ck], -1)
+
+
+def a3_analytic_cases():
+    """Closed-form orientation cases for oly_a3_step (identity, 90 deg rotations, gimbal
+    branch cy ~ 0, round trips): body quaternions from known (roll, pitch, yaw), a root that is
+    rotated about z only, two targets with known yaws.  Returns state / inputs / expectations."""
+    from olympic_hip import _abi
+    h = np.pi / 2
+    rpy = [(0, 0, 0), (0, 0, 1.1), (0, 0, -3.0), (h, 0, 0), (-h, 0, 0), (0, h, 0), (0, -h, 0), (0, 0, h), (0, 0, -h),
+           (0.3, h, 0.0), (h, 0.2, -2.0), (3.0, -1.2, 0.4)]
+    rng = np.random.default_rng(4)
+    rpy += [(rng.uniform(-np.pi, np.pi), rng.uniform(-1.5, 1.5), rng.uniform(-np.pi, np.pi)) for _ in range(500)]
+    rpy = np.array(rpy, dtype=np.float64)
+    N = len(rpy)
+    body_q = euler2quat_sxyz(rpy[:, 0], rpy[:, 1], rpy[:, 2]) * rng.uniform(0.5, 2.0, (N, 1))   # any norm
+    psi = rng.uniform(-np.pi, np.pi, N)                       # root yaw for the goal-step frame
+    psi[:3] = [0.0, h, -h]
+    root_q = euler2quat_sxyz(np.zeros(N), np.zeros(N), psi)
+    theta = rng.uniform(-np.pi, np.pi, (N, 2))                 # target yaws
+    root_pos = rng.normal(0, 1, (N, 3))
+    tgt = rng.normal(0, 1, (N, 2, 3))
+    seq = np.zeros((N, _abi.OLY_MAX_SEQ, 4))
+    seq[:, 0, :3], seq[:, 1, :3] = tgt[:, 0], tgt[:, 1]
+    seq[:, 0, 3], seq[:, 1, 3] = theta[:, 0], theta[:, 1]
+    st = dict(phase=np.zeros(N, np.int32), t1=np.zeros(N, np.int32), t2=np.ones(N, np.int32),
+              reached_frames=np.zeros(N, np.int32), target_reached=np.zeros(N, np.uint8),
+              mode=np.full(N, _abi.MODE_FORWARD, np.int32), seq_len=np.full(N, 2, np.int32), sequence=seq,
+              goal=np.zeros((N, 8)))
+    far = np.full((N, 3), 50.0)
+    qpos = np.zeros((N, 25))
+    qpos[:, 3:7] = body_q
+    inp = dict(qpos=qpos, qvel=np.zeros((N, 24)), act_len=np.zeros((N, 12)), act_vel=np.zeros((N, 12)), lf_pos=far,
+               rf_pos=far.copy(), lf_vel=np.zeros((N, 3)), rf_vel=np.zeros((N, 3)), root_pos=root_pos, root_quat=root_q,
+               head_pos=root_pos.copy(), grf_l=np.zeros(N), grf_r=np.zeros(N), min_z=np.zeros(N),
+               n_r=np.zeros(N, np.int32), n_l=np.zeros(N, np.int32), bad=np.zeros(N, np.uint8))
+    return dict(state=st, inputs=inp, rpy=rpy, psi=psi, theta=theta, root_pos=root_pos, tgt=tgt)
+
+
+def check_a3_analytic(obs, goal, c):
+    rpy, psi, theta, root_pos, tgt = c["rpy"], c["psi"], c["theta"], c["root_pos"], c["tgt"]
+    N, h = len(rpy), np.pi / 2
+    # pitch = +-90 deg: roll and yaw are not separable; mat2euler puts the whole in-plane rotation
+    # into roll (ak = 0), so the expected roll there is roll -+ yaw
+    gimbal = np.isclose(np.abs(rpy[:, 1]), h)
+    roll = np.where(gimbal, rpy[:, 0] - np.sign(rpy[:, 1]) * rpy[:, 2], rpy[:, 0])
+    want = euler2quat_sxyz(roll, rpy[:, 1], np.zeros(N))
+    want = want * np.where(want[:, :1] < 0, -1.0, 1.0)        # roll in (-pi, pi], pitch in [-pi/2, pi/2]: w >= 0
+    np.testing.assert_allclose(obs[:, :4], want, rtol=0, atol=2e-12)
+    assert np.array_equal(obs[:3, :4].round(15), np.array([[1, 0, 0, 0]] * 3, float))       # identity / pure yaw
+    co, si = np.cos(psi), np.sin(psi)
+    for i in range(2):                                         # targets in the root's yaw frame
+        d = tgt[:, i] - root_pos
+        np.testing.assert_allclose(goal[:, 0 + i], co * d[:, 0] + si * d[:, 1], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(goal[:, 2 + i], -si * d[:, 0] + co * d[:, 1], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(goal[:, 4 + i], d[:, 2], rtol=0, atol=1e-12)
+        rel = theta[:, i] - psi
+        dth = np.arctan2(np.sin(goal[:, 6 + i] - rel), np.cos(goal[:, 6 + i] - rel))
+        np.testing.assert_allclose(dth, 0, atol=1e-12)
+    assert np.array_equal(obs[:, 41 - 8:], goal)

@@ -1,0 +1,71 @@
+"""Multi-rank path on a one-GPU box: two rank processes share cuda:0 (gloo rendezvous), each runs
+the real config-5 tail on its env shard.  The driver's 8-GPU run uses the same code over RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_config5_two_ranks_share_one_gpu(tmp_path):
+    """oly_return_scan_stats on each shard -> ONE all-gather of the device triples ->
+    oly_adv_normalize_parts: both ranks hold bit-identical [2,3] statistics; returns and raw
+    advantages equal the single-process block bit for bit (environments are independent); the
+    sharded statistics equal the single-process ones to 1e-12 (different but fixed summation
+    trees), the normalised advantages to 1 f32 ulp."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), str(tmp_path)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["parts"], r1["parts"]) and r0["parts"].shape == (2, 3)      # same on every rank
+    assert np.array_equal(r0["parts"][0], r0["local"]) and np.array_equal(r0["parts"][1], r1["local"])
+    assert (r0["lo"], r0["hi"], r1["lo"], r1["hi"]) == (0, 4096, 4096, 8192)
+    ret = np.concatenate([r0["ret"], r1["ret"]], axis=1)
+    assert np.array_equal(ret, r0["single_ret"])
+    tot = r0["parts"][0] + r0["parts"][1]
+    assert tot[0] == r0["single_stats"][0] == 400 * 8192
+    np.testing.assert_allclose(tot, r0["single_stats"], rtol=1e-12)
+    got = np.concatenate([r0["adv_norm"], r1["adv_norm"]], axis=1)
+    want = r0["single_adv_norm"]
+    assert np.abs(got - want).max() <= np.spacing(np.abs(want).max().astype(np.float32))
+    a = r0["single_adv"].astype(np.float64)
+    np.testing.assert_allclose(want, (a - a.mean()) / (a.std(ddof=1) + 1e-5), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("config", [5, 2])
+def test_bench_starts_its_own_ranks(config):
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two rank processes itself and reports
+    n_gpus = 2 (here both on cuda:0 over gloo; on an 8-GPU node one per GPU over RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--share-device", "--config", str(config), "--steps", "5", "--warmup", "2",
+                          "--T", "100", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["roofline"]["bound"] == "hbm"
+    if config == 5:
+        assert set(line["stages_ms"]) >= {"scan_with_fused_stats", "all_gather_host_wall", "normalise"}
+
+
+def test_bench_fails_loudly_when_a_rank_fails():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device",
+                          "--config", "5", "--steps", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0                        # --share-device without gloo is refused before any GPU work

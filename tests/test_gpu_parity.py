@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from olympic_hip import _abi, specs
-from helpers import a3_fixture_arrays, h1_rows_from_full, h1_synthetic_block, ulp_diff
+from helpers import (a3_analytic_cases, a3_fixture_arrays, check_a3_analytic, h1_rows_from_full, h1_synthetic_block,
+                     ulp_diff)
 
 pytestmark = pytest.mark.gpu
 
@@ -264,6 +265,77 @@ def test_scan_golden_ppo(eng, golden):
     np.testing.assert_allclose(host(adv)[:, 0], g["adv_norm"], rtol=2e-6, atol=2e-7)   # torch f32 mean/std
 
 
+def test_scan_golden_ppo_float64_rewards(eng, golden, oracle):
+    """env.step's reward is float64 and PPOBuffer never narrows it (rl/envs/wrappers.py:14,
+    rl/algos/ppo.py:74-76): with the reward handed over as float64 the returns are bit-exact for
+    rewards float32 cannot represent (the f32 path is exact only for f32 rewards)."""
+    g = golden("ppo_returns_f64.npz")
+    L = g["ep_len"]
+    n = int(L.sum())
+    flags = np.zeros(n, np.uint8)
+    nv = np.zeros(n, np.float32)
+    for e, dn, lv in zip(np.cumsum(L) - 1, g["done_tail"], g["last_val"]):
+        flags[e] = _abi.FLAG_LAST | (_abi.FLAG_ABSORBING if dn else 0)
+        nv[e] = lv
+    # [n,1] takes the scalar-load kernel, [n,4] (four copies side by side) the pipelined one
+    for reps in (1, 4):
+        tile = lambda a: dev(np.repeat(a[:, None], reps, axis=1))
+        ret, adv = eng.return_scan(_abi.SCAN_RETURN, float(g["gamma"]), 0.95, tile(g["rewards"]), tile(g["values"]),
+                                   tile(nv), tile(flags))
+        for c in range(reps):
+            assert np.array_equal(host(ret)[:, c], g["returns"])   # bit-exact vs PPOBuffer.finish_path
+            assert np.array_equal(host(adv)[:, c], g["adv"])
+
+
+@pytest.mark.parametrize("T,N", [(5, 3), (400, 4096), (97, 1028), (70, 16388), (45, 32776)])
+def test_scan_float64_rewards_vs_oracle(eng, oracle, T, N):
+    rng = np.random.default_rng(T + N)
+    r = rng.uniform(-0.3, 1, (T, N))
+    v, vn = (rng.normal(0, 1, (T, N)).astype(np.float32) for _ in range(2))
+    last = rng.uniform(size=(T, N)) < 1 / 30
+    flags = (last * _abi.FLAG_LAST + (last & (rng.uniform(size=(T, N)) < 0.5)) * _abi.FLAG_ABSORBING).astype(np.uint8)
+    ret, adv = eng.return_scan(_abi.SCAN_RETURN, 0.99, 0.0, dev(r), dev(v), dev(vn), dev(flags))
+    e_ret, e_adv = oracle.return_scan_r64(0.99, r, v, vn, flags)
+    assert np.array_equal(host(ret), e_ret) and np.array_equal(host(adv), e_adv)
+
+
+@pytest.mark.parametrize("mode", [_abi.SCAN_RETURN, _abi.SCAN_GAE])
+@pytest.mark.parametrize("T,N", [(1, 4), (400, 4096), (97, 1028), (33, 257), (70, 16388), (45, 32776)])
+def test_scan_fused_statistics(eng, oracle, mode, T, N):
+    """oly_return_scan_stats: ret / adv unchanged (bit-exact vs the oracle) and, from the same
+    pass, (count, sum adv, sum adv^2): fp64 sums in a fixed order, 1e-12 relative to the oracle's
+    sequential sums and bit-identical run to run."""
+    rng = np.random.default_rng(T * 3 + N)
+    r, v, vn = (rng.normal(0, 1, (T, N)).astype(np.float32) for _ in range(3))
+    last = rng.uniform(size=(T, N)) < 1 / 100
+    flags = (last * _abi.FLAG_LAST).astype(np.uint8)
+    st = torch.zeros(3, dtype=torch.float64, device="cuda")
+    ret, adv = eng.return_scan(mode, 0.99, 0.97, dev(r), dev(v), dev(vn), dev(flags), stats3=st)
+    e_ret, e_adv = oracle.return_scan(mode, 0.99, 0.97, r, v, vn, flags)
+    assert np.array_equal(host(ret), e_ret) and np.array_equal(host(adv), e_adv)
+    e_st = oracle.adv_stats(e_adv)
+    got = host(st)
+    assert got[0] == T * N
+    np.testing.assert_allclose(got[1:], e_st[1:], rtol=1e-12, atol=1e-9)
+    st2 = torch.zeros(3, dtype=torch.float64, device="cuda")
+    eng.return_scan(mode, 0.99, 0.97, dev(r), dev(v), dev(vn), dev(flags), stats3=st2)
+    assert torch.equal(st, st2)                                  # deterministic
+
+
+def test_adv_normalize_parts(eng, oracle):
+    """The multi-rank normalisation: [parts,3] triples combined on the device by the balanced
+    rank-order tree = the oracle's; 1 part = oly_adv_normalize."""
+    rng = np.random.default_rng(8)
+    x = rng.normal(0.2, 1.7, 400 * 1024).astype(np.float32)
+    for parts in (1, 2, 3, 8):
+        shards = np.array_split(x, parts)
+        p3 = np.stack([host(eng.adv_stats(dev(s))) for s in shards])
+        for ddof, eps in ((1, 1e-5), (0, 1e-8)):
+            got = host(eng.adv_normalize(dev(x), dev(p3) if parts > 1 else dev(p3[0]), ddof, eps))
+            assert np.array_equal(got, oracle.adv_normalize_parts(x, p3, ddof, eps))
+            np.testing.assert_allclose(got, (x - x.mean()) / (x.std(ddof=ddof) + eps), rtol=2e-5, atol=2e-6)
+
+
 # --------------------------------------------------------------------------------- K7
 @pytest.mark.parametrize("n", [1, 3, 1000, 4096 * 400 + 3])
 def test_adv_stats_normalize(eng, oracle, n):
@@ -417,6 +489,22 @@ def test_contacts_shapes(eng, oracle, N, C):
         assert np.array_equal(host(o[k]), e[k]), k
 
 
+def test_contacts_more_than_the_staged_slots(eng):
+    """ncon > C (or < 0): the surplus contacts were never staged, so the environment is flagged as
+    a bad collision instead of being reduced as if it had C contacts; the staged slots
+    are still counted.  (The oracle refuses such lists with OLY_ERANGE.)"""
+    gb = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)
+    eng.contact_configure(gb, 0, 7, 10)
+    N, C = 6, 4
+    ncon = np.array([4, 5, 9, -1, 0, 2], np.int32)
+    g1 = np.zeros((N, C), np.int32)                       # floor first
+    g2 = np.full((N, C), 8, np.int32)                     # right foot: every staged slot is a foot contact
+    f6 = np.ones((N, C, 6))
+    o = eng.contact_reduce(dev(ncon), dev(g1), dev(g2), dev(f6), dev(np.zeros((N, C))))
+    assert host(o["n_r"]).tolist() == [4, 4, 4, 0, 0, 2]
+    assert host(o["bad"]).tolist() == [0, 1, 1, 1, 0, 0]
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("OLY_FUZZ", "12"))))
 def test_contacts_random(eng, oracle, seed):
     """Random slot counts and densities (none .. every slot a foot contact), valid geom ids and
@@ -475,12 +563,25 @@ def test_a3_golden_sequence(eng, golden, oracle):
         np.testing.assert_allclose(host(o["obs"]), eo["obs"], rtol=1e-13, atol=1e-14)
 
 
-def test_a3_many_envs_vs_oracle(eng, golden, oracle):
+def test_a3_orientation_analytic_cases(eng, golden):
+    """transforms3d is absent (parity unpinned): get_obs' quat -> euler -> quat with the yaw dropped
+    and update_goal_steps' frame change are pinned on closed-form cases through oly_a3_step
+    (helpers.a3_analytic_cases: identity, pure yaw, +-90 deg about each axis, the gimbal branch,
+    round trips).  The oracle is held to the same cases in test_oracle_golden.py."""
+    g = golden("a3_task.npz")
+    eng.a3_configure(specs.A3Spec(mass=41.5), g["clock_lut"])
+    cases = a3_analytic_cases()
+    st_d = {k: dev(v) for k, v in cases["state"].items()}
+    o = eng.a3_step({k: dev(v) for k, v in cases["inputs"].items()}, st_d, obs_f64=True)
+    check_a3_analytic(host(o["obs"]), host(st_d["goal"]), cases)
+
+
+@pytest.mark.parametrize("N", [1500, 4096])
+def test_a3_many_envs_vs_oracle(eng, golden, oracle, N):
     g = golden("a3_task.npz")
     spec = specs.A3Spec(mass=41.5)
     eng.a3_configure(spec, g["clock_lut"])
     rng = np.random.default_rng(12)
-    N = 1500
     E = g["phase"].shape[0]
     pick = rng.integers(0, E, N)
     st_h, _ = a3_fixture_arrays(g, 0)

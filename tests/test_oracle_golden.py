@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from olympic_hip import _abi, specs
-from helpers import h1_rows_from_full, a3_fixture_arrays, ulp_diff
+from helpers import a3_analytic_cases, check_a3_analytic, h1_rows_from_full, a3_fixture_arrays, ulp_diff
 
 
 # ------------------------------------------------------------------------------ K1/K5
@@ -100,6 +100,35 @@ def test_ppo_finish_path(golden, oracle):
     assert st[0] == adv.size
     out = oracle.adv_normalize(adv, st, ddof=1, eps=float(g["eps"]))
     np.testing.assert_allclose(out[:, 0], g["adv_norm"], rtol=2e-6, atol=2e-7)
+
+
+def test_ppo_finish_path_float64_rewards(golden, oracle):
+    """Rewards float32 cannot represent (what env.step really returns): the f64-reward scan is
+    bit-exact vs PPOBuffer.finish_path, the f32-reward scan of the narrowed rewards is not."""
+    g = golden("ppo_returns_f64.npz")
+    flags, next_val = _ppo_block(g)
+    ret, adv = oracle.return_scan_r64(float(g["gamma"]), g["rewards"][:, None], g["values"][:, None],
+                                      next_val[:, None], flags[:, None])
+    assert np.array_equal(ret[:, 0], g["returns"])
+    assert np.array_equal(adv[:, 0], g["adv"])
+    ret32, _ = oracle.return_scan(_abi.SCAN_RETURN, float(g["gamma"]), 0.95, g["rewards"][:, None].astype(np.float32),
+                                  g["values"][:, None], next_val[:, None], flags[:, None])
+    d = ulp_diff(ret32[:, 0], g["returns"])
+    assert d.max() <= 2.0 and (d > 0).any()                  # narrowing the reward first costs last-place bits
+
+
+def test_adv_normalize_parts_tree(oracle):
+    """Rank triples are combined by a balanced pairwise tree in rank order; 1 part = plain normalise."""
+    rng = np.random.default_rng(3)
+    x = rng.normal(0.1, 1.3, 4096).astype(np.float32)
+    shards = np.split(x, 8)
+    parts = np.stack([oracle.adv_stats(s) for s in shards])
+    tot = ((parts[0] + parts[1]) + (parts[2] + parts[3])) + ((parts[4] + parts[5]) + (parts[6] + parts[7]))
+    assert np.array_equal(oracle.adv_normalize_parts(x, parts, 1, 1e-5), oracle.adv_normalize(x, tot, 1, 1e-5))
+    assert np.array_equal(oracle.adv_normalize_parts(x, parts[:1], 0, 1e-8), oracle.adv_normalize(x, parts[0], 0, 1e-8))
+    p3 = parts[:3]                                            # non power of two: padded with zeros
+    assert np.array_equal(oracle.adv_normalize_parts(x, p3, 1, 1e-5),
+                          oracle.adv_normalize(x, (p3[0] + p3[1]) + (p3[2] + 0.0), 1, 1e-5))
 
 
 def test_ppo_reference_smoke_value():
@@ -438,3 +467,13 @@ def test_rollout_cuts_hand_case(oracle):
     assert fl.tolist() == [0, 3, 0, 2] and tl.tolist() == [4, 0, 9, 0] and nc == 2
     fl, tl, nc = oracle.rollout_cuts([0, 1, 0, 0], [3, 3, 8, 9], 10, True)
     assert fl.tolist() == [2, 3, 2, 2] and tl.tolist() == [0, 0, 0, 0] and nc == 4
+
+
+def test_a3_orientation_analytic_cases(golden, oracle):
+    """transforms3d boundary (parity unpinned): the oracle's quaternion / euler algebra on
+    closed-form cases (identity, pure yaw, +-90 deg, gimbal branch, round trips)."""
+    g = golden("a3_task.npz")
+    c = a3_analytic_cases()
+    st = {k: v.copy() for k, v in c["state"].items()}
+    eo = oracle.a3_step(specs.A3Spec(mass=41.5), g["clock_lut"], c["inputs"], st)
+    check_a3_analytic(eo["obs"], st["goal"], c)
