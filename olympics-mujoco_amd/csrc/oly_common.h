@@ -68,6 +68,7 @@ struct oly_ctx {
   bool grf_ok;
   double* stats_ws;  // device [OLY_STATS_MAX_BLOCKS * 2 * OLY_MAX_OBS... ] partial sums
   size_t stats_ws_bytes;
+  bool mlp_attr_done = false;   // dynamic-LDS limit of the fused MLP kernel raised on this device
   unsigned scan_attr_done = 0;  // dynamic-LDS limit of the pipelined scan kernels raised on this device
   int num_cu;
 };

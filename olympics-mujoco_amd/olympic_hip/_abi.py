@@ -57,6 +57,35 @@ class A3State(C.Structure):
     _fields_ = [(n, vp) for n in A3_STATE_FIELDS]
 
 
+A3_BLOCK_F64 = ["qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel", "rf_vel", "root_pos", "root_quat",
+                "head_pos"]
+A3_BLOCK_TAIL = ["ncon", "geom1", "geom2", "force6", "cpos_z"]
+
+
+class A3Blocks(C.Structure):
+    """oly_a3_blocks: [K,N,...] device blocks of K consecutive physics readbacks."""
+    _fields_ = [("K", C.c_int32), ("C", C.c_int32)] + [(n, vp) for n in A3_BLOCK_F64 + A3_BLOCK_TAIL]
+
+
+class A3ResetRecord(C.Structure):
+    """oly_a3_reset_record: one pre-drawn WalkingTask.reset (656 bytes)."""
+    _fields_ = [("mode", C.c_int32), ("phase", C.c_int32), ("seq_len", C.c_int32), ("pad", C.c_int32),
+                ("seq", (C.c_double * 4) * 20)]
+
+
+class A3Rollout(C.Structure):
+    """oly_a3_rollout: policy outputs, rollout-buffer rows, side list, reset pool, device counters."""
+    _fields_ = [("T", C.c_int32), ("max_traj_len", C.c_int32), ("deterministic", C.c_int32), ("pad0", C.c_int32),
+                ("mu", vp), ("value", vp), ("scale", vp), ("eps", vp), ("state", vp), ("pd_target", vp),
+                ("buf_states", vp), ("buf_actions", vp), ("buf_rewards", vp), ("buf_values", vp), ("buf_flags", vp),
+                ("buf_rew6", vp), ("traj_len", vp),
+                ("side_slots", C.c_int32), ("pad1", C.c_int32), ("side_obs", vp), ("side_t", vp), ("side_count", vp),
+                ("pool_depth", C.c_int32), ("pad2", C.c_int32), ("pool", vp), ("pool_count", vp),
+                ("ctr", vp)]
+
+
+VSTEP_RESET_ALL = 1
+
 # oly_a3_readback: per-env slots of the pinned staging (11 double arrays, ncon/geom1/geom2 int32, force6, cpos_z)
 A3_READBACK_FIELDS = (("qpos", C.c_double), ("qvel", C.c_double), ("act_len", C.c_double), ("act_vel", C.c_double),
                       ("lf_pos", C.c_double), ("rf_pos", C.c_double), ("lf_vel", C.c_double), ("rf_vel", C.c_double),
@@ -118,8 +147,13 @@ SIGNATURES = {
     "oly_a3_configure": (C.c_int, [vp, C.POINTER(A3Model)]),
     "oly_a3_step": (C.c_int, [vp, C.c_int, C.POINTER(A3Inputs), C.POINTER(A3State), vp, vp, vp, vp,
                               C.c_int, vp]),
+    "oly_a3_vec_ctr_len": (C.c_int, [C.c_int]),
+    "oly_a3_vec_step": (C.c_int, [vp, C.c_int, C.POINTER(A3Blocks), C.POINTER(A3State), C.POINTER(A3Rollout), C.c_int, vp]),
     "oly_a3_pd_target": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "oly_a3_pd_torque": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "oly_mlp_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "oly_mlp_pack": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "oly_mlp_forward2": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]),
     "oly_return_scan": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                   vp, vp, vp, vp, vp, vp, vp]),
     "oly_return_scan_stats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,

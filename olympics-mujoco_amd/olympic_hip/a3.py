@@ -108,13 +108,19 @@ class WalkingTaskReset:
 
 
 def yaw_of_quat(q):
-    """transforms3d quat2euler(q)[2] (sxyz) of a (w,x,y,z) quaternion."""
-    w, x, y, z = q
+    """transforms3d quat2euler(q)[2] (sxyz) of a (w,x,y,z) quaternion = mat2euler(quat2mat(q))[2]:
+    the same expressions, in the same order, as the device-side transform_sequence (k10_vec_step.hip)."""
+    w, x, y, z = (float(v) for v in q)
     n = w * w + x * x + y * y + z * z
+    if n < np.finfo(np.float64).eps:
+        return 0.0
     s = 2.0 / n
-    r00 = 1.0 - (y * y + z * z) * s
-    r10 = (x * y + w * z) * s
-    return np.arctan2(r10, r00)
+    X, Y, Z = x * s, y * s, z * s
+    r00 = 1.0 - (y * Y + z * Z)
+    r10 = x * Y + w * Z
+    if np.sqrt(r00 * r00 + r10 * r10) > 4.0 * np.finfo(np.float64).eps:
+        return float(np.arctan2(r10, r00))
+    return 0.0
 
 
 class VecA3Env:
@@ -166,6 +172,19 @@ class VecA3Env:
         self.iteration_count = d["iteration_count"]
         for k, v in self.state.items():
             v.copy_(d[k])
+
+    @property
+    def has_device_physics(self):
+        """True when the physics readback is a set of device-resident [K,N,...] blocks: the whole
+        rollout loop can then stay on the device (vecstep.A3DeviceRollout)."""
+        return isinstance(self.physics, ReplayA3Physics)
+
+    def device_rollout(self, policy, critic, T, max_traj_len, deterministic=False, anneal=1.0, graph=True, **kw):
+        """PPO.sample for all N environments with one fused launch per vec step (K10)."""
+        if getattr(self, "_dev_rollout", None) is None:
+            from .vecstep import A3DeviceRollout
+            self._dev_rollout = A3DeviceRollout(self, self.physics.blocks, rs=self._reset_one.rs)
+        return self._dev_rollout.rollout(policy, critic, T, max_traj_len, deterministic, anneal, graph, **kw)
 
     def step(self, actions):
         """(obs [N,41], total_reward [N], done [N] bool, rewards [N,6])  StickFigureA3.py:187-200."""

@@ -258,6 +258,70 @@ class Engine:
                       _abi.OUT_OBS_F64 if obs_f64 else 0, self._s())
         return dict(obs=obs, rew6=rew6, reward=reward, done=done)
 
+    # -------------------------------------------------------------- K10 (one launch per vec step)
+    def a3_vec_ctr_len(self, N):
+        from ._ffi import lib
+        return int(lib().oly_a3_vec_ctr_len(int(N)))
+
+    def a3_vec_prepare(self, blocks, state, ro):
+        """Validate every tensor of a device-resident rollout ONCE and return `launch(flags=0, mu=None,
+        value=None)`, which enqueues oly_a3_vec_step on the current stream (mu / value may be swapped
+        per call for an eager policy forward; everything else is fixed, so the launch is replayable
+        from a HIP graph).
+          blocks: dict of [K,N,...] readback tensors (oly_a3_blocks fields)
+          state:  the VecA3Env task-state dict (oly_a3_state fields; mode / seq_len / sequence are
+                  rewritten by device-side resets)
+          ro:     dict with T, max_traj_len, deterministic, side_slots, pool_depth (ints) and the
+                  tensors mu, value, scale, eps, state, pd_target, buf_states, buf_actions,
+                  buf_rewards, buf_values, buf_flags, buf_rew6 (or None), traj_len, side_obs, side_t,
+                  side_count, pool (uint8 [N*pool_depth*656]), pool_count, ctr."""
+        sp = self.a3_spec
+        if sp is None or not self.contact_ok:
+            raise OlyError("a3_vec_prepare before a3_configure / contact_configure")
+        dv, f32, f64, i32, u8 = self.device, torch.float32, torch.float64, torch.int32, torch.uint8
+        K, N = (int(v) for v in blocks["qpos"].shape[:2])
+        Cc = int(blocks["geom1"].shape[2])
+        cb = _abi.A3Blocks()
+        cb.K, cb.C = K, Cc
+        shapes = dict(qpos=(sp.nq,), qvel=(sp.nv,), act_len=(sp.nu,), act_vel=(sp.nu,), lf_pos=(3,), rf_pos=(3,),
+                      lf_vel=(3,), rf_vel=(3,), root_pos=(3,), root_quat=(4,), head_pos=(3,), ncon=(), geom1=(Cc,),
+                      geom2=(Cc,), force6=(Cc, 6), cpos_z=(Cc,))
+        for name, tail in shapes.items():
+            dt = i32 if name in ("ncon", "geom1", "geom2") else f64
+            setattr(cb, name, _req(blocks.get(name), name, (K, N) + tail, dt, dv).data_ptr())
+        cst = self._a3_struct(_abi.A3State, self._A3_ST, state, N)
+        T, nobs, nu = int(ro["T"]), sp.n_obs, sp.nu
+        slots, depth = int(ro["side_slots"]), int(ro["pool_depth"])
+        det = bool(ro["deterministic"])
+        cr = _abi.A3Rollout()
+        cr.T, cr.max_traj_len, cr.deterministic = T, int(ro["max_traj_len"]), int(det)
+        cr.side_slots, cr.pool_depth = slots, depth
+        spec = dict(mu=((N, nu), f32), value=((N,), f32), scale=((nu,), f32), eps=((T, N, nu), f32),
+                    state=((N, nobs), f32), pd_target=((N, nu), f64), buf_states=((T, N, nobs), f32),
+                    buf_actions=((T, N, nu), f32), buf_rewards=((T, N), f64), buf_values=((T, N), f32),
+                    buf_flags=((T, N), u8), buf_rew6=((T, N, 6), f32), traj_len=((N,), i32),
+                    side_obs=((N * slots, nobs), f32), side_t=((N * slots,), i32), side_count=((N,), i32),
+                    pool=((N * depth * C.sizeof(_abi.A3ResetRecord),), u8), pool_count=((N,), i32),
+                    ctr=((self.a3_vec_ctr_len(N),), i32))
+        optional = {"buf_rew6"} | ({"scale", "eps"} if det else set())
+        for name, (shape, dt) in spec.items():
+            tns = _req(ro.get(name), name, shape, dt, dv, optional=name in optional)
+            setattr(cr, name, None if tns is None else tns.data_ptr())
+        keep = (blocks, state, ro)          # the structs hold raw addresses: keep the tensors alive
+        from ._ffi import check, lib
+        fn, h = lib().oly_a3_vec_step, self.ctx.handle
+
+        def launch(flags=0, mu=None, value=None):
+            if mu is not None:
+                cr.mu = _req(mu, "mu", (N, nu), f32, dv).data_ptr()
+            if value is not None:
+                cr.value = _req(value, "value", (N,), f32, dv).data_ptr()
+            rc = fn(h, N, C.byref(cb), C.byref(cst), C.byref(cr), int(flags), self._s())
+            if rc:
+                check(h, rc, "oly_a3_vec_step")
+            return keep
+        return launch
+
     def a3_pd_target(self, action):
         sp = self.a3_spec
         N = int(action.shape[0])
@@ -277,6 +341,41 @@ class Engine:
         self.ctx.call("oly_a3_pd_torque", N, ptr(kp), ptr(kd), ptr(target), ptr(act_len), ptr(act_vel), ptr(tau),
                       self._s())
         return tau
+
+    # -------------------------------------------------------------- K11 (fused MLP forward)
+    def mlp_pack(self, w1, b1, w2, b2, w3, b3, in_mean=None, in_std=None, packed=None):
+        """torch Linear parameters of a relu MLP in -> 256 -> 256 -> out -> packed operand stream."""
+        from ._ffi import lib
+        f32, dv = torch.float32, self.device
+        H, in_dim = (int(v) for v in w1.shape)
+        out_dim = int(w3.shape[0])
+        n = int(lib().oly_mlp_packed_floats(in_dim, H, out_dim))
+        if n < 0 or tuple(w2.shape) != (H, H) or int(w3.shape[1]) != H:
+            raise OlyError(f"mlp_pack: unsupported MLP shape {in_dim} -> {tuple(w2.shape)} -> {out_dim}")
+        for t, name, shape in ((w1, "w1", (H, in_dim)), (b1, "b1", (H,)), (w2, "w2", (H, H)), (b2, "b2", (H,)),
+                               (w3, "w3", (out_dim, H)), (b3, "b3", (out_dim,))):
+            _req(t, name, shape, f32, dv)
+        _req(in_mean, "in_mean", (in_dim,), f32, dv, optional=True)
+        _req(in_std, "in_std", (in_dim,), f32, dv, optional=True)
+        packed = _req(packed if packed is not None else self._new((n,), f32), "packed", (n,), f32, dv)
+        self.ctx.call("oly_mlp_pack", in_dim, H, out_dim, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
+                      ptr(in_mean), ptr(in_std), ptr(packed), self._s())
+        return packed
+
+    def mlp_forward2(self, x, packed_a, out_a, y_a, packed_b=None, out_b=0, y_b=None, normalize_a=False,
+                     normalize_b=False):
+        """y_a = net_a(x) and (optionally) y_b = net_b(x) in one launch; x [N,in] f32."""
+        N, in_dim = (int(v) for v in x.shape)
+        f32, dv = torch.float32, self.device
+        _req(x, "x", (N, in_dim), f32, dv)
+        _req(packed_a, "packed_a", packed_a.shape, f32, dv)
+        _req(y_a, "y_a", (N, int(out_a)), f32, dv)
+        if packed_b is not None:
+            _req(packed_b, "packed_b", packed_b.shape, f32, dv)
+            _req(y_b, "y_b", (N, int(out_b)), f32, dv)
+        self.ctx.call("oly_mlp_forward2", N, in_dim, ptr(x), ptr(packed_a), int(out_a), int(bool(normalize_a)), ptr(y_a),
+                      ptr(packed_b), int(out_b), int(bool(normalize_b)), ptr(y_b), self._s())
+        return y_a, y_b
 
     # -------------------------------------------------------------- K6
     def return_scan(self, mode, gamma, lam, rew, val, next_val, flags, ret=None, adv=None, stats3=None):

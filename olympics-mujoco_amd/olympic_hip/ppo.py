@@ -310,6 +310,10 @@ class PPO:
     @torch.no_grad()
     def sample_vec(self, env, policy, critic, T, max_traj_len, deterministic=False, anneal=1.0):
         """N envs x T steps; episode cuts as in PPO.sample (:169-196)."""
+        if getattr(self, "use_device_rollout", True) and getattr(env, "has_device_physics", False):
+            # physics readback resident on the device: one fused launch per vec step, replayed from a graph
+            return env.device_rollout(policy, critic, T, max_traj_len, deterministic, anneal,
+                                      graph=bool(getattr(self, "use_graph_rollout", False)))
         N, dev = env.num_envs, env.device
         obs_dim = int(np.prod(env.observation_space.shape)) if hasattr(env, "observation_space") else env.spec.n_obs
         act_dim = int(np.prod(env.action_space.shape)) if hasattr(env, "action_space") else env.spec.n_act

@@ -37,3 +37,39 @@ def h1_synthetic_block(spec, T, N, seed=1234, fall_frac="bench"):
     qpos, qvel = h1_rows_from_full(spec, full)
     action = np.random.default_rng(seed + 1).uniform(-1, 1, (R, spec.n_act)).astype(np.float32)
     return qpos.reshape(T, N, -1), qvel.reshape(T, N, -1), action.reshape(T, N, -1)
+
+
+A3_GEOM_BODYID = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32)   # geoms 7,8 right foot; 11,12 left foot
+A3_FLOOR_BODY, A3_RFOOT_BODY, A3_LFOOT_BODY = 0, 7, 10
+
+
+def a3_synthetic_blocks(N, K, seed=1, C=16, p_bad=1.0 / 300, p_low=0.0):
+    """Config 3: K consecutive synthetic physics readbacks for N StickFigureA3 environments
+    as numpy arrays [K,N,...] (oly_a3_blocks fields): qpos / qvel ~ N(0,1), feet around a footstep
+    grid, root 0.8 m above them, unit root quaternions, contact lists with ncon ~ Poisson(4) clipped to
+    C whose slots are all (floor, foot) pairs except that with probability p_bad per (step, env) one
+    slot is a non-foot geom (check_bad_collisions -> done); p_low: probability of a root height that
+    trips the done height test."""
+    rng = np.random.default_rng(seed)
+    rnd = lambda *s: rng.normal(0, 1, s)
+    base = np.zeros((N, 3)) + np.array([0.3, 0.15, 0.0])
+    b = dict(qpos=rnd(K, N, 25), qvel=rnd(K, N, 24), act_len=rnd(K, N, 12), act_vel=rnd(K, N, 12),
+             lf_pos=base + 0.1 * rnd(K, N, 3), rf_pos=base + 0.3 * rnd(K, N, 3), lf_vel=0.2 * rnd(K, N, 3),
+             rf_vel=0.2 * rnd(K, N, 3), root_quat=rnd(K, N, 4), force6=100 * rnd(K, N, C, 6),
+             cpos_z=0.01 * rnd(K, N, C))
+    b["lf_pos"][..., 2] = np.abs(b["lf_pos"][..., 2]) * 0.3
+    b["rf_pos"][..., 2] = np.abs(b["rf_pos"][..., 2]) * 0.1
+    foot = np.minimum(b["lf_pos"][..., 2], b["rf_pos"][..., 2])
+    low = rng.uniform(size=(K, N)) < p_low
+    b["root_pos"] = base + 0.05 * rnd(K, N, 3)
+    b["root_pos"][..., 2] = foot + np.where(low, 0.5, 0.8) + 0.02 * np.abs(rnd(K, N))
+    b["head_pos"] = b["root_pos"] + np.array([0, 0, 0.4]) + 0.05 * rnd(K, N, 3)
+    b["root_quat"] /= np.linalg.norm(b["root_quat"], axis=-1, keepdims=True)
+    b["ncon"] = np.minimum(rng.poisson(4, (K, N)), C).astype(np.int32)
+    b["geom1"] = np.zeros((K, N, C), np.int32)
+    b["geom2"] = rng.choice([7, 8, 11, 12], (K, N, C)).astype(np.int32)
+    hit = (rng.uniform(size=(K, N)) < p_bad) & (b["ncon"] > 0)
+    slot = rng.integers(0, 1 << 30, (K, N)) % np.maximum(b["ncon"], 1)
+    kk, nn = np.nonzero(hit)
+    b["geom2"][kk, nn, slot[kk, nn]] = 9
+    return {k: np.ascontiguousarray(v) for k, v in b.items()}

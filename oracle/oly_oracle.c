@@ -492,6 +492,187 @@ int oly_a3_pd_torque_cpu(const oly_a3_model* m, int N, const double* kp, const d
   return OLY_OK;
 }
 
+/* ====================================================================== K10 (vec step) */
+
+/* One vec step of PPO.sample (rl/algos/ppo.py:169-196) for N StickFigureA3 environments, row by
+   row, composed from the pieces above exactly as the reference's loop orders them:
+     action = Normal(mu, std*anneal).sample() with the noise given          ppo.py:181
+     memory.store(state, action, reward, value)                             ppo.py:186
+     JVRC.step target                                                       robot.py:88-95
+     contacts -> task.step / calc_reward / done / get_obs                   StickFigureA3.py:187-200
+     traj_len / cut, finish_path's bootstrap row                            ppo.py:178,189-196
+     env.reset() of a cut environment: WalkingTask.reset from a pre-drawn record
+       (walking_task.py:321-397), transform_sequence (:113-135), get_obs with the goal steps
+       zero and the clock of the drawn phase                                StickFigureA3.py:205-235
+   ctr[0] = t, ctr[1] = k (advanced by one unless OLY_VSTEP_RESET_ALL).  Host pointers.       */
+int oly_a3_vec_step_cpu(const oly_a3_model* m, int ngeom, const int32_t* geom_bodyid, int floor_body,
+                        int rfoot_body, int lfoot_body, int N, const oly_a3_blocks* b,
+                        const oly_a3_state* st, const oly_a3_rollout* ro, int flags) {
+  if (!m || !b || !st || !ro || b->K <= 0 || ro->pool_depth <= 0 || m->nu > 16) return OLY_EINVAL;
+  const int nu = m->nu, n_obs = 7 + 2 * nu + 10, C = b->C;
+  const int reset_all = (flags & OLY_VSTEP_RESET_ALL) != 0;
+  const int t = ro->ctr[0], k = ro->ctr[1];
+  const int kk = (int)((unsigned)k % (unsigned)b->K);
+  const size_t tN = (size_t)t * N, kN = (size_t)kk * N;
+  for (int n = 0; n < N; ++n) {
+    if (!reset_all) {
+      for (int j = 0; j < nu; ++j) {
+        float mu = ro->mu[(size_t)n * nu + j], a = mu;
+        if (!ro->deterministic) {
+          float sc = ro->scale[j] * ro->eps[(tN + n) * nu + j];
+          a = mu + sc;
+        }
+        ro->buf_actions[(tN + n) * nu + j] = a;
+        ro->pd_target[(size_t)n * nu + j] = (double)a + m->motor_offset[j];
+      }
+      memcpy(ro->buf_states + (tN + n) * n_obs, ro->state + (size_t)n * n_obs, sizeof(float) * n_obs);
+      ro->buf_values[tN + n] = ro->value[n];
+    }
+    /* contacts of readback row kk; a count beyond the staged slots is a bad collision (as the kernel) */
+    int32_t nc_raw = b->ncon[kN + n], nc = nc_raw < 0 ? 0 : (nc_raw > C ? C : nc_raw);
+    int32_t n_r, n_l;
+    double grf_r, grf_l, min_z;
+    uint8_t bad;
+    int rc0 = oly_contact_reduce_cpu(ngeom, geom_bodyid, floor_body, rfoot_body, lfoot_body, 1, C, &nc,
+                                     b->geom1 + (kN + n) * C, b->geom2 + (kN + n) * C,
+                                     b->force6 + (kN + n) * C * 6, b->cpos_z + (kN + n) * C, &n_r, &n_l, NULL,
+                                     NULL, &grf_r, &grf_l, &min_z, &bad);
+    if (rc0 != OLY_OK) return rc0;
+    if (nc != nc_raw) bad = 1;
+    /* a one-env view of the inputs and of the task state for a3_row */
+    oly_a3_inputs in;
+    in.qpos = b->qpos + (kN + n) * m->nq; in.qvel = b->qvel + (kN + n) * m->nv;
+    in.act_len = b->act_len + (kN + n) * nu; in.act_vel = b->act_vel + (kN + n) * nu;
+    in.lf_pos = b->lf_pos + (kN + n) * 3; in.rf_pos = b->rf_pos + (kN + n) * 3;
+    in.lf_vel = b->lf_vel + (kN + n) * 3; in.rf_vel = b->rf_vel + (kN + n) * 3;
+    in.root_pos = b->root_pos + (kN + n) * 3; in.root_quat = b->root_quat + (kN + n) * 4;
+    in.head_pos = b->head_pos + (kN + n) * 3;
+    in.grf_l = &grf_l; in.grf_r = &grf_r; in.min_z = &min_z; in.n_r = &n_r; in.n_l = &n_l; in.bad = &bad;
+    int32_t phase = st->phase[n], t1 = st->t1[n], t2 = st->t2[n], frames = st->reached_frames[n];
+    uint8_t reached = st->target_reached[n];
+    double goal[8];
+    oly_a3_state s1;
+    s1.phase = &phase; s1.t1 = &t1; s1.t2 = &t2; s1.reached_frames = &frames; s1.target_reached = &reached;
+    s1.mode = st->mode + n; s1.seq_len = st->seq_len + n;
+    s1.sequence = st->sequence + (size_t)n * OLY_MAX_SEQ * 4; s1.goal = goal;
+    double obs[64], rew[6], tot;
+    uint8_t done;
+    a3_row(m, 0, &in, &s1, obs, rew, &tot, &done);
+    int len = ro->traj_len[n] + 1;
+    int cut = done || len >= ro->max_traj_len || t == ro->T - 1;
+    int need_reset = reset_all || (cut && t < ro->T - 1);
+    if (!reset_all) {
+      ro->buf_rewards[tN + n] = tot;
+      if (ro->buf_rew6)
+        for (int i = 0; i < 6; ++i) ro->buf_rew6[(tN + n) * 6 + i] = (float)rew[i];
+      ro->buf_flags[tN + n] = (uint8_t)((cut ? OLY_FLAG_LAST : 0) | (done ? OLY_FLAG_ABSORBING : 0));
+      ro->traj_len[n] = cut ? 0 : len;
+      if (cut && !done) { /* finish_path(last_val = (not done) * V(state)): V of THIS observation */
+        int sc = ro->side_count[n];
+        if (sc < ro->side_slots) {
+          size_t srow = (size_t)n * ro->side_slots + sc;
+          for (int c = 0; c < n_obs; ++c) ro->side_obs[srow * n_obs + c] = (float)obs[c];
+          ro->side_t[srow] = t;
+        }
+        ro->side_count[n] = sc + 1;
+      }
+    }
+    float* next = ro->state + (size_t)n * n_obs;
+    for (int c = 0; c < n_obs; ++c) next[c] = (float)obs[c];
+    if (need_reset) {
+      int rc = ro->pool_count[n];
+      const oly_a3_reset_record* rec = ro->pool + (size_t)n * ro->pool_depth + (unsigned)rc % (unsigned)ro->pool_depth;
+      int new_len = rec->seq_len < 1 ? 1 : (rec->seq_len > OLY_MAX_SEQ ? OLY_MAX_SEQ : rec->seq_len);
+      /* transform_sequence: mid point of the feet, root yaw = quat2euler(root xquat)[2] */
+      double R[3][3];
+      quat2mat(in.root_quat, R);
+      double cy = sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
+      double root_yaw = (cy > 4.0 * 2.220446049250313e-16) ? atan2(R[1][0], R[0][0]) : 0.0;
+      double cyw = cos(root_yaw), syw = sin(root_yaw);
+      double mid0 = (in.lf_pos[0] + in.rf_pos[0]) / 2, mid1 = (in.lf_pos[1] + in.rf_pos[1]) / 2;
+      double* seq = (double*)st->sequence + (size_t)n * OLY_MAX_SEQ * 4;
+      for (int r = 0; r < OLY_MAX_SEQ; ++r) {
+        if (r < new_len) {
+          double x = rec->seq[r][0], y = rec->seq[r][1];
+          seq[4 * r] = mid0 + x * cyw - y * syw;
+          seq[4 * r + 1] = mid1 + x * syw + y * cyw;
+          seq[4 * r + 2] = rec->seq[r][2];
+          seq[4 * r + 3] = root_yaw + rec->seq[r][3];
+        } else {
+          seq[4 * r] = seq[4 * r + 1] = seq[4 * r + 2] = seq[4 * r + 3] = 0.0;
+        }
+      }
+      st->phase[n] = rec->phase;
+      st->t1[n] = 0;
+      st->t2[n] = (new_len == 1) ? 0 : 1; /* t1 = t2 = 0, then update_target_steps :228-244 */
+      st->reached_frames[n] = 0;
+      st->target_reached[n] = 0;
+      ((int32_t*)st->mode)[n] = rec->mode;
+      ((int32_t*)st->seq_len)[n] = new_len;
+      for (int i = 0; i < 8; ++i) st->goal[8 * (size_t)n + i] = 0.0;
+      ro->pool_count[n] = rc + 1;
+      /* get_obs of the un-advanced task: clock of the drawn phase, goal steps zero */
+      double ang = 2 * PI * rec->phase / (double)m->period;
+      next[7 + 2 * nu] = (float)sin(ang);
+      next[8 + 2 * nu] = (float)cos(ang);
+      for (int i = 0; i < 8; ++i) next[9 + 2 * nu + i] = 0.0f;
+    } else {
+      st->phase[n] = phase; st->t1[n] = t1; st->t2[n] = t2;
+      st->reached_frames[n] = frames; st->target_reached[n] = reached;
+      for (int i = 0; i < 8; ++i) st->goal[8 * (size_t)n + i] = goal[i];
+    }
+  }
+  if (!reset_all) {
+    ro->ctr[0] = t + 1;
+    ro->ctr[1] = k + 1;
+  }
+  return OLY_OK;
+}
+
+/* ============================================================================== K11 */
+
+/* One ReLU MLP in -> 256 -> 256 -> out as the f32 matrix cores evaluate it: every pre-activation is
+   the fmaf chain over k ascending from 0, bias added after the chain; the output layer runs four
+   chains over the k quarters [64w, 64w + 64) and adds them in order w = 0..3, then the bias.
+   Gaussian_FF_Actor._get_dist_params (rl/policies/actor.py:180-195) / FF_V.forward (critic.py:62-74)
+   up to the summation order of the Linear layers.                                                 */
+int oly_mlp_forward_cpu(int N, int in_dim, int out_dim, const float* x, const float* w1, const float* b1,
+                        const float* w2, const float* b2, const float* w3, const float* b3,
+                        const float* in_mean, const float* in_std, float* y) {
+  enum { H = 256 };
+  if (in_dim > 64 || out_dim > 32) return OLY_ERANGE;
+  for (int n = 0; n < N; ++n) {
+    float xin[64], h1[H], h2[H];
+    for (int k = 0; k < in_dim; ++k) {
+      float v = x[(size_t)n * in_dim + k];
+      if (in_mean && in_std) v = (v - in_mean[k]) / in_std[k];
+      xin[k] = v;
+    }
+    for (int j = 0; j < H; ++j) {
+      float acc = 0.0f;
+      for (int k = 0; k < in_dim; ++k) acc = fmaf(xin[k], w1[(size_t)j * in_dim + k], acc);
+      float v = acc + b1[j];
+      h1[j] = (v > 0.0f || v != v) ? v : 0.0f;
+    }
+    for (int j = 0; j < H; ++j) {
+      float acc = 0.0f;
+      for (int k = 0; k < H; ++k) acc = fmaf(h1[k], w2[(size_t)j * H + k], acc);
+      float v = acc + b2[j];
+      h2[j] = (v > 0.0f || v != v) ? v : 0.0f;
+    }
+    for (int j = 0; j < out_dim; ++j) {
+      float s = 0.0f;
+      for (int w = 0; w < 4; ++w) {
+        float acc = 0.0f;
+        for (int k = 64 * w; k < 64 * w + 64; ++k) acc = fmaf(h2[k], w3[(size_t)j * H + k], acc);
+        s = (w == 0) ? acc : s + acc;
+      }
+      y[(size_t)n * out_dim + j] = s + b3[j];
+    }
+  }
+  return OLY_OK;
+}
+
 /* ============================================================================== K6 */
 
 int oly_return_scan_cpu(int mode, int T, int N, double gamma, double lam, const float* rew,

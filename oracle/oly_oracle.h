@@ -60,6 +60,14 @@ int oly_a3_pd_torque_cpu(const oly_a3_model* m, int N, const double* kp, const d
                          const double* target, const double* act_len, const double* act_vel,
                          double* tau);
 
+int oly_a3_vec_step_cpu(const oly_a3_model* m, int ngeom, const int32_t* geom_bodyid, int floor_body,
+                        int rfoot_body, int lfoot_body, int N, const oly_a3_blocks* b,
+                        const oly_a3_state* st, const oly_a3_rollout* ro, int flags);
+
+int oly_mlp_forward_cpu(int N, int in_dim, int out_dim, const float* x, const float* w1, const float* b1,
+                        const float* w2, const float* b2, const float* w3, const float* b3,
+                        const float* in_mean, const float* in_std, float* y);
+
 int oly_return_scan_cpu(int mode, int T, int N, double gamma, double lam, const float* rew,
                         const float* val, const float* next_val, const uint8_t* flags, float* ret,
                         float* adv);

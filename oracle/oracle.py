@@ -168,6 +168,51 @@ def a3_step(spec, clock_lut, inputs, state, obs_f64=True):
     return dict(obs=obs, rew6=rew6, reward=reward, done=done, rew6_f64=rew6_64, reward_f64=reward_64)
 
 
+def a3_vec_step(spec, clock_lut, contact, blocks, state, ro, flags=0):
+    """oly_a3_vec_step_cpu on numpy arrays, IN PLACE (state / ro arrays are updated like the device
+    buffers).  contact = (geom_bodyid, floor, rfoot, lfoot); blocks / state / ro use the field names of
+    oly_a3_blocks / oly_a3_state / oly_a3_rollout; ro["pool"] is a uint8 array of packed records;
+    ro["ctr"] is an int32 [2] array (t, k)."""
+    m = spec.to_c(_c(clock_lut, np.float64))
+    gb = _c(contact[0], np.int32)
+    K, N = blocks["qpos"].shape[:2]
+    cb = _abi.A3Blocks()
+    cb.K, cb.C = int(K), int(blocks["geom1"].shape[2])
+    for name in _abi.A3_BLOCK_F64 + _abi.A3_BLOCK_TAIL:
+        a = blocks[name]
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == (np.int32 if name in ("ncon", "geom1", "geom2") else np.float64), name
+        setattr(cb, name, a.ctypes.data)
+    cst = _abi.A3State()
+    for name in _abi.A3_STATE_FIELDS:
+        assert state[name].flags["C_CONTIGUOUS"], name
+        setattr(cst, name, state[name].ctypes.data)
+    cr = _abi.A3Rollout()
+    cr.T, cr.max_traj_len, cr.deterministic = int(ro["T"]), int(ro["max_traj_len"]), int(bool(ro["deterministic"]))
+    cr.side_slots, cr.pool_depth = int(ro["side_slots"]), int(ro["pool_depth"])
+    for name in ("mu", "value", "scale", "eps", "state", "pd_target", "buf_states", "buf_actions", "buf_rewards",
+                 "buf_values", "buf_flags", "buf_rew6", "traj_len", "side_obs", "side_t", "side_count", "pool",
+                 "pool_count", "ctr"):
+        a = ro.get(name)
+        if a is not None:
+            assert a.flags["C_CONTIGUOUS"], name
+        setattr(cr, name, None if a is None else a.ctypes.data)
+    _chk(lib().oly_a3_vec_step_cpu(C.byref(m), len(gb), _p(gb), int(contact[1]), int(contact[2]), int(contact[3]),
+                                   int(N), C.byref(cb), C.byref(cst), C.byref(cr), int(flags)), "a3_vec_step")
+
+
+def mlp_forward(x, w1, b1, w2, b2, w3, b3, in_mean=None, in_std=None):
+    """relu MLP in -> 256 -> 256 -> out, k-ordered f32 fma chains (oly_mlp_forward2's arithmetic)."""
+    x, w1, b1, w2, b2, w3, b3 = (_c(a, np.float32) for a in (x, w1, b1, w2, b2, w3, b3))
+    in_mean, in_std = _c(in_mean, np.float32), _c(in_std, np.float32)
+    N, in_dim = x.shape
+    out_dim = w3.shape[0]
+    assert w1.shape == (256, in_dim) and w2.shape == (256, 256) and w3.shape == (out_dim, 256)
+    y = np.empty((N, out_dim), np.float32)
+    _chk(lib().oly_mlp_forward_cpu(N, in_dim, out_dim, _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3),
+                                   _p(in_mean), _p(in_std), _p(y)), "mlp_forward")
+    return y
+
+
 def a3_pd_target(spec, action):
     m = spec.to_c(np.zeros((4, spec.period)))
     action = _c(action, np.float32)

@@ -279,6 +279,7 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr
                 max_traj_len=16, use_gae=False, num_procs=N, max_grad_norm=0.05, mirror_coeff=0.0,
                 eval_freq=2 if mode == "fused" else 100)
     ppo = PPO(args, str(tmp_path))
+    ppo.use_device_rollout = False               # this test drives the per-step host loop (custom reset above)
     ppo.fused_loss, ppo.use_graph = mode != "torch_losses", mode.startswith("fused_graph")
     if mode == "fused_graph_fresh":
         ppo.graph_recapture_every = 1            # every update runs as the FIRST replay of a new capture
@@ -616,6 +617,7 @@ def test_graphed_rollout_equals_eager_rollout(golden):
     torch.manual_seed(0)
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
     ppo = PPO.__new__(PPO)
+    ppo.use_device_rollout = False               # the per-step host loop; the device rollout has its own test
     bufs = []
     for graph in (False, True):
         ppo.use_graph_rollout = graph

@@ -1,0 +1,282 @@
+"""K10, the one-launch vec step of the PPO rollout loop (rl/algos/ppo.py:169-196), and the
+device-resident rollout built on it: against the oracle's row-by-row restatement, against the
+separate K3 + K2 kernels, and graph replay against the eager loop."""
+import numpy as np
+import pytest
+import torch
+
+from olympic_hip import _abi, specs
+from olympic_hip.synthetic import A3_FLOOR_BODY, A3_GEOM_BODYID, A3_LFOOT_BODY, A3_RFOOT_BODY, a3_synthetic_blocks
+from olympic_hip.vecstep import REC, draw_reset_records
+
+pytestmark = pytest.mark.gpu
+CONTACT = (A3_GEOM_BODYID, A3_FLOOR_BODY, A3_RFOOT_BODY, A3_LFOOT_BODY)
+
+
+@pytest.fixture(scope="module")
+def eng(golden):
+    from olympic_hip.engine import Engine
+    e = Engine(0)
+    e.a3_configure(specs.A3Spec(mass=41.5), golden("a3_task.npz")["clock_lut"])
+    e.contact_configure(*CONTACT)
+    return e
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _host_rollout(spec, N, K, T, max_traj_len, depth, seed, det=False, p_bad=0.05, p_low=0.02):
+    """Everything oly_a3_vec_step touches, as numpy arrays (the oracle works on these in place)."""
+    rng = np.random.default_rng(seed)
+    rs = np.random.RandomState(seed)
+    blocks = a3_synthetic_blocks(N, K, seed=seed, p_bad=p_bad, p_low=p_low)
+    pool = draw_reset_records(rs, N * depth, spec, iter_count=6000)
+    slots = T // max_traj_len + 2
+    nobs, nu = spec.n_obs, spec.nu
+    state = dict(phase=np.zeros(N, np.int32), t1=np.zeros(N, np.int32), t2=np.zeros(N, np.int32),
+                 reached_frames=np.zeros(N, np.int32), target_reached=np.zeros(N, np.uint8),
+                 mode=np.full(N, _abi.MODE_STANDING, np.int32), seq_len=np.ones(N, np.int32),
+                 sequence=np.zeros((N, _abi.OLY_MAX_SEQ, 4)), goal=np.zeros((N, 8)))
+    ro = dict(T=T, max_traj_len=max_traj_len, deterministic=det, side_slots=slots, pool_depth=depth,
+              mu=np.zeros((N, nu), np.float32), value=np.zeros(N, np.float32),
+              scale=None if det else rng.uniform(0.05, 0.4, nu).astype(np.float32),
+              eps=None if det else rng.normal(0, 1, (T, N, nu)).astype(np.float32),
+              state=np.zeros((N, nobs), np.float32), pd_target=np.zeros((N, nu)),
+              buf_states=np.zeros((T, N, nobs), np.float32), buf_actions=np.zeros((T, N, nu), np.float32),
+              buf_rewards=np.zeros((T, N)), buf_values=np.zeros((T, N), np.float32),
+              buf_flags=np.zeros((T, N), np.uint8), buf_rew6=np.zeros((T, N, 6), np.float32),
+              traj_len=np.zeros(N, np.int32), side_obs=np.zeros((N * slots, nobs), np.float32),
+              side_t=np.full(N * slots, -1, np.int32), side_count=np.zeros(N, np.int32),
+              pool=pool.view(np.uint8).reshape(-1).copy(), pool_count=np.zeros(N, np.int32),
+              ctr=np.array([0, 3], np.int32))
+    return blocks, state, ro, rng
+
+
+def _to_device(eng, blocks, state, ro):
+    N = len(state["phase"])
+    d_blocks = {k: dev(v) for k, v in blocks.items()}
+    d_state = {k: dev(v) for k, v in state.items()}
+    d_ro = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in ro.items()}
+    ctr = torch.zeros(eng.a3_vec_ctr_len(N), dtype=torch.int32, device="cuda")
+    ctr[0::2], ctr[1::2] = int(ro["ctr"][0]), int(ro["ctr"][1])
+    d_ro["ctr"] = ctr
+    return d_blocks, d_state, d_ro
+
+
+@pytest.mark.parametrize("N,T,max_len,det", [(300, 9, 3, False), (4096, 6, 4, False), (37, 7, 100, True)])
+def test_vec_step_vs_oracle(eng, golden, oracle, N, T, max_len, det):
+    """RESET_ALL + T steps, the kernel and the oracle side by side on the same inputs.  Integer
+    state, flags, cursors, counters, actions (f32 mul + add), PD targets: bit-exact.  Float64 values
+    that pass through sin / cos / tan / exp / atan2 (device libm vs glibc): 1e-11 relative;
+    observations are those values narrowed to float32: at most one float32 ulp."""
+    spec = specs.A3Spec(mass=41.5)
+    lut = golden("a3_task.npz")["clock_lut"]
+    blocks, state, ro, rng = _host_rollout(spec, N, 5, T, max_len, 2, seed=N + T, det=det)
+    d_blocks, d_state, d_ro = _to_device(eng, blocks, state, ro)
+    launch = eng.a3_vec_prepare(d_blocks, d_state, d_ro)
+    h = lambda t_: t_.cpu().numpy()
+
+    def compare(step):
+        for k in ("phase", "t1", "t2", "reached_frames", "target_reached", "mode", "seq_len"):
+            assert np.array_equal(h(d_state[k]), state[k]), (step, k)
+        np.testing.assert_allclose(h(d_state["sequence"]), state["sequence"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(h(d_state["goal"]), state["goal"], rtol=1e-11, atol=1e-12)
+        for k in ("traj_len", "side_count", "side_t", "pool_count", "buf_flags"):
+            assert np.array_equal(h(d_ro[k]), ro[k]), (step, k)
+        assert np.array_equal(h(d_ro["buf_actions"]), ro["buf_actions"])
+        assert np.array_equal(h(d_ro["pd_target"]), ro["pd_target"])
+        assert np.array_equal(h(d_ro["buf_values"]), ro["buf_values"])
+        np.testing.assert_allclose(h(d_ro["buf_rewards"]), ro["buf_rewards"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(h(d_ro["buf_rew6"]), ro["buf_rew6"], rtol=2e-6, atol=1e-7)
+        for k in ("state", "buf_states", "side_obs"):
+            a, b = h(d_ro[k]), ro[k]
+            assert np.abs(a - b).max() <= np.spacing(np.float32(1.0)) * max(1.0, np.abs(b).max()), (step, k)
+        c = h(d_ro["ctr"]).reshape(-1, 2)
+        assert (c[:, 0] == ro["ctr"][0]).all() and (c[:, 1] == ro["ctr"][1]).all()
+
+    launch(_abi.VSTEP_RESET_ALL)
+    oracle.a3_vec_step(spec, lut, CONTACT, blocks, state, ro, _abi.VSTEP_RESET_ALL)
+    compare("reset")
+    assert (ro["pool_count"] == 1).all() and ro["ctr"].tolist() == [0, 3]
+    for t in range(T):
+        mu = rng.normal(0, 0.3, (N, spec.nu)).astype(np.float32)
+        val = rng.normal(0, 1, N).astype(np.float32)
+        ro["mu"][...], ro["value"][...] = mu, val
+        # the observation the "policy" sees is the previous step's output: keep both sides on the oracle's
+        d_ro["state"].copy_(dev(ro["state"]))
+        launch(0, dev(mu), dev(val))
+        oracle.a3_vec_step(spec, lut, CONTACT, blocks, state, ro, 0)
+        compare(t)
+    assert ro["ctr"].tolist() == [T, 3 + T]
+    fl = ro["buf_flags"]
+    assert (fl[-1] & _abi.FLAG_LAST).all()                       # the block end cuts every environment
+    assert ((fl & _abi.FLAG_LAST) != 0).sum() > N                # and time limits / dones cut more
+    assert (ro["side_count"] <= ro["side_slots"]).all()
+    cut_not_done = ((fl & _abi.FLAG_LAST) != 0) & ((fl & _abi.FLAG_ABSORBING) == 0)
+    assert cut_not_done.sum() == (ro["side_t"] >= 0).sum()       # one bootstrap row per non-terminal cut
+
+
+def test_vec_step_equals_the_separate_kernels(eng, golden):
+    """The fused launch against oly_contact_reduce + oly_a3_step + oly_a3_pd_target +
+    oly_rollout_cuts on the same readback row: the same libm entry points on the same arguments, so
+    observations, rewards, task state and flags are bit-identical."""
+    spec = specs.A3Spec(mass=41.5)
+    N, T = 1000, 4
+    blocks, state, ro, rng = _host_rollout(spec, N, 4, T, 100, 2, seed=5, det=True, p_bad=0.1, p_low=0.05)
+    d_blocks, d_state, d_ro = _to_device(eng, blocks, state, ro)
+    launch = eng.a3_vec_prepare(d_blocks, d_state, d_ro)
+    launch(_abi.VSTEP_RESET_ALL)
+    traj_len = torch.zeros(N, dtype=torch.int32, device="cuda")
+    n_cut = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for t in range(T - 1):           # the last step resets nobody but cuts everybody: covered above
+        kk = (3 + t) % 4
+        ref_state = {k: v.clone() for k, v in d_state.items()}
+        cr = eng.contact_reduce(d_blocks["ncon"][kk], d_blocks["geom1"][kk], d_blocks["geom2"][kk],
+                                d_blocks["force6"][kk], d_blocks["cpos_z"][kk], want_idx=False)
+        kin = {k: d_blocks[k][kk] for k in ("qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel",
+                                            "rf_vel", "root_pos", "root_quat", "head_pos")}
+        kin.update({k: cr[k] for k in ("grf_l", "grf_r", "min_z", "n_r", "n_l", "bad")})
+        o = eng.a3_step(kin, ref_state)
+        mu = torch.randn((N, spec.nu), device="cuda")
+        flags = torch.zeros(N, dtype=torch.uint8, device="cuda")
+        eng.rollout_cuts(o["done"], traj_len, flags, n_cut, 100, False)
+        launch(0, mu, torch.zeros(N, device="cuda"))
+        assert torch.equal(d_ro["buf_actions"][t], mu)
+        assert torch.equal(d_ro["pd_target"], eng.a3_pd_target(mu))
+        assert torch.equal(d_ro["buf_flags"][t], flags)
+        assert torch.equal(d_ro["buf_rewards"][t].float(), o["reward"])       # K2 narrows its f64 total to f32
+        assert torch.equal(d_ro["buf_rew6"][t], o["rew6"])
+        keep = ~(flags & _abi.FLAG_LAST).bool()                                # environments that were not reset
+        assert int(keep.sum()) > N // 2 and int((~keep).sum()) > 5
+        assert torch.equal(d_ro["state"][keep], o["obs"][keep])
+        for k in ("phase", "t1", "t2", "reached_frames", "target_reached", "goal"):
+            assert torch.equal(d_state[k][keep], ref_state[k][keep]), k
+        # reset environments: un-advanced task, goal steps zero, robot part of the observation unchanged
+        rs_ = ~keep
+        assert torch.equal(d_ro["state"][rs_][:, :31], o["obs"][rs_][:, :31])
+        assert not d_ro["state"][rs_][:, 33:].any() and not d_state["goal"][rs_].any()
+        assert not d_state["reached_frames"][rs_].any() and not d_state["t1"][rs_].any()
+        traj_len = d_ro["traj_len"].clone()
+
+
+def _make_env(N, K, seed, p_bad=0.02):
+    from olympic_hip.a3 import ReplayA3Physics, VecA3Env
+    from olympic_hip.engine import Engine
+    blocks = {k: dev(v) for k, v in a3_synthetic_blocks(N, K, seed=seed, p_bad=p_bad, p_low=0.01).items()}
+    env = VecA3Env(specs.A3Spec(mass=41.5), N, Engine(0), ReplayA3Physics(blocks), *CONTACT, rs=np.random.RandomState(seed))
+    env.device = env.eng.device
+    return env
+
+
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_device_rollout_graph_replay_equals_eager_loop(deterministic):
+    """The same launches replayed from HIP graphs (8 steps per graph, a 3-step eager tail) must fill
+    the rollout buffer exactly like the op-by-op loop: states, actions, float64 rewards, values,
+    next_values, flags, task state; and the buffer obeys the rollout's invariants."""
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    N, T, max_len = 512, 27, 10
+    torch.manual_seed(0)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    out = []
+    for graph in (False, True):
+        env = _make_env(N, 7, seed=3)
+        torch.manual_seed(11)                                     # the action noise block
+        buf = env.device_rollout(pi, vf, T, max_len, deterministic=deterministic, anneal=0.7, graph=graph)
+        out.append((buf, {k: v.clone() for k, v in env.state.items()}, dict(env._dev_rollout.last_info)))
+    (a, sa, ia), (b, sb, ib) = out
+    for name in ("states", "actions", "rewards", "values", "next_values", "flags"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert all(torch.equal(sa[k], sb[k]) for k in sa) and ia == ib
+    assert a.rewards.dtype == torch.float64
+    last = (a.flags & _abi.FLAG_LAST).bool()
+    absorbing = (a.flags & _abi.FLAG_ABSORBING).bool()
+    assert bool(last[-1].all()) and int(last.sum()) >= N * (T // max_len) and not bool((absorbing & ~last).any())
+    assert ia["resets"] == N + int(last[:-1].sum())               # env.reset() of all, then one per cut
+    assert ia["side_rows"] == int((last & ~absorbing).sum())
+    # V(s_{t+1}): the next row's value where the episode goes on
+    assert torch.equal(a.next_values[:-1][~last[:-1]], a.values[1:][~last[:-1]])
+    # the policy really produced the stored actions / values from the stored states
+    with torch.no_grad():
+        mu = pi(a.states.reshape(-1, 41)).reshape(T, N, 12)
+        assert torch.allclose(a.values, vf(a.states.reshape(-1, 41)).reshape(T, N), rtol=1e-5, atol=1e-6)
+    if deterministic:
+        assert torch.allclose(a.actions, mu, rtol=1e-5, atol=1e-6)
+    else:
+        z = (a.actions - mu) / (float(pi.fixed_std) * 0.7)
+        assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+
+
+def test_ppo_train_on_the_device_rollout(tmp_path):
+    """PPO.train end to end with the device rollout (graphs for sampling and updates): finite losses,
+    the optimiser steps, float64 rewards reach the return scan, two iterations re-use the graphs."""
+    from olympic_hip.ppo import PPO, MLPCritic, MLPGaussianActor
+    N = 256
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=2,
+                max_traj_len=16, use_gae=False, num_procs=N, max_grad_norm=0.05, mirror_coeff=0.0, eval_freq=100)
+    ppo = PPO(args, str(tmp_path))
+    ppo.use_graph_rollout = True
+    torch.manual_seed(0)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    w0 = pi.means.weight.detach().clone()
+    hist = ppo.train(lambda: _make_env(N, 9, seed=4), pi, vf, n_itr=3, verbose=False)
+    assert len(hist) == 3 and all(np.isfinite(h["losses"]).all() for h in hist)
+    assert not torch.equal(w0, pi.means.weight) and ppo.total_steps == 3 * 16 * N
+
+
+# --------------------------------------------------------------------------------- K11
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 4096, 12288 + 5])
+def test_fused_mlp_forward_vs_oracle_and_torch(eng, oracle, N):
+    """oly_mlp_forward2 (actor 41 -> 256 -> 256 -> 12 and critic -> 1 in one launch): bit-exact against
+    the oracle's k-ordered fma chains (the matrix cores' f32 arithmetic, restated), and within fp32
+    summation-order noise (1e-5 relative to the row scale) of torch's own Linear / relu forward."""
+    from olympic_hip.mlp import FusedMLPForward
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    torch.manual_seed(N)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    with torch.no_grad():
+        for p_ in list(pi.parameters()) + list(vf.parameters()):
+            p_.mul_(3.0)                                   # default init is tiny: make the sums non-trivial
+        for m_ in (pi.means.bias, vf.network_out.bias, pi.actor_layers[0].bias):
+            m_.normal_(0, 0.5)
+    pi.obs_mean = torch.randn(41, device="cuda") * 0.3
+    pi.obs_std = torch.rand(41, device="cuda") + 0.5
+    x = torch.randn(N, 41, device="cuda") * 2
+    fw = FusedMLPForward(eng, pi, vf)
+    mu, val = fw(x)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref_mu, ref_v = pi(x), vf(x).reshape(N)
+    scale = max(1.0, float(ref_mu.abs().max()))
+    assert float((mu - ref_mu).abs().max()) <= 2e-5 * scale
+    assert float((val - ref_v).abs().max()) <= 2e-5 * max(1.0, float(ref_v.abs().max()))
+    assert torch.equal(fw.value(x), val)                   # the one-network launch = the same chains
+    n = min(N, 300)                                        # the CPU chain is slow: a slice
+    sl = slice(N - n, N)
+    h = lambda t_: t_.detach().cpu().numpy()
+    par = lambda parts: [h(a) for lin in parts for a in (lin.weight, lin.bias)]
+    e_mu = oracle.mlp_forward(h(x[sl]), *par(fw.pa), in_mean=h(pi.obs_mean), in_std=h(pi.obs_std))
+    e_v = oracle.mlp_forward(h(x[sl]), *par(fw.pc))
+    assert np.array_equal(h(mu[sl]), e_mu)                 # bit-exact: same products, same order
+    assert np.array_equal(h(val[sl]), e_v[:, 0])
+
+
+def test_fused_mlp_identity_with_asymmetric_weights(eng):
+    """Layout check with exact integer data (a symmetric weight matrix would hide a row / column swap):
+    hidden layers pass the input through (identity blocks), the head is an asymmetric integer matrix."""
+    from olympic_hip.mlp import FusedMLPForward
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    with torch.no_grad():
+        for net, layers, head in ((pi, pi.actor_layers, pi.means), (vf, vf.critic_layers, vf.network_out)):
+            for lin in list(layers) + [head]:
+                lin.weight.zero_()
+                lin.bias.zero_()
+            layers[0].weight[:41, :41] = torch.eye(41)
+            layers[1].weight.copy_(torch.eye(256))
+            head.weight.copy_(torch.arange(head.out_features * 256, dtype=torch.float32).reshape(head.out_features, 256) % 7 - 2)
+    x = torch.randint(0, 5, (77, 41), device="cuda").float()      # non-negative: relu is the identity
+    mu, val = FusedMLPForward(eng, pi, vf)(x)
+    xp = torch.zeros(77, 256, device="cuda")
+    xp[:, :41] = x
+    assert torch.equal(mu, xp @ pi.means.weight.t()) and torch.equal(val, (xp @ vf.network_out.weight.t()).reshape(-1))

@@ -212,7 +212,9 @@ def test_struct_layouts_match_the_header():
     """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
     import tempfile
     fields = {"oly_il_model": _abi.IlModel, "oly_a3_model": _abi.A3Model, "oly_a3_inputs": _abi.A3Inputs,
-              "oly_a3_state": _abi.A3State, "oly_a3_readback": _abi.A3Readback, "oly_il_contacts": _abi.IlContacts}
+              "oly_a3_state": _abi.A3State, "oly_a3_readback": _abi.A3Readback, "oly_il_contacts": _abi.IlContacts,
+              "oly_a3_blocks": _abi.A3Blocks, "oly_a3_reset_record": _abi.A3ResetRecord,
+              "oly_a3_rollout": _abi.A3Rollout}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/olympic_hip.h"', "int main(){"]
     for cname, cls in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -397,3 +399,38 @@ def test_discriminator_losses_match_reference(golden):
     vl = VDBLoss(info_constraint=0.1, lr_beta=1e-5)
     np.testing.assert_allclose(float(vl((t("d"), t("mu"), t("logvar")), t("target"))), float(g["vdb_loss"]), rtol=2e-6)
     np.testing.assert_allclose(float(vl._beta), float(g["vdb_beta_after"]), rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------ reset-record pool
+def test_reset_records_follow_walking_task_reset():
+    """The vectorised record draw (device-side resets) against the scalar WalkingTaskReset, which
+    test_walking_task_reset_matches_reference pins to the reference: same distribution parameters, and
+    for identical draws the same local step sequence."""
+    from olympic_hip.a3 import WalkingTaskReset
+    from olympic_hip.vecstep import draw_reset_records
+    spec = specs.A3Spec(mass=41.5)
+    rec = draw_reset_records(np.random.RandomState(0), 4000, spec, iter_count=7000)
+    assert set(np.unique(rec["mode"])) == {_abi.MODE_STANDING, _abi.MODE_FORWARD}
+    assert abs((rec["mode"] == _abi.MODE_STANDING).mean() - 0.2) < 0.03
+    assert set(np.unique(rec["phase"])) == {0, 44} and abs((rec["phase"] == 44).mean() - 0.5) < 0.04
+    fwd = rec[rec["mode"] == _abi.MODE_FORWARD]
+    assert (fwd["seq_len"] == 20).all() and (rec[rec["mode"] == _abi.MODE_STANDING]["seq_len"] == 1).all()
+    # a scalar reset with the same draws: replay them through a stub RandomState
+    class Replay:
+        def __init__(self, vals):
+            self.vals = list(vals)
+
+        def uniform(self, lo, hi):
+            return self.vals.pop(0)
+
+        def randint(self, lo, hi):
+            return self.vals.pop(0)
+    for r in fwd[:50]:
+        first = abs(r["seq"][0, 1])
+        zs = r["seq"][:, 2]
+        step_h = zs[-1] / max(1, np.count_nonzero(np.diff(zs)))
+        c = int(np.argmax(zs != 0)) - 1 if zs.any() else 2
+        rr = WalkingTaskReset(spec, Replay([first, c]))            # _sequence draws uniform, then randint
+        seq = rr._sequence(r["phase"], 88, step_size=0.3, step_gap=0.15, step_height=step_h, num_steps=20, lateral=False)
+        np.testing.assert_allclose(np.array(seq)[:, :2], r["seq"][:, :2], rtol=0, atol=0)
+        np.testing.assert_allclose(np.array(seq)[:, 2], zs, rtol=1e-12, atol=1e-15)

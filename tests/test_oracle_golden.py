@@ -477,3 +477,58 @@ def test_a3_orientation_analytic_cases(golden, oracle):
     st = {k: v.copy() for k, v in c["state"].items()}
     eo = oracle.a3_step(specs.A3Spec(mass=41.5), g["clock_lut"], c["inputs"], st)
     check_a3_analytic(eo["obs"], st["goal"], c)
+
+
+def test_vec_step_replays_the_reference_sequence(golden, oracle):
+    """oly_a3_vec_step_cpu (contacts -> task.step -> reward -> done -> get_obs -> cut rule, one call
+    per step) on the reference-generated a3_task fixture: until an environment is done for the
+    first time (the fixture keeps stepping, the rollout loop resets) observations, rewards, done
+    flags and integer task state are the reference's."""
+    from olympic_hip.vecstep import REC
+    g = golden("a3_task.npz")
+    spec = specs.A3Spec(mass=float(g["mass"]))
+    E, K = g["phase"].shape
+    names = ("qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel", "rf_vel", "root_pos", "root_quat",
+             "head_pos", "ncon", "geom1", "geom2", "force6", "cpos_z")
+    blocks = {n: np.ascontiguousarray(np.swapaxes(g[n], 0, 1)) for n in names}
+    state, _ = a3_fixture_arrays(g, 0)
+    T, nobs, nu, slots = K, spec.n_obs, spec.nu, 2
+    pool = np.zeros(E, REC)
+    pool["mode"], pool["seq_len"] = _abi.MODE_STANDING, 1
+    ro = dict(T=T, max_traj_len=10 ** 6, deterministic=True, side_slots=slots, pool_depth=1,
+              mu=np.zeros((E, nu), np.float32), value=np.zeros(E, np.float32), scale=None, eps=None,
+              state=np.zeros((E, nobs), np.float32), pd_target=np.zeros((E, nu)),
+              buf_states=np.zeros((T, E, nobs), np.float32), buf_actions=np.zeros((T, E, nu), np.float32),
+              buf_rewards=np.zeros((T, E)), buf_values=np.zeros((T, E), np.float32),
+              buf_flags=np.zeros((T, E), np.uint8), buf_rew6=np.zeros((T, E, 6), np.float32),
+              traj_len=np.zeros(E, np.int32), side_obs=np.zeros((E * slots, nobs), np.float32),
+              side_t=np.full(E * slots, -1, np.int32), side_count=np.zeros(E, np.int32),
+              pool=pool.view(np.uint8).reshape(-1).copy(), pool_count=np.zeros(E, np.int32),
+              ctr=np.zeros(2, np.int32))
+    contact = (g["geom_bodyid"], int(g["floor_body"]), int(g["rfoot_body"]), int(g["lfoot_body"]))
+    fixture_state, _ = a3_fixture_arrays(g, 0)
+    for k in range(K - 1):
+        # put every environment back on the fixture's trajectory (undoing the resets of step k-1)
+        for name in ("mode", "seq_len", "sequence"):
+            state[name][...] = fixture_state[name]
+        if k > 0:
+            for name in ("phase", "t1", "t2", "reached_frames"):
+                state[name][...] = g[name][:, k - 1]
+            state["target_reached"][...] = g["target_reached"][:, k - 1]
+        oracle.a3_vec_step(spec, g["clock_lut"], contact, blocks, state, ro, 0)
+        done = g["done"][:, k]
+        assert np.array_equal((ro["buf_flags"][k] & _abi.FLAG_ABSORBING) != 0, done)
+        assert np.array_equal((ro["buf_flags"][k] & _abi.FLAG_LAST) != 0, done)          # no time limit here
+        np.testing.assert_allclose(ro["buf_rewards"][k], g["reward"][:, k], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(ro["buf_rew6"][k], g["rew6"][:, k], rtol=2e-6, atol=1e-7)
+        a = ~done                                                    # not reset: the reference's next observation
+        assert np.array_equal(ro["state"][a], g["obs"][a, k].astype(np.float32))
+        for name in ("phase", "t1", "t2", "reached_frames"):
+            assert np.array_equal(state[name][a], g[name][a, k]), name
+        # a reset environment restarts un-advanced: robot part unchanged, goal steps zero, counters zero,
+        # clock of the drawn phase (walking_task.py:321-344, StickFigureA3.py:205-235)
+        assert np.array_equal(ro["state"][done][:, :nobs - 10], g["obs"][done, k].astype(np.float32)[:, :nobs - 10])
+        assert not ro["state"][done][:, nobs - 8:].any() and not state["reached_frames"][done].any()
+        assert np.array_equal(ro["state"][done][:, nobs - 10:nobs - 8], np.tile(np.float32([0, 1]), (done.sum(), 1)))
+    assert g["done"][:, :K - 1].sum() > 100 and (~g["done"][:, :K - 1]).sum() > 100
+    assert ro["ctr"].tolist() == [K - 1, K - 1] and ro["pool_count"].sum() == g["done"][:, :K - 1].sum()

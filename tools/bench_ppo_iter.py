@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--minibatch", type=int, default=65536)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--mode", default="fused_graph", choices=["torch_losses", "fused", "fused_graph"])
+    ap.add_argument("--rollout", default="host", choices=["host", "device"],
+                    help="host: one env.step per python iteration (K5, K3, K2 launches); device: one fused K10 launch "
+                         "per vec step, replayed from a HIP graph, resets on the device")
     args = ap.parse_args()
     N, T = args.N, args.T
     gen = torch.Generator(device="cuda").manual_seed(1)
@@ -76,6 +79,7 @@ def main():
     ppo = PPO(hp, tempfile.mkdtemp(prefix="oly_ppo_"))
     ppo.fused_loss, ppo.use_graph = args.mode != "torch_losses", args.mode == "fused_graph"
     ppo.use_graph_rollout = args.mode == "fused_graph"
+    ppo.use_device_rollout = args.rollout == "device"
     torch.manual_seed(0)
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
     hist = ppo.train(Env, pi, vf, n_itr=args.itr, verbose=False)
