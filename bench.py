@@ -253,12 +253,44 @@ def per_step_block(rk, eng, spec, N):
     us10 = wall_us(g.replay) / 10
     out["h1_graph_of_10_steps"] = {"us_per_vec_step": us10, "env_steps_per_s": N / (us10 * 1e-6),
                                    "launches_per_step": 1, "note": "ten consecutive vec steps per graph replay"}
-    try:
-        from olympic_hip.vecstep import bench_config3_sampling
-        out["config3_a3_ppo_sampling"] = bench_config3_sampling(eng, N, rk.dev)
-    except ImportError:
-        pass
+    out["config3_a3_ppo_sampling"] = config3_sampling(N, rk.dev)
     return out
+
+
+def config3_sampling(N, dev, T=400, reps=3):
+    """BASELINE.json configs[2], the sampling half: N StickFigureA3 environments x T steps with the
+    synthetic physics readback resident on the device, policy 41->256->256->12 + critic -> 1 (random
+    normc-like init), Gaussian sampling, episode cuts and device-side resets: per vec step ONE K11
+    launch (both MLPs) and ONE K10 launch (everything else), replayed from HIP graphs of 8 steps."""
+    import numpy as np
+    import torch
+    from olympic_hip import specs
+    from olympic_hip.a3 import ReplayA3Physics, VecA3Env
+    from olympic_hip.engine import Engine
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    from olympic_hip.synthetic import A3_FLOOR_BODY, A3_GEOM_BODYID, A3_LFOOT_BODY, A3_RFOOT_BODY, a3_synthetic_blocks
+    blocks = {k: torch.as_tensor(v).to(dev) for k, v in a3_synthetic_blocks(N, 32, seed=1).items()}
+    env = VecA3Env(specs.A3Spec(mass=41.5), N, Engine(dev.index or 0), ReplayA3Physics(blocks), A3_GEOM_BODYID,
+                   A3_FLOOR_BODY, A3_RFOOT_BODY, A3_LFOOT_BODY, rs=np.random.RandomState(0))
+    torch.manual_seed(0)
+    pi, vf = MLPGaussianActor(41, 12).to(dev), MLPCritic(41).to(dev)
+    res = {}
+    for label, graph in (("eager_launches", False), ("graph_replay", True)):
+        for _ in range(2):
+            env.device_rollout(pi, vf, T, T, graph=graph)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            env.device_rollout(pi, vf, T, T, graph=graph)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        res[label] = {"us_per_vec_step": 1e6 * dt / T, "env_steps_per_s": N * T / dt}
+    info = env._dev_rollout.last_info
+    res.update({"N": N, "T": T, "launches_per_step": 2, "kernels": "mlp_forward_kernel (K11) + a3_vec_kernel (K10)",
+                "timing": "wall clock of whole rollouts (reset-pool refill and bootstrap pass included) / T",
+                "resets_per_rollout": info.get("resets"), "bootstrap_rows": info.get("side_rows"),
+                "round1_host_loop_us_per_vec_step": 360.0})
+    return res
 
 
 def bench_config2(args, rk):

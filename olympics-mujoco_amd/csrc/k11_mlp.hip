@@ -4,15 +4,15 @@
 //
 // Why: in the per-vec-step regime (N = 4096 rows per forward) the library path is six GEMM launches
 // of ~10 us each plus four ReLU launches (profiles/r02: 99 us per actor + critic forward, replayed
-// from a graph); the arithmetic is 1.3 GFLOP = 8 us at the f32 MFMA rate.  Here a workgroup owns
+// from a graph); the arithmetic is 1.3 GFLOP = 8 us at the f32 MFMA rate.  Here a workgroup (8 waves) owns
 // 32 rows of ONE network and carries them through all three layers: activations never leave LDS,
 // weights stream from L2 in the MFMA B-operand layout (packed once per policy update by
 // mlp_pack_kernel), 128 row tiles x 2 networks = 256 workgroups = one per CU.
 //
 // Numerics: v_mfma_f32_32x32x2_f32 is exact f32 (one rounding per product, k ascending), so
 //   y = b + sum_k x_k * w_k  is the f32 fma chain  fma(x_k, w_k, acc)  in k order, starting from 0,
-// with the bias added after the chain; layer 3 splits k over the four waves (k in [64w, 64w+64))
-// and adds the four partial chains in wave order, then the bias.  Deterministic, and restated
+// with the bias added after the chain; layer 3 splits k over the eight waves (k in [32w, 32w+32))
+// and adds the eight partial chains in wave order, then the bias.  Deterministic, and restated
 // bit for bit by the oracle (oly_mlp_forward_cpu); against torch's own fp32 Linear the difference is
 // summation order only (<= 1e-5 relative on these layers).
 #include "oly_common.h"
@@ -24,7 +24,9 @@ constexpr int RT = 32;          // rows per workgroup
 constexpr int LDP = 33;         // LDS row pitch of the [k][row] activation images (conflict-free)
 constexpr int MAX_IN = 64;
 constexpr int MAX_OUT = 32;
-constexpr int THREADS = 256;
+constexpr int THREADS = 512;     // 8 waves
+constexpr int KSPLIT = 8;        // output layer: k split over the waves
+constexpr int G1 = 8;            // layer 1: k zero-padded to MAX_IN = 8 groups of four k-steps
 
 struct PackLayout {
   int in_dim, out_dim, g1;      // g1: groups of four k-steps in layer 1
@@ -35,8 +37,7 @@ __host__ __device__ inline PackLayout pack_layout(int in_dim, int out_dim) {
   PackLayout L;
   L.in_dim = in_dim;
   L.out_dim = out_dim;
-  const int steps1 = (in_dim + 1) / 2;
-  L.g1 = (steps1 + 3) / 4;
+  L.g1 = G1;
   L.w1 = 0;
   L.b1 = L.w1 + (size_t)8 * L.g1 * 256;
   L.w2 = L.b1 + HID;
@@ -107,32 +108,38 @@ struct MlpArgs {
   MlpNet net[2];
 };
 
-// one 32-row x 64-column slab of  act(A W + b):  A from the [k][row] LDS image, W from the packed
-// stream, k = 0 .. 8 G - 1 in order.  Two accumulator tiles per wave share every A fragment.
-template <int UNROLL>
-__device__ __forceinline__ void layer_64cols(const float* __restrict__ aT, const float4* __restrict__ w0,
-                                             const float4* __restrict__ w1, int G, int lane, f32x16& acc0,
-                                             f32x16& acc1) {
+// one 32-row x 32-column tile of  A W  (k = 0 .. 8 G - 1 in order): A fragments from the [k][row] LDS
+// image (one group ahead), W from the packed stream (two groups ahead), fully unrolled so that every
+// load is in flight behind the 64-cycle MFMAs of the groups before it.
+template <int G>
+__device__ __forceinline__ void layer_tile(const float* __restrict__ aT, const float4* __restrict__ w, int lane,
+                                           f32x16& acc) {
   const int r = lane & 31, h = lane >> 5;
-  float4 b0 = w0[lane], b1 = w1[lane];
+  float4 b[3];
+  float a[2][4];
+  b[0] = w[lane];
+  if (G > 1) b[1] = w[64 + lane];
+  {
+    const float* ap = aT + (size_t)h * LDP + r;
+    a[0][0] = ap[0]; a[0][1] = ap[2 * LDP]; a[0][2] = ap[4 * LDP]; a[0][3] = ap[6 * LDP];
+  }
+#pragma unroll
   for (int g = 0; g < G; ++g) {
-    float4 n0 = b0, n1 = b1;
-    if (g + 1 < G) {                       // next group's weights in flight during this group's MFMAs
-      n0 = w0[(size_t)(g + 1) * 64 + lane];
-      n1 = w1[(size_t)(g + 1) * 64 + lane];
+    if (g + 2 < G) b[(g + 2) % 3] = w[(size_t)(g + 2) * 64 + lane];
+    if (g + 1 < G) {
+      const float* ap = aT + (size_t)(8 * (g + 1) + h) * LDP + r;
+      a[(g + 1) & 1][0] = ap[0]; a[(g + 1) & 1][1] = ap[2 * LDP];
+      a[(g + 1) & 1][2] = ap[4 * LDP]; a[(g + 1) & 1][3] = ap[6 * LDP];
     }
-    const float* ap = aT + (size_t)(8 * g + h) * LDP + r;
-    const float a0 = ap[0], a1 = ap[2 * LDP], a2 = ap[4 * LDP], a3 = ap[6 * LDP];
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b0.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b1.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b0.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b1.w, acc1, 0, 0, 0);
-    b0 = n0;
-    b1 = n1;
+    // keep the loads above ahead of this group's MFMAs (hipcc otherwise sinks each load to just before
+    // its first use and waits for it there)
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 bb = b[g % 3];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][0], bb.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][1], bb.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][2], bb.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][3], bb.w, acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -149,6 +156,8 @@ __device__ __forceinline__ void store_relu(const f32x16& acc, const float* __res
   }
 }
 
+// 8 waves: wave w owns output columns [32 w, 32 w + 32) of the hidden layers (two waves per SIMD keep the
+// matrix pipe fed across each other's LDS / L2 waits) and k in [32 w, 32 w + 32) of the output layer.
 __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(MlpArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xT = lds;                    // [MAX_IN][LDP]   layer-1 input, k-major
@@ -175,41 +184,22 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(MlpArgs p) {
   __syncthreads();
 
   const float4* P4 = reinterpret_cast<const float4*>(P);
-  // ---- layer 1: [32, in] x [in, 256]
-  {
-    f32x16 acc0 = {0}, acc1 = {0};
-    const float4* w0 = P4 + (L.w1 >> 2) + (size_t)(2 * wave) * L.g1 * 64;
-    const float4* w1 = w0 + (size_t)L.g1 * 64;
-    layer_64cols<1>(xT, w0, w1, L.g1, lane, acc0, acc1);
-    store_relu(acc0, P + L.b1, 64 * wave, lane, hA);
-    store_relu(acc1, P + L.b1, 64 * wave + 32, lane, hA);
-  }
-  __syncthreads();
-  // ---- layer 2: [32, 256] x [256, 256]
-  {
-    f32x16 acc0 = {0}, acc1 = {0};
-    const float4* w0 = P4 + (L.w2 >> 2) + (size_t)(2 * wave) * 32 * 64;
-    const float4* w1 = w0 + (size_t)32 * 64;
-    layer_64cols<1>(hA, w0, w1, 32, lane, acc0, acc1);
-    store_relu(acc0, P + L.b2, 64 * wave, lane, hB);
-    store_relu(acc1, P + L.b2, 64 * wave + 32, lane, hB);
-  }
-  __syncthreads();
-  // ---- layer 3: [32, 256] x [256, out <= 32]; wave w owns k in [64 w, 64 w + 64)
-  {
+  {  // ---- layer 1: [32, in <= 64] x [64, 256] (k zero-padded to 64)
     f32x16 acc = {0};
+    layer_tile<G1>(xT, P4 + (L.w1 >> 2) + (size_t)wave * G1 * 64, lane, acc);
+    store_relu(acc, P + L.b1, 32 * wave, lane, hA);
+  }
+  __syncthreads();
+  {  // ---- layer 2: [32, 256] x [256, 256]
+    f32x16 acc = {0};
+    layer_tile<32>(hA, P4 + (L.w2 >> 2) + (size_t)wave * 32 * 64, lane, acc);
+    store_relu(acc, P + L.b2, 32 * wave, lane, hB);
+  }
+  __syncthreads();
+  {  // ---- layer 3: [32, 256] x [256, out <= 32]; wave w owns k in [32 w, 32 w + 32)
+    f32x16 acc = {0};
+    layer_tile<4>(hB + (size_t)(32 * wave) * LDP, P4 + (L.w3 >> 2) + (size_t)(4 * wave) * 64, lane, acc);
     const int r = lane & 31, h = lane >> 5;
-    const float4* w3 = P4 + (L.w3 >> 2);
-#pragma unroll
-    for (int gg = 0; gg < 8; ++gg) {
-      const int g = 8 * wave + gg;
-      const float4 b = w3[(size_t)g * 64 + lane];
-      const float* ap = hB + (size_t)(8 * g + h) * LDP + r;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[0], b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * LDP], b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[4 * LDP], b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[6 * LDP], b.w, acc, 0, 0, 0);
-    }
     float* part = hA + (size_t)wave * RT * LDP;        // [row][col] partial of this wave
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -222,9 +212,8 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(MlpArgs p) {
   for (int e = tid; e < rows * out_dim; e += THREADS) {
     const int m = e / out_dim, c = e - m * out_dim;
     float s = hA[m * LDP + c];
-    s += hA[(RT + m) * LDP + c];
-    s += hA[(2 * RT + m) * LDP + c];
-    s += hA[(3 * RT + m) * LDP + c];
+#pragma unroll
+    for (int w = 1; w < KSPLIT; ++w) s += hA[(w * RT + m) * LDP + c];
     s += P[L.b3 + c];
     net.y[(size_t)(row0 + m) * out_dim + c] = s;
   }

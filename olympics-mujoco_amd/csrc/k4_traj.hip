@@ -91,6 +91,52 @@ inline int blocks_for(long n) {
   long b = (n + THREADS - 1) / THREADS;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
+
+// Expert data for the discriminator (GAIL._fit_discriminator, gail_TRPO.py:176-202): row m of
+// create_dataset's `states` is flattened sample m of the table restricted to the kept keys and row m
+// of `next_states` is sample m + 1 (utils/trajectory.py:158-175), so the device-resident table IS the
+// dataset: a minibatch is a row gather by caller-supplied indices, narrowed to float32 like the
+// reference's .astype(np.float32).  One lane per output element, n_cols consecutive lanes per row.
+__global__ __launch_bounds__(THREADS) void expert_gather_kernel(TrajDev tj, long B, const long* __restrict__ idx,
+                                                                int n_cols, const int* __restrict__ cols,
+                                                                float* __restrict__ out_states,
+                                                                float* __restrict__ out_next) {
+  const long total = B * n_cols;
+  const long stride = (long)gridDim.x * THREADS;
+  const long M = (long)tj.n_traj * tj.len;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += stride) {
+    const long b = e / n_cols;
+    const int c = (int)(e - b * n_cols);
+    long m = idx[b];
+    m = m < 0 ? 0 : (m > M - 2 ? M - 2 : m);      // dataset rows are 0 .. M-2 (clamped: device data cannot raise)
+    const int k = cols[c];
+    const double* row = tj.rows + (size_t)m * tj.n_keys;
+    out_states[e] = (float)row[k];
+    if (out_next) out_next[e] = (float)row[tj.n_keys + k];
+  }
+}
+
+// The whole dataset as arrays (create_dataset's return value), float64 like the reference's.
+__global__ __launch_bounds__(THREADS) void expert_dataset_kernel(TrajDev tj, int n_cols, const int* __restrict__ cols,
+                                                                 double* __restrict__ states,
+                                                                 double* __restrict__ next_states,
+                                                                 double* __restrict__ absorbing,
+                                                                 double* __restrict__ last) {
+  const long M = (long)tj.n_traj * tj.len;
+  const long total = (M - 1) * n_cols;
+  const long stride = (long)gridDim.x * THREADS;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += stride) {
+    const long m = e / n_cols;
+    const int k = cols[(int)(e - m * n_cols)];
+    const double* row = tj.rows + (size_t)m * tj.n_keys;
+    states[e] = row[k];
+    next_states[e] = row[tj.n_keys + k];
+  }
+  for (long m = (long)blockIdx.x * THREADS + threadIdx.x; m < M; m += stride) {
+    if (m < M - 1 && absorbing) absorbing[m] = 0.0;
+    if (last) last[m] = ((m + 1) % tj.len == 0) ? 1.0 : 0.0;      // split_points[1:] - 1 (equal-length trajectories)
+  }
+}
 }  // namespace
 
 extern "C" int oly_traj_upload(oly_ctx* ctx, int n_keys, int n_traj, int len, const double* table_host) {
@@ -153,5 +199,42 @@ extern "C" int oly_traj_euler(oly_ctx* ctx, int N, int n_qpos, double dt, const 
   hipLaunchKernelGGL(traj_euler_kernel, dim3(blocks_for((long)N * n_qpos)), dim3(THREADS), 0, oly_s(stream),
                      ctx->traj.n_keys, N, n_qpos, dt, curr_qpos, sample);
   OLY_LAUNCH_CHECK(ctx, "traj_euler_kernel");
+  return OLY_OK;
+}
+
+extern "C" int64_t oly_expert_rows(oly_ctx* ctx) {
+  if (!ctx || !ctx->traj_ok) return -1;
+  return (int64_t)ctx->traj.n_traj * ctx->traj.len - 1;
+}
+
+extern "C" int oly_expert_gather(oly_ctx* ctx, int64_t B, const int64_t* idx, int n_cols, const int32_t* cols,
+                                 float* out_states, float* out_next, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->traj_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_expert_gather before oly_traj_upload");
+  if (B < 0 || n_cols <= 0 || n_cols > ctx->traj.n_keys || !cols || (B > 0 && (!idx || !out_states)))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_expert_gather: bad argument (B=%ld n_cols=%d)", (long)B, n_cols);
+  if ((long)ctx->traj.n_traj * ctx->traj.len < 2) OLY_FAIL(ctx, OLY_ERANGE, "oly_expert_gather: the table has no transition");
+  if (B == 0) return OLY_OK;
+  long blocks = (B * n_cols + THREADS - 1) / THREADS;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(expert_gather_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->traj, (long)B,
+                     reinterpret_cast<const long*>(idx), n_cols, cols, out_states, out_next);
+  OLY_LAUNCH_CHECK(ctx, "expert_gather_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_expert_dataset(oly_ctx* ctx, int n_cols, const int32_t* cols, double* states, double* next_states,
+                                  double* absorbing, double* last, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->traj_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_expert_dataset before oly_traj_upload");
+  if (n_cols <= 0 || n_cols > ctx->traj.n_keys || !cols || !states || !next_states)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_expert_dataset: bad argument");
+  const long M = (long)ctx->traj.n_traj * ctx->traj.len;
+  if (M < 2) OLY_FAIL(ctx, OLY_ERANGE, "oly_expert_dataset: the table has no transition");
+  long blocks = ((M - 1) * n_cols + THREADS - 1) / THREADS;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(expert_dataset_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->traj, n_cols,
+                     cols, states, next_states, absorbing, last);
+  OLY_LAUNCH_CHECK(ctx, "expert_dataset_kernel");
   return OLY_OK;
 }

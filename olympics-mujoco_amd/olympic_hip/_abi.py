@@ -142,6 +142,9 @@ SIGNATURES = {
     "oly_traj_reset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "oly_traj_next": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "oly_traj_euler": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]),
+    "oly_expert_rows": (C.c_int64, [vp]),
+    "oly_expert_gather": (C.c_int, [vp, C.c_int64, vp, C.c_int, vp, vp, vp, vp]),
+    "oly_expert_dataset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "oly_contact_configure": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
     "oly_contact_reduce": (C.c_int, [vp, C.c_int, C.c_int] + [vp] * 13 + [vp]),
     "oly_a3_configure": (C.c_int, [vp, C.POINTER(A3Model)]),

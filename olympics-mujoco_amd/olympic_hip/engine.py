@@ -177,6 +177,39 @@ class Engine:
         self.ctx.call("oly_traj_euler", N, int(n_qpos), C.c_double(dt), ptr(curr_qpos), ptr(sample), self._s())
         return sample
 
+    # -------------------------------------------------------------- expert data (K4 table as the dataset)
+    def expert_rows(self):
+        from ._ffi import lib
+        n = int(lib().oly_expert_rows(self.ctx.handle))
+        if n < 0:
+            raise OlyError("expert data before traj_upload")
+        return n
+
+    def expert_gather(self, idx, cols, want_next=False, check=True):
+        """Rows `idx` ([B] int64 device tensor, caller-drawn) of create_dataset's states (and next_states)
+        restricted to the table keys `cols` ([n_cols] int32 device tensor), as float32."""
+        B, n_cols = int(idx.shape[0]), int(cols.shape[0])
+        _req(idx, "idx", (B,), torch.int64, self.device)
+        _req(cols, "cols", (n_cols,), torch.int32, self.device)
+        if check and B:
+            lo, hi = int(idx.min()), int(idx.max())
+            if lo < 0 or hi >= self.expert_rows():
+                raise OlyError(f"expert_gather: row index out of range [{lo}, {hi}] for {self.expert_rows()} rows")
+        st = self._new((B, n_cols), torch.float32)
+        nx = self._new((B, n_cols), torch.float32) if want_next else None
+        self.ctx.call("oly_expert_gather", C.c_int64(B), ptr(idx), n_cols, ptr(cols), ptr(st), ptr(nx), self._s())
+        return (st, nx) if want_next else st
+
+    def expert_dataset(self, cols):
+        """dict(states, next_states [rows, n_cols] f64, absorbing [rows], last [rows + 1]) on the device."""
+        n_cols, rows = int(cols.shape[0]), self.expert_rows()
+        _req(cols, "cols", (n_cols,), torch.int32, self.device)
+        d = dict(states=self._new((rows, n_cols), torch.float64), next_states=self._new((rows, n_cols), torch.float64),
+                 absorbing=self._new((rows,), torch.float64), last=self._new((rows + 1,), torch.float64))
+        self.ctx.call("oly_expert_dataset", n_cols, ptr(cols), ptr(d["states"]), ptr(d["next_states"]),
+                      ptr(d["absorbing"]), ptr(d["last"]), self._s())
+        return d
+
     # -------------------------------------------------------------- K3
     def contact_configure(self, geom_bodyid, floor_body, rfoot_body, lfoot_body):
         gb = np.ascontiguousarray(geom_bodyid, dtype=np.int32)

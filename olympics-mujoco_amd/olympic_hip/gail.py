@@ -175,6 +175,41 @@ class VDBLoss:
         return loss
 
 
+class ExpertDataset:
+    """The demonstrations of GAIL / VAIL resident on the device.
+
+    Trajectory.create_dataset (utils/trajectory.py:129-193) returns states / next_states as slices of
+    the flattened trajectory table; here the table is uploaded ONCE (oly_traj_upload, the same copy
+    K4's reset / next-sample kernels read) and the dataset is never materialised: a minibatch of the
+    discriminator (gail_TRPO.py:176-202, demo_obs = states[indices][:, state_mask].astype(np.float32))
+    is one row gather on the device by caller-drawn indices."""
+
+    def __init__(self, engine, trajectory, ignore_keys=("q_pelvis_tx", "q_pelvis_tz"), state_mask=None):
+        self.eng = engine
+        if engine.traj_shape != tuple(trajectory.table.shape):
+            engine.traj_upload(trajectory.table)
+        keys = list(trajectory.keys)
+        kept = [i for i, k in enumerate(keys) if k not in set(ignore_keys or ())]
+        mask = np.arange(len(kept)) if state_mask is None else np.asarray(state_mask, dtype=np.int64)
+        self.dataset_cols = torch.as_tensor(np.asarray(kept, dtype=np.int32), device=engine.device)
+        self.cols = torch.as_tensor(np.asarray(kept, dtype=np.int32)[mask], device=engine.device)   # mask folded in
+        self.rows = engine.expert_rows()
+
+    def arrays(self):
+        """states / next_states / absorbing / last exactly as create_dataset returns them (float64)."""
+        return self.eng.expert_dataset(self.dataset_cols)
+
+    def shuffled_indices(self, batch, rs=None):
+        """The first batch of mushroom's minibatch_generator (np.random.shuffle of arange(rows), first
+        `batch` entries): the reference's draw, made on the host, handed over as an input."""
+        idx = np.arange(self.rows)
+        (rs if rs is not None else np.random).shuffle(idx)
+        return torch.as_tensor(idx[:batch].astype(np.int64), device=self.eng.device)
+
+    def minibatch(self, idx, want_next=False):
+        return self.eng.expert_gather(idx, self.cols, want_next=want_next)
+
+
 class DiscriminatorTrainer:
     """The discriminator half of GAIL._fit_discriminator (gail_TRPO.py:167-218), states-only
     input as in the UnitreeH1 configuration: per epoch draw as many demonstration states as
@@ -189,7 +224,11 @@ class DiscriminatorTrainer:
                  n_epochs=1, use_noisy_targets=False, variational=True):
         self.r, self.loss, self.n_epochs = reward, loss, n_epochs
         dev = reward.eng.device
-        self.demo = torch.as_tensor(np.asarray(demo_states), dtype=torch.float32, device=dev)
+        # an ExpertDataset serves minibatches straight from the device-resident trajectory table (its
+        # columns already carry the state mask); an array is the dataset's `states` uploaded as is
+        self.expert = demo_states if isinstance(demo_states, ExpertDataset) else None
+        self.demo = None if self.expert is not None else torch.as_tensor(np.asarray(demo_states), dtype=torch.float32,
+                                                                         device=dev)
         self.noisy, self.variational = use_noisy_targets, variational
         self.opt = torch.optim.Adam(reward.net.parameters(), lr=lr, weight_decay=weight_decay)
 
@@ -198,9 +237,16 @@ class DiscriminatorTrainer:
         n = plcy_obs.shape[0]
         losses = []
         for _ in range(self.n_epochs):
-            idx = torch.randint(0, self.demo.shape[0], (n,), device=dev, generator=generator)
-            x = torch.cat([plcy_obs.to(torch.float32), self.demo[idx]]).contiguous()
-            xs = r.stand.forward(x, r.mask)                      # updates the running statistics
+            if self.expert is not None:
+                idx = torch.randint(0, self.expert.rows, (n,), device=dev, generator=generator)
+                plcy = plcy_obs.to(torch.float32)
+                plcy = plcy if r.mask is None else plcy[:, r.mask.long()]
+                x = torch.cat([plcy, self.expert.minibatch(idx)]).contiguous()
+                xs = r.stand.forward(x, None)                    # updates the running statistics
+            else:
+                idx = torch.randint(0, self.demo.shape[0], (n,), device=dev, generator=generator)
+                x = torch.cat([plcy_obs.to(torch.float32), self.demo[idx]]).contiguous()
+                xs = r.stand.forward(x, r.mask)                  # updates the running statistics
             if self.noisy:
                 demo_t = torch.empty((n, 1), device=dev).uniform_(0.80, 0.99, generator=generator)
                 plcy_t = torch.empty((n, 1), device=dev).uniform_(0.01, 0.10, generator=generator)

@@ -410,8 +410,12 @@ class PPO:
         self.old_policy = deepcopy(policy)
         self.policy, self.critic = policy, critic
         use_graph = bool(getattr(self, "use_graph", False))
-        self.actor_optimizer = optim.Adam(policy.parameters(), lr=self.lr, eps=self.eps, capturable=use_graph)
-        self.critic_optimizer = optim.Adam(critic.parameters(), lr=self.lr, eps=self.eps, capturable=use_graph)
+        # ONE optimiser arithmetic for the eager and the graph-replayed update: Adam(capturable=True) forms
+        # its bias corrections with device tensors, capturable=False with python floats - last-bit
+        # differences that Adam amplifies to 1e-3 within a few updates (profiles/r02/graph_drift)
+        capturable = use_graph or next(policy.parameters()).is_cuda
+        self.actor_optimizer = optim.Adam(policy.parameters(), lr=self.lr, eps=self.eps, capturable=capturable)
+        self.critic_optimizer = optim.Adam(critic.parameters(), lr=self.lr, eps=self.eps, capturable=capturable)
         env = env_fn()
         post = PPORollout(env.eng, gamma=self.gamma, lam=self.lam, eps=self.eps)
         obs_mirr = getattr(env, "mirror_clock_observation", None) if hasattr(env, "mirror_observation") else None
@@ -447,11 +451,14 @@ class PPO:
             stats = []
             graphed = None
             if use_graph and fused:
-                # Captured anew for every iteration's update phase (~15 ms).  A graph kept across
-                # iterations was observed on this ROCm / PyTorch build to drift from the eager
-                # update (first-layer bias gradients) once the rollout's eager allocations had run
-                # between replays; back-to-back replays within one update phase reproduce the eager
-                # update (tests/test_gpu_facade.py::test_ppo_train_iterations_on_vec_a3).
+                # Captured anew for every iteration's update phase (~15 ms).  profiles/r02/graph_drift/README.md:
+                # a captured torch update replays bit-exactly until a [synchronize -> kernel write into a newly
+                # allocated block of >= 1 MB] happens between two replays; after that the multi-block
+                # reductions of the first-layer bias gradients come back wrong (no tensor visible from python
+                # is overwritten: the victim is internal to the captured graph / the runtime).  A rollout does
+                # exactly that between two update phases, the minibatch loop below does not (index_select into
+                # static buffers, replay, tiny clones, a host-drawn permutation copied H2D), so the graph's
+                # lifetime is one update phase.
                 graphed = GraphedUpdate(self, env.eng, minibatch, observations.shape[1], actions.shape[1],
                                         obs_mirr, act_src, act_sign)
             for _ in range(self.epochs):

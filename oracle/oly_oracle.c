@@ -632,8 +632,8 @@ int oly_a3_vec_step_cpu(const oly_a3_model* m, int ngeom, const int32_t* geom_bo
 /* ============================================================================== K11 */
 
 /* One ReLU MLP in -> 256 -> 256 -> out as the f32 matrix cores evaluate it: every pre-activation is
-   the fmaf chain over k ascending from 0, bias added after the chain; the output layer runs four
-   chains over the k quarters [64w, 64w + 64) and adds them in order w = 0..3, then the bias.
+   the fmaf chain over k ascending from 0, bias added after the chain; the output layer runs eight
+   chains over k in [32w, 32w + 32) and adds them in order w = 0..7, then the bias.
    Gaussian_FF_Actor._get_dist_params (rl/policies/actor.py:180-195) / FF_V.forward (critic.py:62-74)
    up to the summation order of the Linear layers.                                                 */
 int oly_mlp_forward_cpu(int N, int in_dim, int out_dim, const float* x, const float* w1, const float* b1,
@@ -662,9 +662,9 @@ int oly_mlp_forward_cpu(int N, int in_dim, int out_dim, const float* x, const fl
     }
     for (int j = 0; j < out_dim; ++j) {
       float s = 0.0f;
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < 8; ++w) {
         float acc = 0.0f;
-        for (int k = 64 * w; k < 64 * w + 64; ++k) acc = fmaf(h2[k], w3[(size_t)j * H + k], acc);
+        for (int k = 32 * w; k < 32 * w + 32; ++k) acc = fmaf(h2[k], w3[(size_t)j * H + k], acc);
         s = (w == 0) ? acc : s + acc;
       }
       y[(size_t)n * out_dim + j] = s + b3[j];
