@@ -32,6 +32,11 @@ struct oly_batcher {
   unsigned char *h_con, *d_con;            // one slab: ncon [W,N] | geom1 [W,N,C] | geom2 | force6 [W,N,C,6]
   size_t con_bytes, off_g1, off_g2, off_f6;
   double* d_grf;                           // [N, n_grf] window mean
+  // packed mode: the worker reduces each env's slots to the first-contact force of every sensor pair
+  // right after its physics callback (per-thread scratch slots), only [W,N,n_grf] doubles cross PCIe
+  int packed;
+  double *h_grfw, *d_grfw;                 // pinned / device [W,N,n_grf]
+  std::vector<std::vector<unsigned char>> scratch;   // one env's slot slab per worker thread
   // thread pool
   std::vector<std::thread> workers;
   std::mutex mu;
@@ -50,7 +55,57 @@ void kinematic_step(int, const double*, double* qpos, double* qvel, void* user) 
   for (int i = 0; i < n; ++i) qpos[i] += b->dt * qvel[i];
 }
 
-void run_range(oly_batcher* b, int lo, int hi) {
+// One env's W contact snapshots -> per-substep ground-force vector: for every sensor pair the FIRST
+// contact between its two collision groups (either geom order), its force[:3]; zeros without one.
+// The host twin of il_grf_kernel's filter (UnitreeH1._get_ground_forces, UnitreeH1.py:113-123).
+void pack_env(const oly_batcher* b, int e, const int32_t* ncon, const int32_t* g1, const int32_t* g2,
+              const double* f6) {
+  const oly_ctx* ctx = b->ctx;
+  const int P = ctx->grf.n_pairs, K = 3 * P, C = b->C;
+  for (int w = 0; w < b->W; ++w) {
+    double* out = b->h_grfw + ((size_t)w * b->N + e) * K;
+    for (int k = 0; k < K; ++k) out[k] = 0.0;
+    int nc = ncon[w];
+    nc = nc < 0 ? 0 : (nc > C ? C : nc);
+    for (int p = 0; p < P; ++p) {
+      for (int i = 0; i < nc; ++i) {
+        const int a = g1[(size_t)w * C + i], c2 = g2[(size_t)w * C + i];
+        const int ga = (a >= 0 && a < ctx->grf.ngeom) ? ctx->grf_group_host[a] : -1;
+        const int gb = (c2 >= 0 && c2 < ctx->grf.ngeom) ? ctx->grf_group_host[c2] : -1;
+        if (ga < 0 || gb < 0) continue;
+        if ((ga == ctx->grf.pair_a[p] && gb == ctx->grf.pair_b[p]) || (ga == ctx->grf.pair_b[p] && gb == ctx->grf.pair_a[p])) {
+          const double* f = f6 + ((size_t)w * C + i) * 6;
+          out[3 * p] = f[0]; out[3 * p + 1] = f[1]; out[3 * p + 2] = f[2];
+          break;
+        }
+      }
+    }
+  }
+}
+
+void run_range(oly_batcher* b, int lo, int hi, int id) {
+  if (b->cfn && b->packed) {
+    const size_t W = (size_t)b->W, C = (size_t)b->C;
+    unsigned char* sc = b->scratch[id].data();
+    int32_t* ncon = reinterpret_cast<int32_t*>(sc);
+    const size_t off_g1 = (sizeof(int32_t) * W + 15) & ~(size_t)15;
+    const size_t off_g2 = off_g1 + sizeof(int32_t) * W * C;
+    const size_t off_f6 = (off_g2 + sizeof(int32_t) * W * C + 15) & ~(size_t)15;
+    for (int e = lo; e < hi; ++e) {
+      oly_il_contacts oc;
+      oc.W = b->W; oc.C = b->C;
+      oc.ncon = ncon; oc.ncon_stride = 1;
+      oc.geom1 = reinterpret_cast<int32_t*>(sc + off_g1);
+      oc.geom2 = reinterpret_cast<int32_t*>(sc + off_g2);
+      oc.geom_stride = (long)C;
+      oc.force6 = reinterpret_cast<double*>(sc + off_f6);
+      oc.force_stride = (long)(C * 6);
+      b->cfn(e, b->h_ctrl + (size_t)e * b->nu, b->h_qpos + (size_t)e * b->nq, b->h_qvel + (size_t)e * b->nv, &oc,
+             b->cuser);
+      pack_env(b, e, ncon, oc.geom1, oc.geom2, oc.force6);
+    }
+    return;
+  }
   if (b->cfn) {
     const size_t N = (size_t)b->N, C = (size_t)b->C;
     for (int e = lo; e < hi; ++e) {
@@ -83,7 +138,7 @@ void worker_main(oly_batcher* b, int id) {
       if (b->stop) return;
       seen = b->generation;
     }
-    if (lo < hi) run_range(b, lo, hi);
+    if (lo < hi) run_range(b, lo, hi, id);
     {
       std::lock_guard<std::mutex> lk(b->mu);
       if (--b->pending == 0) b->cv_done.notify_one();
@@ -118,6 +173,7 @@ extern "C" int oly_batcher_create(oly_batcher** out, oly_ctx* ctx, int N, int n_
   b->h_qpos = b->h_qvel = b->h_ctrl = nullptr;
   b->d_qpos = b->d_qvel = b->d_ctrl = b->d_prev = nullptr;
   b->W = b->C = 0; b->cfn = nullptr; b->cuser = nullptr; b->h_con = b->d_con = nullptr; b->d_grf = nullptr;
+  b->packed = 0; b->h_grfw = b->d_grfw = nullptr;
   const size_t sq = sizeof(double) * N * b->nq, sv = sizeof(double) * N * b->nv, sc = sizeof(double) * N * b->nu;
   bool ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_qpos), sq, hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc(reinterpret_cast<void**>(&b->h_qvel), sv, hipHostMallocDefault) == hipSuccess &&
@@ -155,6 +211,8 @@ extern "C" void oly_batcher_destroy(oly_batcher* b) {
   if (b->h_con) (void)hipHostFree(b->h_con);
   if (b->d_con) (void)hipFree(b->d_con);
   if (b->d_grf) (void)hipFree(b->d_grf);
+  if (b->h_grfw) (void)hipHostFree(b->h_grfw);
+  if (b->d_grfw) (void)hipFree(b->d_grfw);
   delete b;
 }
 
@@ -181,6 +239,29 @@ extern "C" int oly_batcher_enable_contacts(oly_batcher* b, int W, int C, oly_phy
   memset(b->h_con, 0, b->con_bytes);
   b->W = W; b->C = C; b->cuser = user;
   b->cfn = physics;   // workers read cfn under the step's generation hand-shake only
+  return OLY_OK;
+}
+
+extern "C" int oly_batcher_enable_contacts_packed(oly_batcher* b, int W, int C, oly_physics_contacts_fn physics,
+                                                  void* user) {
+  if (!b) return OLY_EINVAL;
+  oly_ctx* ctx = b->ctx;
+  if (W <= 0 || C <= 0 || !physics) OLY_FAIL(ctx, OLY_EINVAL, "oly_batcher_enable_contacts_packed: bad W, C or NULL physics");
+  if (!ctx->grf_ok || !ctx->grf_group_host) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_batcher_enable_contacts_packed before oly_grf_configure");
+  if (ctx->il_host.n_grf != 3 * ctx->grf.n_pairs)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_batcher_enable_contacts_packed: model n_grf=%d but %d sensor pairs", ctx->il_host.n_grf,
+             ctx->grf.n_pairs);
+  if (b->cfn) OLY_FAIL(ctx, OLY_EINVAL, "oly_batcher_enable_contacts_packed: contacts already enabled");
+  OLY_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)b->N, K = (size_t)ctx->il_host.n_grf;
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_grfw), sizeof(double) * W * N * K, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_grfw), sizeof(double) * W * N * K) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_grf), sizeof(double) * N * K) != hipSuccess)
+    OLY_FAIL(ctx, OLY_ENOMEM, "oly_batcher_enable_contacts_packed: allocation failed");
+  const size_t slab = ((sizeof(int32_t) * W + 15) & ~(size_t)15) + 2 * sizeof(int32_t) * W * C + 16 + sizeof(double) * W * C * 6;
+  b->scratch.assign((size_t)(b->n_threads > 0 ? b->n_threads : 1), std::vector<unsigned char>(slab, 0));
+  b->W = W; b->C = C; b->cuser = user; b->packed = 1;
+  b->cfn = physics;
   return OLY_OK;
 }
 
@@ -226,7 +307,13 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
   OLY_HIP(ctx, hipMemcpyAsync(b->d_qpos, b->h_qpos, sizeof(double) * b->N * b->nq, hipMemcpyHostToDevice, s));
   OLY_HIP(ctx, hipMemcpyAsync(b->d_qvel, b->h_qvel, sizeof(double) * b->N * b->nv, hipMemcpyHostToDevice, s));
   const double* grf = nullptr;
-  if (b->cfn) {
+  if (b->cfn && b->packed) {
+    const size_t K = (size_t)ctx->il_host.n_grf;
+    OLY_HIP(ctx, hipMemcpyAsync(b->d_grfw, b->h_grfw, sizeof(double) * b->W * b->N * K, hipMemcpyHostToDevice, s));
+    rc = oly_il_grf_window(ctx, b->W, b->N, (int)K, b->d_grfw, b->d_grf, stream);
+    if (rc) return rc;
+    grf = b->d_grf;
+  } else if (b->cfn) {
     OLY_HIP(ctx, hipMemcpyAsync(b->d_con, b->h_con, b->con_bytes, hipMemcpyHostToDevice, s));
     rc = oly_il_ground_forces(ctx, b->W, b->N, b->C, reinterpret_cast<const int32_t*>(b->d_con),
                               reinterpret_cast<const int32_t*>(b->d_con + b->off_g1),

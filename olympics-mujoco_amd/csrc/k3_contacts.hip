@@ -11,6 +11,8 @@
 // + popcount (bit-exact), the force sum as an IN-ORDER serial chain over the group (same
 // rounding as the reference's python loop), the minimum by a shuffle tree.
 // Bound: HBM, 4 + C*(4+4+48+8) B read per env (1028 B at C = 16).
+#include <cstdlib>
+
 #include "oly_common.h"
 
 namespace {
@@ -166,7 +168,36 @@ __global__ __launch_bounds__(THREADS) void il_grf_kernel(GrfDev gd, int W, int N
   }
 }
 
+// Window mean of per-substep ground-force vectors that are already dense rows (the host batcher packs
+// the first-contact force of every sensor pair while it copies the contacts out of mjData): lane per
+// output element, the W samples added in substep order, divided by W (RunningAveragedWindow after one
+// control step, loco_env_base.py:1072-1084,1163-1174).  HBM: (W + 1) * K * 8 B per environment.
+__global__ __launch_bounds__(THREADS) void il_grf_window_kernel(int W, long NK, const double* __restrict__ step,
+                                                                double* __restrict__ mean) {
+  const long stride = (long)gridDim.x * THREADS;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < NK; e += stride) {
+    double acc = 0.0;
+    for (int w = 0; w < W; ++w) acc += step[(size_t)w * NK + e];
+    mean[e] = acc / (double)W;
+  }
+}
+
 }  // namespace
+
+extern "C" int oly_il_grf_window(oly_ctx* ctx, int W, int N, int K, const double* grf_step, double* grf_mean,
+                                 oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (W <= 0 || N < 0 || K <= 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_il_grf_window: bad W, N or K");
+  if (N == 0) return OLY_OK;
+  if (!grf_step || !grf_mean) OLY_FAIL(ctx, OLY_EINVAL, "oly_il_grf_window: NULL pointer");
+  const long NK = (long)N * K;
+  long blocks = (NK + THREADS - 1) / THREADS;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(il_grf_window_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), W, NK, grf_step,
+                     grf_mean);
+  OLY_LAUNCH_CHECK(ctx, "il_grf_window_kernel");
+  return OLY_OK;
+}
 
 extern "C" int oly_contact_configure(oly_ctx* ctx, int ngeom, const int32_t* geom_bodyid_host,
                                      int floor_body, int rfoot_body, int lfoot_body) {
@@ -217,6 +248,10 @@ extern "C" int oly_grf_configure(oly_ctx* ctx, int ngeom, const int32_t* geom_gr
   if (hipMalloc(&ctx->grf.geom_group, sizeof(int) * ngeom) != hipSuccess)
     OLY_FAIL(ctx, OLY_ENOMEM, "oly_grf_configure: hipMalloc failed");
   OLY_HIP(ctx, hipMemcpy(ctx->grf.geom_group, geom_group_host, sizeof(int) * ngeom, hipMemcpyHostToDevice));
+  free(ctx->grf_group_host);
+  ctx->grf_group_host = static_cast<int*>(malloc(sizeof(int) * ngeom));
+  if (!ctx->grf_group_host) OLY_FAIL(ctx, OLY_ENOMEM, "oly_grf_configure: out of host memory");
+  memcpy(ctx->grf_group_host, geom_group_host, sizeof(int) * ngeom);
   ctx->grf.ngeom = ngeom;
   ctx->grf.n_pairs = n_pairs;
   for (int k = 0; k < n_pairs; ++k) { ctx->grf.pair_a[k] = pair_a[k]; ctx->grf.pair_b[k] = pair_b[k]; }

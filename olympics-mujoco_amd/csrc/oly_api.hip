@@ -57,6 +57,7 @@ extern "C" void oly_destroy(oly_ctx* ctx) {
   if (ctx->contact.geom_bodyid) (void)hipFree(ctx->contact.geom_bodyid);
   if (ctx->traj.rows) (void)hipFree(ctx->traj.rows);
   if (ctx->grf.geom_group) (void)hipFree(ctx->grf.geom_group);
+  free(ctx->grf_group_host);
   delete ctx;
 }
 

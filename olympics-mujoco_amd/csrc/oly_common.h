@@ -66,6 +66,7 @@ struct oly_ctx {
   bool traj_ok;
   GrfDev grf;
   bool grf_ok;
+  int* grf_group_host;          // host copy of grf.geom_group (the batcher packs contacts on the host)
   double* stats_ws;  // device [OLY_STATS_MAX_BLOCKS * 2 * OLY_MAX_OBS... ] partial sums
   size_t stats_ws_bytes;
   bool mlp_attr_done = false;   // dynamic-LDS limit of the fused MLP kernel raised on this device

@@ -132,6 +132,8 @@ SIGNATURES = {
     "oly_batcher_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "oly_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "oly_batcher_enable_contacts": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "oly_batcher_enable_contacts_packed": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "oly_il_grf_window": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "oly_a3_batcher_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "oly_a3_batcher_destroy": (None, [vp]),
     "oly_a3_batcher_slots": (C.c_int, [vp, C.c_int, C.POINTER(A3Readback)]),

@@ -44,8 +44,11 @@ class HostBatcher:
         self.absorbing = torch.empty(self.N, dtype=torch.uint8, device=dev)
         self.fall_code = torch.empty(self.N, dtype=torch.uint8, device=dev)
 
-    def enable_contacts(self, n_intermediate, max_contacts, physics):
-        """use_foot_forces: `physics(env, ctrl, qpos, qvel, con)` performs the control step's W
+    def enable_contacts(self, n_intermediate, max_contacts, physics, packed=False):
+        """packed=True: the worker threads reduce each environment's contact slots to the first-contact
+        force of every sensor pair on the host (oly_batcher_enable_contacts_packed): same observations,
+        W * 3 * n_pairs doubles per environment over PCIe instead of every slot.
+        use_foot_forces: `physics(env, ctrl, qpos, qvel, con)` performs the control step's W
         intermediate steps and writes contact snapshot w into con["ncon"][w], con["geom1"][w, i],
         con["geom2"][w, i], con["force6"][w, i, :] (numpy views of the pinned staging)."""
         sp = self.spec
@@ -65,7 +68,8 @@ class HostBatcher:
             physics(env, np.ctypeslib.as_array(ctrl, (nu,)), np.ctypeslib.as_array(qpos, (nq,)),
                     np.ctypeslib.as_array(qvel, (nv,)), con)
         self._ccb = _abi.PHYSICS_CONTACTS_FN(tramp)
-        rc = lib().oly_batcher_enable_contacts(self._h, W, Cc, C.cast(self._ccb, C.c_void_p), None)
+        fn = lib().oly_batcher_enable_contacts_packed if packed else lib().oly_batcher_enable_contacts
+        rc = fn(self._h, W, Cc, C.cast(self._ccb, C.c_void_p), None)
         check(self.eng.ctx.handle, rc, "oly_batcher_enable_contacts")
         return self
 

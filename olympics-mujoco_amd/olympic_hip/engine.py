@@ -498,6 +498,15 @@ class Engine:
                       ptr(mean), self._s())
         return dict(mean=mean, steps=steps)
 
+    def il_grf_window(self, grf_step, mean=None):
+        """[W,N,K] per-substep ground-force rows -> [N,K] window mean (sum in substep order / W)."""
+        W, N, K = (int(v) for v in grf_step.shape)
+        _req(grf_step, "grf_step", (W, N, K), torch.float64, self.device)
+        mean = _req(mean if mean is not None else self._new((N, K), torch.float64), "mean", (N, K), torch.float64,
+                    self.device)
+        self.ctx.call("oly_il_grf_window", W, N, K, ptr(grf_step), ptr(mean), self._s())
+        return mean
+
     # -------------------------------------------------------------- K8
     def disc_standardize(self, x, mask, mean, std, out=None):
         B, Dx = int(x.shape[0]), int(x.shape[1])

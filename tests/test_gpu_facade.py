@@ -713,9 +713,12 @@ def test_a3_host_batcher_replays_golden_sequence(golden):
     b.close()
 
 
-def test_host_batcher_with_foot_force_contacts(oracle):
+@pytest.mark.parametrize("packed", [False, True])
+def test_host_batcher_with_foot_force_contacts(oracle, packed):
     """IL batcher with use_foot_forces: the physics callback writes W = 10 contact snapshots per
-    env and control step; obs = [joint obs, window-mean ground forces / 1000]."""
+    env and control step; obs = [joint obs, window-mean ground forces / 1000].  packed: the worker
+    threads reduce the slots to per-pair first-contact forces on the host (dense rows over PCIe,
+    oly_il_grf_window on the device): identical observations."""
     from olympic_hip.batcher import HostBatcher
     from olympic_hip.engine import Engine
     sp = specs.unitree_h1("walk").with_foot_forces("UnitreeH1")
@@ -740,7 +743,7 @@ def test_host_batcher_with_foot_force_contacts(oracle):
     with pytest.raises(Exception, match="oly_batcher_enable_contacts"):
         b.step(torch.zeros((N, sp.n_act), device="cuda"))           # foot-force model without contact staging
     eng.grf_configure(sp.geom_group, sp.grf_pairs)
-    b.enable_contacts(W, Cc, physics)
+    b.enable_contacts(W, Cc, physics, packed=packed)
     prev = rng.normal(1.25, 0.3, N)
     b.set_prev(prev)
     means = np.stack([oracle.il_ground_forces(sp.geom_group, sp.grf_pairs, con["ncon"][k], con["geom1"][k],

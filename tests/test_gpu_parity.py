@@ -1019,6 +1019,8 @@ def test_il_ground_forces_vs_oracle(eng, oracle, W, N, C):
     assert np.array_equal(host(o["steps"]), e_step)
     assert np.array_equal(host(o["mean"]), e_mean)
     assert (e_step != 0).any() or N == 1
+    # the dense form (rows already reduced per substep, as the packed host batcher stages them)
+    assert np.array_equal(host(eng.il_grf_window(dev(e_step))), e_mean)
 
 
 def test_h1_env_with_foot_forces(eng, oracle):

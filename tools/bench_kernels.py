@@ -47,6 +47,14 @@ def big(eng):
     for mode, name, bpe in ((_abi.SCAN_RETURN, "K6_return_[400,262144]", 17), (_abi.SCAN_GAE, "K6_gae_[400,262144]", 21)):
         rec(name, timeit(eng, lambda: eng.return_scan(mode, 0.99, 0.97, r, v, nv, fl, ret, adv), reps=10), bpe * T * N)
     st = torch.empty(3, dtype=torch.float64, device=dev)
+    rec("K6_return_fused_stats_[400,262144]",
+        timeit(eng, lambda: eng.return_scan(_abi.SCAN_RETURN, 0.99, 0.97, r, v, nv, fl, ret, adv, stats3=st), reps=10),
+        17 * T * N)
+    r64 = r.double()
+    rec("K6_return_f64_rewards_fused_stats_[400,262144]",
+        timeit(eng, lambda: eng.return_scan(_abi.SCAN_RETURN, 0.99, 0.97, r64, v, nv, fl, ret, adv, stats3=st), reps=10),
+        21 * T * N)
+    del r64
     rec("K7_stats_[104857600]", timeit(eng, lambda: eng.adv_stats(adv, st), reps=10), 4 * T * N)
     rec("K7_normalize_[104857600]", timeit(eng, lambda: eng.adv_normalize(adv, st, 1, 1e-5), reps=10), 8 * T * N)
     x = adv.view(-1, 32)
@@ -82,6 +90,23 @@ def big(eng):
         timeit(eng, lambda: eng.il_ground_forces(ncon[:Nc].view(W, -1), g1.view(W, Nc // W, C), g2.view(W, Nc // W, C),
                                                  f6.view(W, Nc // W, C, 6)), reps=10), (4 + C * 8 + 2 * 24) * Nc)   # ncon + geom pairs + the two selected force rows
     del f6, pz, g1, g2
+    Wd, Nd, Kd = 10, 1 << 20, 6          # dense per-substep rows as the packed host batcher stages them (H1: 2 pairs x 3)
+    steps = rnd((Wd, Nd, Kd), torch.float64)
+    mean_o = torch.empty((Nd, Kd), dtype=torch.float64, device=dev)
+    rec("K3_il_grf_window_dense_[10,1048576,6]", timeit(eng, lambda: eng.il_grf_window(steps, mean_o), reps=10),
+        8 * Kd * (Wd + 1) * Nd)
+    del steps, mean_o
+    # K11 at a throughput size: 1 Mi rows through actor + critic (fp32 MFMA), reported as TFLOP/s too
+    from olympic_hip.mlp import FusedMLPForward
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    pi_, vf_ = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    fw = FusedMLPForward(eng, pi_, vf_)
+    xm = rnd((1 << 20, 41))
+    ms = timeit(eng, lambda: fw(xm), reps=10)
+    flop = 2 * (1 << 20) * ((41 * 256 + 256 * 256 + 256 * 12) + (41 * 256 + 256 * 256 + 256))
+    out["K11_mlp_forward2_[1048576,41]"] = dict(ms=ms, TFLOPs=flop / ms / 1e9, frac_of_f32_mfma_peak_157=flop / ms / 1e9 / 157.3,
+                                                 GBps=(41 + 13) * 4 * (1 << 20) / ms / 1e6)
+    del xm
     sp = specs.A3Spec(mass=41.5)
     eng.a3_configure(sp, np.zeros((4, sp.period)))
     Na = 1 << 20
@@ -125,6 +150,11 @@ def main():
         out[name] = dict(ms=ms, GBps=bpe * T * N / ms / 1e6, bytes_per_elem=bpe, elems=T * N)
     # K7
     st = torch.empty(3, dtype=torch.float64, device=dev)
+    ms = timeit(eng, lambda: eng.return_scan(_abi.SCAN_RETURN, 0.99, 0.97, r, v, nv, fl, ret, adv, stats3=st))
+    out["K6_return_fused_stats"] = dict(ms=ms, GBps=17 * T * N / ms / 1e6, note="scan + finishing launch")
+    r64 = r.double()
+    ms = timeit(eng, lambda: eng.return_scan(_abi.SCAN_RETURN, 0.99, 0.97, r64, v, nv, fl, ret, adv, stats3=st))
+    out["K6_return_f64_rewards_fused_stats"] = dict(ms=ms, GBps=21 * T * N / ms / 1e6)
     ms = timeit(eng, lambda: eng.adv_stats(adv, st))
     out["K7_stats"] = dict(ms=ms, GBps=4 * T * N / ms / 1e6)
     ms = timeit(eng, lambda: eng.adv_normalize(adv, st, 1, 1e-5))
