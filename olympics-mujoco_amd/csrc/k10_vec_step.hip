@@ -8,10 +8,10 @@
 // LATENCY-bound, not bandwidth-bound.  The stand-alone K2 gives one lane a whole environment:
 // ~27 dependent fp64 transcendental calls per lane = 24 us on 64 waves.  Here an environment is
 // 16 lanes (the K3 layout: one lane per contact slot, 4 environments per wave, 16 per
-// workgroup), and the transcendental calls are spread over those lanes in two dependency
-// rounds: every lane evaluates ONE function on ONE argument per round, so a round costs one
-// evaluation of each function class present (sin, cos, tan, exp, atan2) instead of 18 / 9 in
-// sequence.  The arithmetic per value is K2's, expression for expression (same libm entry
+// workgroup), and the transcendental calls are spread over lanes in two dependency rounds: the
+// environment's lanes form ONE argument each, then the evaluation is regrouped by function over the
+// workgroup's four waves (sin/cos, tan, exp, atan2), so a round costs ONE libm evaluation per wave
+// instead of 18 / 9 in sequence on one lane.  The arithmetic per value is K2's, expression for expression (same libm entry
 // points, -ffp-contract=off): observations, rewards and task state are bit-identical to
 // oly_contact_reduce + oly_a3_step.
 //
@@ -42,12 +42,10 @@ enum {
   L_AV = 26,     // qvel[3:6]
   L_AL = 29,     // act_len 16
   L_AVL = 45,    // act_vel 16
-  L_SA = 61,     // sequence row t1
-  L_SB = 65,     // sequence row t2
-  L_SC = 69,     // sequence row t2 + 1
-  L_R1 = 73,     // round-1 results [16][2]
-  L_R2 = 105,    // round-2 results [16][2]
-  L_ENV = 137
+  L_SEQ = 61,    // the whole step sequence [20][4]
+  L_R1 = 141,    // round-1 results [16][2]
+  L_R2 = 173,    // round-2 results [16][2]
+  L_ENV = 205
 };
 
 enum { F_NONE = 0, F_SINCOS = 1, F_TAN = 2, F_EXP = 3, F_ATAN2 = 4 };
@@ -89,8 +87,7 @@ __device__ __forceinline__ void eval_task(int cls, double a, double b, double& r
   r0 = 0.0;
   r1 = 0.0;
   if (cls == F_SINCOS) {
-    r0 = sin(a);
-    r1 = cos(a);
+    sincos(a, &r0, &r1);   // bit-identical to sin() / cos() on gfx950 (tools/hip/check_sincos.hip: 2^24 arguments)
   } else if (cls == F_TAN) {
     r0 = tan(a);
   } else if (cls == F_EXP) {
@@ -102,6 +99,8 @@ __device__ __forceinline__ void eval_task(int cls, double a, double b, double& r
 
 __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   __shared__ double s_env[EPW][L_ENV];
+  __shared__ double s_arg[EPW][SLOTS][2];   // libm arguments of the current round, by (environment, task)
+  __shared__ uint8_t s_cls[EPW][SLOTS];
   __shared__ float s_pre[EPW][MAX_NOBS + 1], s_post[EPW][MAX_NOBS + 1];
   const A3Dev* __restrict__ m = p.md;
   const int nu = m->nu, n_obs = m->n_obs, period = m->period, nq = m->nq, nv = m->nv;
@@ -122,30 +121,99 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   const size_t kN = (size_t)kk * N;
   double* se = s_env[el];
 
-  // ---------------------------------------------------------------- policy tail + memory.store
-  if (!reset_all) {
-    const bool det = p.ro.deterministic != 0;
-    for (int e = tid; e < rows * nu; e += THREADS) {
-      const int r = e / nu, j = e - r * nu;
-      const size_t nn = (size_t)(row0 + r);
-      const float mu = p.ro.mu[nn * nu + j];
-      float a = mu;
-      if (!det) {
-        const float sc = p.ro.scale[j] * p.ro.eps[(tN + nn) * nu + j];
-        a = mu + sc;
-      }
-      p.ro.buf_actions[(tN + nn) * nu + j] = a;
-      p.ro.pd_target[nn * nu + j] = (double)a + m->motor_offset[j];
-    }
-    for (int e = tid; e < rows * n_obs; e += THREADS)
-      p.ro.buf_states[(tN + row0) * n_obs + e] = p.ro.state[(size_t)row0 * n_obs + e];
-    if (tid < rows) p.ro.buf_values[tN + row0 + tid] = p.ro.value[row0 + tid];
-  }
-
-  // ---------------------------------------------------------------- K3: foot contacts of row kk
+  // ---------------------------------------------------------------- every independent global load, up front
+  // The launch is latency-bound: nothing below waits for a load that could have been issued here.  Contact
+  // slots and the whole step sequence are fetched unconditionally (a few hundred bytes per environment)
+  // instead of behind the counts / indices that select from them.
   const int C = p.b.C;
   const int passes = (C + SLOTS - 1) / SLOTS;
-  const int nc_raw = env_ok ? p.b.ncon[kN + n] : 0;
+  int nc_raw = 0, phase0 = 0, t1 = 0, t2 = 0, frames = 0, mode = OLY_MODE_STANDING, seq_len = 1, tlen = 0, rc = 0;
+  double va = 0.0, vb = 0.0, v_len = 0.0, v_vel = 0.0, vs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  int g1_0 = -1, g2_0 = -1;
+  double f0[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pz0 = 0.0;
+  int dst_b = -1;
+  if (env_ok) {
+    nc_raw = p.b.ncon[kN + n];
+    phase0 = p.st.phase[n];
+    t1 = p.st.t1[n];
+    t2 = p.st.t2[n];
+    frames = p.st.reached_frames[n];
+    mode = p.st.mode[n];
+    seq_len = p.st.seq_len[n];
+    tlen = p.ro.traj_len[n];
+    rc = p.ro.pool_count[n];
+    const size_t r3 = (kN + n) * 3, r4 = (kN + n) * 4;
+    if (slot < 4) va = p.b.root_quat[r4 + slot];
+    else if (slot < 7) va = p.b.root_pos[r3 + slot - 4];
+    else if (slot < 10) va = p.b.head_pos[r3 + slot - 7];
+    else if (slot < 13) va = p.b.lf_pos[r3 + slot - 10];
+    else va = p.b.rf_pos[r3 + slot - 13];
+    if (slot < 3) { vb = p.b.lf_vel[r3 + slot]; dst_b = L_LV + slot; }
+    else if (slot < 6) { vb = p.b.rf_vel[r3 + slot - 3]; dst_b = L_RV + slot - 3; }
+    else if (slot < 10) { vb = p.b.qpos[(kN + n) * nq + 3 + slot - 6]; dst_b = L_BQ + slot - 6; }
+    else if (slot < 13) { vb = p.b.qvel[(kN + n) * nv + 3 + slot - 10]; dst_b = L_AV + slot - 10; }
+    if (slot < nu) {
+      v_len = p.b.act_len[(kN + n) * nu + slot];
+      v_vel = p.b.act_vel[(kN + n) * nu + slot];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) vs[q] = p.st.sequence[(size_t)n * OLY_MAX_SEQ * 4 + slot + SLOTS * q];
+    if (slot < C) {
+      const size_t e0 = (kN + n) * C + slot;
+      g1_0 = p.b.geom1[e0];
+      g2_0 = p.b.geom2[e0];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) f0[q] = p.b.force6[e0 * 6 + q];
+      pz0 = p.b.cpos_z[e0];
+    }
+  }
+
+  // ---------------------------------------------------------------- policy tail: loads now, stores at the very end
+  // (the noise row eps[t] is touched for the first time here: its HBM latency hides behind the whole step)
+  constexpr int ACT_PT = (EPW * MAX_NU + THREADS - 1) / THREADS;       // action elements per thread
+  constexpr int OBS_PT = (EPW * MAX_NOBS + THREADS - 1) / THREADS;     // observation elements per thread
+  float pt_act[ACT_PT], pt_obs[OBS_PT], pt_val = 0.f;
+  if (!reset_all) {
+    const bool det = p.ro.deterministic != 0;
+#pragma unroll
+    for (int q = 0; q < ACT_PT; ++q) {
+      const int e = tid + q * THREADS;
+      pt_act[q] = 0.f;
+      if (e < rows * nu) {
+        const int r = e / nu, j = e - r * nu;
+        const size_t nn = (size_t)(row0 + r);
+        const float mu = p.ro.mu[nn * nu + j];
+        float a = mu;
+        if (!det) {
+          const float sc = p.ro.scale[j] * p.ro.eps[(tN + nn) * nu + j];
+          a = mu + sc;
+        }
+        pt_act[q] = a;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < OBS_PT; ++q) {
+      const int e = tid + q * THREADS;
+      pt_obs[q] = (e < rows * n_obs) ? p.ro.state[(size_t)row0 * n_obs + e] : 0.f;
+    }
+    if (tid < rows) pt_val = p.ro.value[row0 + tid];
+  }
+
+  // ---------------------------------------------------------------- stage the environment's inputs in LDS
+  if (env_ok) {
+    se[slot] = va;
+    if (dst_b >= 0) se[dst_b] = vb;
+    if (slot < nu) {
+      se[L_AL + slot] = v_len;
+      se[L_AVL + slot] = v_vel;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) se[L_SEQ + slot + SLOTS * q] = vs[q];
+  }
+  t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
+  t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
+
+  // ---------------------------------------------------------------- K3: foot contacts of row kk
   const int nc = min(max(nc_raw, 0), C);
   int cnt_r = 0, cnt_l = 0;
   double sum_r = 0.0, sum_l = 0.0, mz = 0.0;
@@ -155,20 +223,29 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
     bool is_r = false, is_l = false;
     double nrm = 0.0, pz = 0.0;
     if (env_ok && i < nc) {
-      const size_t e = (kN + n) * C + i;
-      const int g1 = p.b.geom1[e], g2 = p.b.geom2[e];
+      int g1 = g1_0, g2 = g2_0;
+      double f[6] = {f0[0], f0[1], f0[2], f0[3], f0[4], f0[5]};
+      pz = pz0;
+      if (ps > 0) {            // more than 16 contact slots: the later passes load on demand
+        const size_t e = (kN + n) * C + i;
+        g1 = p.b.geom1[e];
+        g2 = p.b.geom2[e];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) f[q] = p.b.force6[e * 6 + q];
+        pz = p.b.cpos_z[e];
+      }
       if (g1 >= 0 && g1 < p.cd.ngeom && g2 >= 0 && g2 < p.cd.ngeom) {
         const int b1 = p.cd.geom_bodyid[g1], b2 = p.cd.geom_bodyid[g2];
         is_r = (b1 == p.cd.floor_body) && (b2 == p.cd.rfoot_body);
         is_l = (b1 == p.cd.floor_body) && (b2 == p.cd.lfoot_body);
       }
       if (is_r || is_l) {
-        const double* f = p.b.force6 + e * 6;
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < 6; ++q) s += f[q] * f[q];
         nrm = sqrt(s);
-        pz = p.b.cpos_z[e];
+      } else {
+        pz = 0.0;
       }
     }
     const unsigned long long br = __ballot(is_r), bl = __ballot(is_l);
@@ -193,47 +270,6 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   const double grf_r = sum_r, grf_l = sum_l;
   const double min_z = have ? mz : 0.0;
   const bool bad = (cnt_r + cnt_l) != nc_raw;
-
-  // ---------------------------------------------------------------- stage the environment's inputs
-  int phase0 = 0, t1 = 0, t2 = 0, frames = 0, mode = OLY_MODE_STANDING, seq_len = 1, tlen = 0;
-  int rc = 0;
-  if (env_ok) {
-    phase0 = p.st.phase[n];
-    t1 = p.st.t1[n];
-    t2 = p.st.t2[n];
-    frames = p.st.reached_frames[n];
-    mode = p.st.mode[n];
-    seq_len = p.st.seq_len[n];
-    tlen = p.ro.traj_len[n];
-    rc = p.ro.pool_count[n];
-    t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
-    t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
-    const int t3 = min(t2 + 1, OLY_MAX_SEQ - 1);
-    const size_t r3 = (kN + n) * 3, r4 = (kN + n) * 4;
-    // round A: one element per lane
-    double va;
-    if (slot < 4) va = p.b.root_quat[r4 + slot];
-    else if (slot < 7) va = p.b.root_pos[r3 + slot - 4];
-    else if (slot < 10) va = p.b.head_pos[r3 + slot - 7];
-    else if (slot < 13) va = p.b.lf_pos[r3 + slot - 10];
-    else va = p.b.rf_pos[r3 + slot - 13];
-    se[slot] = va;
-    // round B
-    if (slot < 3) se[L_LV + slot] = p.b.lf_vel[r3 + slot];
-    else if (slot < 6) se[L_RV + slot - 3] = p.b.rf_vel[r3 + slot - 3];
-    else if (slot < 10) se[L_BQ + slot - 6] = p.b.qpos[(kN + n) * nq + 3 + slot - 6];
-    else if (slot < 13) se[L_AV + slot - 10] = p.b.qvel[(kN + n) * nv + 3 + slot - 10];
-    // rounds C, D: actuator rows
-    if (slot < nu) {
-      se[L_AL + slot] = p.b.act_len[(kN + n) * nu + slot];
-      se[L_AVL + slot] = p.b.act_vel[(kN + n) * nu + slot];
-    }
-    // round E: the three sequence rows the step can touch
-    if (slot < 12) {
-      const int row = slot < 4 ? t1 : (slot < 8 ? t2 : t3);
-      se[L_SA + slot] = p.st.sequence[((size_t)n * OLY_MAX_SEQ + row) * 4 + (slot & 3)];
-    }
-  }
   __syncthreads();
 
   // ---------------------------------------------------------------- level 1: everything without libm
@@ -245,7 +281,7 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   // WalkingTask.step (walking_task.py:246-293)
   int phase = phase0 + 1;
   if (phase >= period) phase = 0;
-  double tx = se[L_SA], ty = se[L_SA + 1], tz = se[L_SA + 2];
+  const double tx = se[L_SEQ + 4 * t1], ty = se[L_SEQ + 4 * t1 + 1], tz = se[L_SEQ + 4 * t1 + 2];
   const double dl = norm3d(lf0 - tx, lf1 - ty, lf2 - tz);
   const double dr = norm3d(rf0 - tx, rf1 - ty, rf2 - tz);
   int reached;
@@ -256,18 +292,15 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
     reached = 0;
     frames = 0;
   }
-  int selA = L_SA, selB = L_SB;   // LDS rows holding sequence[t1] / sequence[t2] after the update
   if (reached && frames >= m->delay_frames) {  // update_target_steps
-    const int t2_old = t2;
     t1 = t2;
     t2 += 1;
     if (t2 == seq_len) t2 = seq_len - 1;
     t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
     reached = 0;
     frames = 0;
-    selA = L_SB;
-    selB = (t2 == t2_old) ? L_SB : L_SC;
   }
+  const int selA = L_SEQ + 4 * t1, selB = L_SEQ + 4 * t2;   // sequence[t1] / sequence[t2] after the update
   const double s1x = se[selA], s1y = se[selA + 1], s1z = se[selA + 2], s1w = se[selA + 3];
   const double s2x = se[selB], s2y = se[selB + 1], s2z = se[selB + 2], s2w = se[selB + 3];
 
@@ -361,10 +394,23 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
     case 14: if (need_reset && cyr > 4.0 * EPS) { cls = F_ATAN2; a = R[1][0]; b = R[0][0]; } break;   // root yaw
     default: if (need_reset) { cls = F_SINCOS; a = 2 * PI * new_phase / (double)period; } break;      // clock after reset
   }
+  // The environment's lanes only FORM the arguments.  The evaluation is regrouped by function so that a
+  // wave runs ONE libm body instead of diverging over five: wave 0 takes the sin/cos tasks of the
+  // workgroup's 16 environments, wave 1 the tan tasks, wave 2 the exp tasks, wave 3 the atan2 tasks.
+  s_arg[el][slot][0] = a;
+  s_arg[el][slot][1] = b;
+  s_cls[el][slot] = (uint8_t)(env_ok ? cls : F_NONE);
+  __syncthreads();
   double r0, r1;
-  eval_task(env_ok ? cls : F_NONE, a, b, r0, r1);
-  se[L_R1 + 2 * slot] = r0;
-  se[L_R1 + 2 * slot + 1] = r1;
+  {
+    constexpr int R1_TASK[4][4] = {{0, 1, 6, 13}, {2, 3, 4, 5}, {7, 8, 9, 10}, {11, 12, 14, -1}};
+    const int ee = lane & 15, task = R1_TASK[wave][lane >> 4];
+    if (task >= 0) {
+      eval_task(s_cls[ee][task], s_arg[ee][task][0], s_arg[ee][task][1], r0, r1);
+      s_env[ee][L_R1 + 2 * task] = r0;
+      s_env[ee][L_R1 + 2 * task + 1] = r1;
+    }
+  }
   __syncthreads();
 
   // ---------------------------------------------------------------- round 2
@@ -393,9 +439,24 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
     case 5: if (need_reset) { cls = F_SINCOS; a = root_yaw; } break;               // transform_sequence rotation
     default: break;
   }
-  eval_task(env_ok ? cls : F_NONE, a, b, r0, r1);
-  se[L_R2 + 2 * slot] = r0;
-  se[L_R2 + 2 * slot + 1] = r1;
+  if (slot < 6) {
+    s_arg[el][slot][0] = a;
+    s_arg[el][slot][1] = b;
+    s_cls[el][slot] = (uint8_t)(env_ok ? cls : F_NONE);
+  }
+  __syncthreads();
+  {
+    // wave 0: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's clock-after-reset, slot 15, which only
+    // needed level-1 values); wave 1: atan2 (the two goal yaws); wave 2: exp (orientation); wave 3: idle
+    constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
+    const int ee = lane & 15, task = R2_TASK[wave][lane >> 4];
+    if (task >= 0) {
+      eval_task(s_cls[ee][task], s_arg[ee][task][0], s_arg[ee][task][1], r0, r1);
+      const int dst = task == 15 ? L_R1 + 2 * 15 : L_R2 + 2 * task;
+      s_env[ee][dst] = r0;
+      s_env[ee][dst + 1] = r1;
+    }
+  }
   __syncthreads();
 
   // ---------------------------------------------------------------- combine, observation rows
@@ -511,6 +572,25 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
       }
       if (slot < 8) p.st.goal[8 * (size_t)n + slot] = goal[slot];
     }
+  }
+  // memory.store(state, action, value) and the PD target (ppo.py:186, robot.py:88-95)
+  if (!reset_all) {
+#pragma unroll
+    for (int q = 0; q < ACT_PT; ++q) {
+      const int e = tid + q * THREADS;
+      if (e < rows * nu) {
+        const int r = e / nu, j = e - r * nu;
+        const size_t nn = (size_t)(row0 + r);
+        p.ro.buf_actions[(tN + nn) * nu + j] = pt_act[q];
+        p.ro.pd_target[nn * nu + j] = (double)pt_act[q] + m->motor_offset[j];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < OBS_PT; ++q) {
+      const int e = tid + q * THREADS;
+      if (e < rows * n_obs) p.ro.buf_states[(tN + row0) * n_obs + e] = pt_obs[q];
+    }
+    if (tid < rows) p.ro.buf_values[tN + row0 + tid] = pt_val;
   }
   // next observation for the policy: dense [rows, n_obs] stream
   for (int e = tid; e < rows * n_obs; e += THREADS) {

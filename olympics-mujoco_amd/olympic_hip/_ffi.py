@@ -17,6 +17,7 @@ class OlyError(RuntimeError):
 
 
 _lib = None
+_ROCTX = os.environ.get("OLY_ROCTX", "0") == "1"
 
 
 def lib():
@@ -80,7 +81,15 @@ class Context:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def call(self, name, *args):
-        rc = getattr(lib(), name)(self._h, *args)
+        if _ROCTX:                                   # OLY_ROCTX=1: a roctx range per entry point (rocprofv3 --marker-trace)
+            import torch
+            torch.cuda.nvtx.range_push(name)
+            try:
+                rc = getattr(lib(), name)(self._h, *args)
+            finally:
+                torch.cuda.nvtx.range_pop()
+        else:
+            rc = getattr(lib(), name)(self._h, *args)
         check(self._h, rc, name)
 
     def close(self):

@@ -325,6 +325,9 @@ class StickFigureA3:
         obs = self.vec._evaluate(inp)["obs"]
         for k, v in keep.items():
             self.vec.state[k].copy_(v)
+        # get_obs reads the task's STORED goal steps (StickFigureA3.py:150-154): after a reset those are the
+        # zeros WalkingTask.reset wrote (walking_task.py:325-328), not what update_goal_steps would derive
+        obs[:, -8:] = keep["goal"].to(obs.dtype)
         return obs if self.num_envs > 1 else obs[0].cpu().numpy()
 
     def reset(self, env_mask=None):

@@ -61,3 +61,32 @@ def mean_std_from_stats(stats3, ddof):
     mean = stats3[1] / cnt
     var = torch.clamp((stats3[2] - cnt * mean * mean) / (cnt - ddof), min=0.0)
     return mean, torch.sqrt(var)
+
+
+def broadcast_parameters(modules, src=0):
+    """One learner replicated on every rank: copy rank `src`'s parameters and buffers to all ranks
+    (the reference has ONE policy / critic that every ray worker receives, rl/algos/ppo.py:200-207)."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src=src)
+
+
+def allreduce_gradients(params):
+    """Mean of the gradients over ranks in ONE fused all-reduce (policy + critic ~ 160 k floats = 0.6 MB:
+    latency-bound on xGMI, so a single flat buffer).  With equal shard sizes the mean of the per-rank
+    minibatch means is the gradient of the global minibatch the reference's single learner would see."""
+    if not is_dist() or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n

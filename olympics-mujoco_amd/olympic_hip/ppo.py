@@ -417,6 +417,14 @@ class PPO:
         self.actor_optimizer = optim.Adam(policy.parameters(), lr=self.lr, eps=self.eps, capturable=capturable)
         self.critic_optimizer = optim.Adam(critic.parameters(), lr=self.lr, eps=self.eps, capturable=capturable)
         env = env_fn()
+        from . import dist as odist
+        multi_rank = odist.is_dist() and torch.distributed.get_world_size() > 1
+        if multi_rank:
+            # one learner, replicated: same initial weights everywhere, gradients averaged before every step;
+            # the advantage statistics are already global (PPORollout).  The graph-captured update holds no
+            # collective, so multi-rank training takes the eager update path.
+            odist.broadcast_parameters([policy, critic, self.old_policy])
+            use_graph = False
         post = PPORollout(env.eng, gamma=self.gamma, lam=self.lam, eps=self.eps)
         obs_mirr = getattr(env, "mirror_clock_observation", None) if hasattr(env, "mirror_observation") else None
         act_mirr = getattr(env, "mirror_action", None)
@@ -492,6 +500,8 @@ class PPO:
                     else:
                         (a_l + self.mirror_coeff * m_l + self.ent_coeff * ent).sum().backward()
                         c_l.backward()
+                    if multi_rank:
+                        odist.allreduce_gradients(list(policy.parameters()) + list(critic.parameters()))
                     torch.nn.utils.clip_grad_norm_(policy.parameters(), self.grad_clip)
                     self.actor_optimizer.step()
                     torch.nn.utils.clip_grad_norm_(critic.parameters(), self.grad_clip)

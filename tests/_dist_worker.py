@@ -30,6 +30,15 @@ def main():
     for ddof, eps, key in ((1, 1e-5, "ppo"), (0, 1e-8, "gail")):
         mean, std = odist.mean_std_from_stats(total, ddof)
         res[key] = ((mine - mean) / (std + eps)).float().numpy()
+    # one learner replicated: parameters broadcast from rank 0, gradients averaged in one all-reduce
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 2))
+    odist.broadcast_parameters([net])
+    res["w_after_broadcast"] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    for i, p in enumerate(net.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    odist.allreduce_gradients(list(net.parameters()))
+    res["g_after_allreduce"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
     np.savez(os.path.join(out, f"rank{rank}.npz"), **res)
     if rank == 0:
         np.save(os.path.join(out, "full.npy"), adv.astype(np.float64))

@@ -275,6 +275,13 @@ def test_adv_stats_allgather_two_ranks_gloo(tmp_path):
         got = np.concatenate([r0[key], r1[key]], axis=1)
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
     assert r0["total"][0] == adv.size
+    # replicated learner: identical weights after the broadcast, gradients = mean over ranks
+    assert np.array_equal(r0["w_after_broadcast"], r1["w_after_broadcast"])
+    torch.manual_seed(100)
+    net0 = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 2))
+    assert np.array_equal(r0["w_after_broadcast"], torch.cat([p.detach().reshape(-1) for p in net0.parameters()]).numpy())
+    want = np.concatenate([np.full(n, 1.5 * (i + 1), np.float32) for i, n in enumerate((35, 7, 14, 2))])
+    assert np.array_equal(r0["g_after_allreduce"], want) and np.array_equal(r1["g_after_allreduce"], want)
 
 
 # ------------------------------------------------------------------------------ A3 host side
