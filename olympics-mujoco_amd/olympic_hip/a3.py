@@ -292,6 +292,15 @@ class StickFigureA3:
     def device(self):
         return self.vec.eng.device
 
+    @property
+    def has_device_physics(self):
+        return self.vec.has_device_physics
+
+    def device_rollout(self, *args, **kw):
+        """PPO.sample on the device (vecstep.A3DeviceRollout) when the physics readback lives there."""
+        self.vec.iteration_count = self.robot.iteration_count if np.isfinite(self.robot.iteration_count) else 10 ** 9
+        return self.vec.device_rollout(*args, **kw)
+
     def _draw_init_state(self):
         """reset_model's draws, in the reference's order (StickFigureA3.py:213-228)."""
         rs, sp, c = self.rs, self.spec, 0.02

@@ -117,6 +117,31 @@ def test_vec_step_vs_oracle(eng, golden, oracle, N, T, max_len, det):
     assert cut_not_done.sum() == (ro["side_t"] >= 0).sum()       # one bootstrap row per non-terminal cut
 
 
+def test_vec_step_more_than_sixteen_contact_slots(eng, golden, oracle):
+    """C = 20 contact slots per environment: the second 16-slot pass loads on demand; still the oracle's
+    numbers (contact counts and force sums cross the pass boundary)."""
+    spec = specs.A3Spec(mass=41.5)
+    lut = golden("a3_task.npz")["clock_lut"]
+    N, T, C = 77, 4, 20
+    blocks, state, ro, rng = _host_rollout(spec, N, 3, T, 3, 2, seed=9, det=True)
+    b20 = a3_synthetic_blocks(N, 3, seed=9, C=C, p_bad=0.3, p_low=0.02)
+    b20["ncon"] = rng.integers(0, C + 1, b20["ncon"].shape).astype(np.int32)      # up to all 20 slots in use
+    blocks = b20
+    d_blocks, d_state, d_ro = _to_device(eng, blocks, state, ro)
+    launch = eng.a3_vec_prepare(d_blocks, d_state, d_ro)
+    launch(_abi.VSTEP_RESET_ALL)
+    oracle.a3_vec_step(spec, lut, CONTACT, blocks, state, ro, _abi.VSTEP_RESET_ALL)
+    for t in range(T):
+        d_ro["state"].copy_(dev(ro["state"]))
+        launch(0)
+        oracle.a3_vec_step(spec, lut, CONTACT, blocks, state, ro, 0)
+        assert np.array_equal(d_ro["buf_flags"].cpu().numpy(), ro["buf_flags"])
+        np.testing.assert_allclose(d_ro["buf_rewards"].cpu().numpy(), ro["buf_rewards"], rtol=1e-11, atol=1e-13)
+        for k in ("phase", "t1", "t2", "reached_frames", "mode", "seq_len"):
+            assert np.array_equal(d_state[k].cpu().numpy(), state[k]), k
+    assert (blocks["ncon"] > 16).any()
+
+
 def test_vec_step_equals_the_separate_kernels(eng, golden):
     """The fused launch against oly_contact_reduce + oly_a3_step + oly_a3_pd_target +
     oly_rollout_cuts on the same readback row: the same libm entry points on the same arguments, so
