@@ -21,7 +21,10 @@
 #include "oly_common.h"
 
 namespace {
-constexpr int THREADS = 256;
+#ifndef OLY_K10_THREADS
+#define OLY_K10_THREADS 256   // 128 (8 environments, two workgroups per CU) measured slower: 15.7 vs 14.1 us
+#endif
+constexpr int THREADS = OLY_K10_THREADS;
 constexpr int SLOTS = 16;               // lanes per environment
 constexpr int EPW = THREADS / SLOTS;    // environments per workgroup
 constexpr double PI = 3.141592653589793;
@@ -403,8 +406,13 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   __syncthreads();
   double r0, r1;
   {
+#if OLY_K10_THREADS == 256   // 16 environments: one function per wave
     constexpr int R1_TASK[4][4] = {{0, 1, 6, 13}, {2, 3, 4, 5}, {7, 8, 9, 10}, {11, 12, 14, -1}};
     const int ee = lane & 15, task = R1_TASK[wave][lane >> 4];
+#else                        // 8 environments, two workgroups per CU: two functions per wave
+    constexpr int R1_TASK[2][8] = {{0, 1, 6, 13, 2, 3, 4, 5}, {7, 8, 9, 10, 11, 12, 14, -1}};
+    const int ee = lane & 7, task = R1_TASK[wave][lane >> 3];
+#endif
     if (task >= 0) {
       eval_task(s_cls[ee][task], s_arg[ee][task][0], s_arg[ee][task][1], r0, r1);
       s_env[ee][L_R1 + 2 * task] = r0;
@@ -448,8 +456,13 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   {
     // wave 0: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's clock-after-reset, slot 15, which only
     // needed level-1 values); wave 1: atan2 (the two goal yaws); wave 2: exp (orientation); wave 3: idle
+#if OLY_K10_THREADS == 256
     constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
     const int ee = lane & 15, task = R2_TASK[wave][lane >> 4];
+#else
+    constexpr int R2_TASK[2][8] = {{3, 4, 5, 15, -1, -1, -1, -1}, {0, 1, 2, -1, -1, -1, -1, -1}};
+    const int ee = lane & 7, task = R2_TASK[wave][lane >> 3];
+#endif
     if (task >= 0) {
       eval_task(s_cls[ee][task], s_arg[ee][task][0], s_arg[ee][task][1], r0, r1);
       const int dst = task == 15 ? L_R1 + 2 * 15 : L_R2 + 2 * task;
