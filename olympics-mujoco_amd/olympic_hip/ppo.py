@@ -320,7 +320,21 @@ class PPO:
         buf = RolloutBuffer(T, N, obs_dim, act_dim, dev)
         state = env.reset().to(torch.float32)
         traj_len = torch.zeros(N, dtype=torch.int32, device=dev)
-        if getattr(self, "use_graph_rollout", False):
+        from .mlp import FusedMLPForward
+        eng_ = getattr(env, "eng", None)
+        if eng_ is not None and getattr(self, "fused_forward", True) and FusedMLPForward.supports(policy, critic) \
+                and next(policy.parameters()).is_cuda:
+            # host-stepped physics: the actor + critic forward of every vec step is still ONE launch (K11)
+            # instead of the modules' ten (rl/algos/ppo.py:181-182); the sample is mu + (std * anneal) * eps
+            fw = FusedMLPForward(eng_, policy, critic)
+            scale = None if deterministic else fw.std(state, act_dim) * float(anneal)
+
+            def ac(s):
+                mu, v = fw(s.contiguous())
+                if deterministic:
+                    return mu.clone(), v.clone()
+                return mu + scale * torch.randn_like(mu), v.clone()
+        elif getattr(self, "use_graph_rollout", False):
             # one graph per rollout (same lifetime rule as the update graph: no eager allocations of
             # other phases between its replays)
             ac = GraphedActorCritic(policy, critic, N, obs_dim, dev, deterministic, anneal)

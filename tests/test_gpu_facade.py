@@ -622,6 +622,7 @@ def test_graphed_rollout_equals_eager_rollout(golden):
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
     ppo = PPO.__new__(PPO)
     ppo.use_device_rollout = False               # the per-step host loop; the device rollout has its own test
+    ppo.fused_forward = False                    # the modules' torch forward (eager vs its graph replay)
     bufs = []
     for graph in (False, True):
         ppo.use_graph_rollout = graph
@@ -636,6 +637,12 @@ def test_graphed_rollout_equals_eager_rollout(golden):
     z = (s.actions - mu) / (float(pi.fixed_std) * 0.5)
     assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02   # N(mu, (std * anneal)^2)
     assert torch.equal(s.values, vf(s.states.reshape(-1, 41)).reshape(T, N))
+    # the default host loop evaluates both MLPs with ONE K11 launch per vec step: same rollout up to the
+    # summation order of the matrix products
+    ppo.fused_forward = True
+    f = ppo.sample_vec(Env(), pi, vf, T, 10, deterministic=True)
+    assert torch.equal(f.states, a.states) and torch.equal(f.flags, a.flags) and torch.equal(f.rewards, a.rewards)
+    assert torch.allclose(f.actions, a.actions, rtol=1e-5, atol=1e-6) and torch.allclose(f.values, a.values, rtol=1e-5, atol=1e-6)
 
 
 def test_examples_run(tmp_path):
