@@ -364,7 +364,10 @@ def bench_config2(args, rk):
                      "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
     }
     if world == 1 and not args.no_per_step and args.robot == "h1":
-        line["per_step"] = per_step_block(rk, eng, spec, N)
+        try:                       # a secondary block must never cost the headline line
+            line["per_step"] = per_step_block(rk, eng, spec, N)
+        except Exception as e:     # noqa: BLE001
+            line["per_step"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_config2(spec)
     return line
