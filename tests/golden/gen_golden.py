@@ -31,6 +31,9 @@ fixtures do.  Fixture -> reference function map (file:line in /root/reference):
                   terms of tasks/rewards.py, StickFigureA3.get_obs
                   (StickFigureA3.py:144), JVRC.step (environments/robot.py:88),
                   MujocoRobotInterface.step_pd (mujoco_robot_interface.py:425)
+  a3_reset.npz    WalkingTask.reset + transform_sequence + get_obs of the freshly reset task
+                  (walking_task.py:113-135,321-397, StickFigureA3.py:229-232) with the local step
+                  sequence captured between generate_step_sequence and transform_sequence
   contacts.npz    MujocoRobotInterface.get_{r,l}foot_floor_contacts (:245-273),
                   get_{r,l}foot_grf (:275-297), check_* (:381-413)
   symmetry.npz    _get_symmetry_matrix (rl/envs/wrappers.py:75),
@@ -763,6 +766,69 @@ def gen_a3_task():
          pd_q=q_seq, pd_qd=qd_seq, pd_tau=taus, **rec)
 
 
+def gen_a3_reset():
+    """StickFigureA3.reset_model's task half: WalkingTask.reset (walking_task.py:321-397: mode / phase draws,
+    generate_step_sequence, transform_sequence about the feet's mid point and the root yaw) followed by
+    get_obs of the un-advanced task (StickFigureA3.py:229-232): goal steps zero, clock of the drawn phase.
+    The local step sequence (generate_step_sequence's return value) is captured on its way into
+    transform_sequence: it is what the device-side reset takes as its pre-drawn record."""
+    rng = np.random.default_rng(23)
+    client = FakeA3Client(41.5, A3_GEOM_BODY, A3_BODIES)
+    install_mujoco_lookups(client)
+    cwd = os.getcwd()
+    os.chdir(REF)                                        # walking_task.py:42 opens a CWD-relative file
+    WT = ns.walking_task.WalkingTask
+    A3 = ns.a3.StickFigureA3
+    E = 48
+    rec = dict(lfoot=np.zeros((E, 3)), rfoot=np.zeros((E, 3)), root_quat=np.zeros((E, 4)), iter_count=np.zeros(E, np.int64),
+               qpos=np.zeros((E, 25)), qvel=np.zeros((E, 24)), act_len=np.zeros((E, 12)), act_vel=np.zeros((E, 12)),
+               mode=np.zeros(E, np.int32), phase=np.zeros(E, np.int32), seq_len=np.zeros(E, np.int32),
+               local_sequence=np.zeros((E, 20, 4)), sequence=np.zeros((E, 20, 4)), t1=np.zeros(E, np.int32),
+               t2=np.zeros(E, np.int32), obs=np.zeros((E, 41)), seed=np.zeros(E, np.int64))
+    for e in range(E):
+        task = WT(client=client, dt=0.025, neutral_foot_orient=np.array([1, 0, 0, 0]), root_body="torso",
+                  lfoot_body="left_foot", rfoot_body="right_foot", head_body="head")
+        task._goal_height_ref, task._total_duration = 0.80, 1.1
+        task._swing_duration, task._stance_duration = 0.75, 0.35
+        base = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), 0.0])
+        rq = quat_from_rpy(rng.normal(0, 0.3), rng.normal(0, 0.3), rng.uniform(-np.pi, np.pi)) * rng.choice([-1.0, 1.0])
+        client.state = {"xpos_left_foot": base + [rng.normal(0, 0.05), 0.1, 0.03],
+                        "xpos_right_foot": base + [rng.normal(0, 0.05), -0.1, 0.02], "xquat_torso": rq}
+        captured = {}
+        orig = task.generate_step_sequence
+
+        def capture(orig=orig, captured=captured, **kw):
+            out = orig(**kw)
+            captured["local"] = np.array(out)
+            return out
+        task.generate_step_sequence = capture
+        seed = 2000 + e
+        np.random.seed(seed)
+        it = int(rng.choice([0, 4000, 9000, 20000]))
+        task.reset(iter_count=it)
+        env = A3.__new__(A3)
+        env._algorithm_type = AlgorithmType.REINFORCEMENT_LEARNING
+        env.task, env.actuators, env.base_obs_len = task, list(range(12)), 41
+        qpos = np.concatenate([rng.normal(0, 1, 3), quat_from_rpy(rng.normal(0, 0.4), rng.normal(0, 0.4), rng.uniform(-3, 3)),
+                               rng.uniform(-1, 1, 18)])
+        qvel, alen, avel = rng.normal(0, 1, 24), rng.uniform(-1, 1, 12), rng.normal(0, 2, 12)
+        env.interface = types.SimpleNamespace(get_qpos=lambda qpos=qpos: qpos, get_qvel=lambda qvel=qvel: qvel,
+                                              get_act_joint_positions=lambda alen=alen: list(alen),
+                                              get_act_joint_velocities=lambda avel=avel: list(avel))
+        obs = env.get_obs()
+        n = len(task.sequence)
+        rec["lfoot"][e], rec["rfoot"][e] = client.state["xpos_left_foot"], client.state["xpos_right_foot"]
+        rec["root_quat"][e], rec["iter_count"][e], rec["seed"][e] = rq, it, seed
+        rec["qpos"][e], rec["qvel"][e], rec["act_len"][e], rec["act_vel"][e] = qpos, qvel, alen, avel
+        rec["mode"][e], rec["phase"][e], rec["seq_len"][e] = task.mode.value, task._phase, n
+        rec["local_sequence"][e, :n] = captured["local"]
+        rec["sequence"][e, :n] = np.array(task.sequence)
+        rec["t1"][e], rec["t2"][e], rec["obs"][e] = task.t1, task.t2, obs
+    os.chdir(cwd)
+    print("a3_reset: modes", np.bincount(rec["mode"]), "phases", np.unique(rec["phase"]))
+    save("a3_reset.npz", **rec)
+
+
 # --------------------------------------------------------------- G7 symmetry
 def gen_symmetry():
     base_mir_obs = [0.1, -1, 2, -3, -4, 5, -6, 13, -14, -15, 16, -17, 18, 7, -8, -9, 10, -11, 12,
@@ -933,7 +999,7 @@ def gen_il_robot(cls_name, mod, xml, defaults):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd", "robots", "norm", "ppo64"]
+    which = sys.argv[1:] or ["tables", "h1", "ppo", "stats", "traj", "contacts", "a3", "sym", "vail", "ppoupd", "robots", "norm", "ppo64", "a3reset"]
     tab = gen_h1_tables() if any(w in which for w in ("tables", "h1", "traj")) else None
     if "h1" in which:
         gen_h1_step(tab)
@@ -951,6 +1017,8 @@ if __name__ == "__main__":
         gen_contacts()
     if "a3" in which:
         gen_a3_task()
+    if "a3reset" in which:
+        gen_a3_reset()
     if "sym" in which:
         gen_symmetry()
     if "vail" in which:

@@ -117,3 +117,45 @@ def check_a3_analytic(obs, goal, c):
         dth = np.arctan2(np.sin(goal[:, 6 + i] - rel), np.cos(goal[:, 6 + i] - rel))
         np.testing.assert_allclose(dth, 0, atol=1e-12)
     assert np.array_equal(obs[:, 41 - 8:], goal)
+
+
+def a3_reset_fixture_rollout(g, spec):
+    """The a3_reset.npz fixture as the inputs of one RESET_ALL vec step: K = 1 readback row holding the
+    fixture's foot / root poses and joint state, one pool record per environment = the captured draws."""
+    from olympic_hip import _abi
+    from olympic_hip.vecstep import REC
+    E = len(g["mode"])
+    z = lambda *s: np.zeros((1, E) + s)
+    blocks = dict(qpos=g["qpos"][None].copy(), qvel=g["qvel"][None].copy(), act_len=g["act_len"][None].copy(),
+                  act_vel=g["act_vel"][None].copy(), lf_pos=g["lfoot"][None].copy(), rf_pos=g["rfoot"][None].copy(),
+                  lf_vel=z(3), rf_vel=z(3), root_pos=z(3), root_quat=g["root_quat"][None].copy(), head_pos=z(3),
+                  ncon=np.zeros((1, E), np.int32), geom1=np.zeros((1, E, 16), np.int32),
+                  geom2=np.zeros((1, E, 16), np.int32), force6=z(16, 6), cpos_z=z(16))
+    blocks = {k: np.ascontiguousarray(v) for k, v in blocks.items()}
+    pool = np.zeros(E, REC)
+    pool["mode"], pool["phase"], pool["seq_len"], pool["seq"] = g["mode"], g["phase"], g["seq_len"], g["local_sequence"]
+    zi = lambda dt, *s: np.zeros((E,) + s, dt)
+    state = dict(phase=zi(np.int32), t1=zi(np.int32), t2=zi(np.int32), reached_frames=zi(np.int32),
+                 target_reached=zi(np.uint8), mode=np.full(E, _abi.MODE_STANDING, np.int32), seq_len=np.ones(E, np.int32),
+                 sequence=zi(np.float64, _abi.OLY_MAX_SEQ, 4), goal=np.ones((E, 8)))
+    nobs, nu, T, slots = spec.n_obs, spec.nu, 2, 2
+    ro = dict(T=T, max_traj_len=10, deterministic=True, side_slots=slots, pool_depth=1, mu=zi(np.float32, nu),
+              value=zi(np.float32), scale=None, eps=None, state=zi(np.float32, nobs), pd_target=zi(np.float64, nu),
+              buf_states=np.zeros((T, E, nobs), np.float32), buf_actions=np.zeros((T, E, nu), np.float32),
+              buf_rewards=np.zeros((T, E)), buf_values=np.zeros((T, E), np.float32), buf_flags=np.zeros((T, E), np.uint8),
+              buf_rew6=None, traj_len=zi(np.int32), side_obs=np.zeros((E * slots, nobs), np.float32),
+              side_t=np.full(E * slots, -1, np.int32), side_count=zi(np.int32),
+              pool=pool.view(np.uint8).reshape(-1).copy(), pool_count=zi(np.int32), ctr=np.zeros(2, np.int32))
+    return blocks, state, ro
+
+
+def check_a3_reset_fixture(g, state, next_obs):
+    """State and first observation after the reset against the reference's (a3_reset.npz)."""
+    for k in ("mode", "phase", "seq_len", "t1", "t2"):
+        assert np.array_equal(state[k], g[k]), k
+    assert not state["reached_frames"].any() and not state["target_reached"].any() and not state["goal"].any()
+    # transform_sequence: cos / sin / atan2 of the root yaw through libm vs numpy: 1e-12
+    np.testing.assert_allclose(state["sequence"], g["sequence"], rtol=1e-12, atol=1e-13)
+    want = g["obs"].astype(np.float32)
+    assert np.abs(next_obs - want).max() <= np.spacing(np.float32(1.0)) * max(1.0, np.abs(want).max())
+    assert not next_obs[:, -8:].any() and not g["obs"][:, -8:].any()          # goal steps zero after reset

@@ -117,6 +117,33 @@ def test_vec_step_vs_oracle(eng, golden, oracle, N, T, max_len, det):
     assert cut_not_done.sum() == (ro["side_t"] >= 0).sum()       # one bootstrap row per non-terminal cut
 
 
+def test_vec_step_reset_matches_reference_reset(eng, golden):
+    """The device-side env.reset() (OLY_VSTEP_RESET_ALL) on the reference-generated a3_reset fixture: same
+    checks as the oracle's (test_oracle_golden.py), through the kernel; and the host path of the facade
+    (reset_task + _get_obs) on the same fixture."""
+    from helpers import a3_reset_fixture_rollout, check_a3_reset_fixture
+    g = golden("a3_reset.npz")
+    spec = specs.A3Spec(mass=41.5)
+    blocks, state, ro = a3_reset_fixture_rollout(g, spec)
+    d_blocks, d_state, d_ro = _to_device(eng, blocks, state, ro)
+    eng.a3_vec_prepare(d_blocks, d_state, d_ro)(_abi.VSTEP_RESET_ALL)
+    check_a3_reset_fixture(g, {k: v.cpu().numpy() for k, v in d_state.items()}, d_ro["state"].cpu().numpy())
+    # host path: WalkingTaskReset with the fixture's seeds + the facade's reset observation
+    from olympic_hip.a3 import AlgorithmType, ReplayA3Physics, StickFigureA3
+    keys = ("qpos", "qvel", "act_len", "act_vel", "lf_pos", "rf_pos", "lf_vel", "rf_vel", "root_pos", "root_quat",
+            "head_pos", "ncon", "geom1", "geom2", "force6", "cpos_z")
+    for e in (0, 5, 17, 40):
+        one = {k: d_blocks[k][:, e:e + 1].contiguous() for k in keys}
+        env = StickFigureA3(algorithm_type=AlgorithmType.REINFORCEMENT_LEARNING, physics=ReplayA3Physics(one, mass=41.5))
+        env.vec.iteration_count = int(g["iter_count"][e])
+        np.random.seed(int(g["seed"][e]))
+        env.vec.reset_task([0], g["lfoot"][e:e + 1], g["rfoot"][e:e + 1], g["root_quat"][e:e + 1])
+        st = {k: v.cpu().numpy() for k, v in env.vec.state.items()}
+        assert int(st["mode"][0]) == int(g["mode"][e]) and int(st["phase"][0]) == int(g["phase"][e])
+        np.testing.assert_allclose(st["sequence"][0], g["sequence"][e], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(env._get_obs(), g["obs"][e], rtol=1e-11, atol=1e-12)     # float64 facade
+
+
 def test_vec_step_more_than_sixteen_contact_slots(eng, golden, oracle):
     """C = 20 contact slots per environment: the second 16-slot pass loads on demand; still the oracle's
     numbers (contact counts and force sums cross the pass boundary)."""

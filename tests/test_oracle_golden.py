@@ -532,3 +532,19 @@ def test_vec_step_replays_the_reference_sequence(golden, oracle):
         assert np.array_equal(ro["state"][done][:, nobs - 10:nobs - 8], np.tile(np.float32([0, 1]), (done.sum(), 1)))
     assert g["done"][:, :K - 1].sum() > 100 and (~g["done"][:, :K - 1]).sum() > 100
     assert ro["ctr"].tolist() == [K - 1, K - 1] and ro["pool_count"].sum() == g["done"][:, :K - 1].sum()
+
+
+def test_vec_step_reset_matches_reference_reset(golden, oracle):
+    """env.reset() inside the vec step (OLY_VSTEP_RESET_ALL) on the reference-generated a3_reset fixture:
+    WalkingTask.reset's transform_sequence (mid point of the feet, root yaw incl. rolled / pitched roots),
+    t1 / t2 after update_target_steps, and get_obs of the un-advanced task (goal steps zero, clock of the
+    drawn phase), from the local step sequence captured inside the reference's reset."""
+    from helpers import a3_reset_fixture_rollout, check_a3_reset_fixture
+    g = golden("a3_reset.npz")
+    spec = specs.A3Spec(mass=41.5)
+    blocks, state, ro = a3_reset_fixture_rollout(g, spec)
+    lut = golden("a3_task.npz")["clock_lut"]
+    oracle.a3_vec_step(spec, lut, (np.arange(13, dtype=np.int32), 0, 7, 10), blocks, state, ro, _abi.VSTEP_RESET_ALL)
+    check_a3_reset_fixture(g, state, ro["state"])
+    assert (ro["pool_count"] == 1).all() and ro["ctr"].tolist() == [0, 0]
+    assert set(np.unique(g["mode"])) == {_abi.MODE_STANDING, _abi.MODE_FORWARD} and set(np.unique(g["phase"])) == {0, 44}
