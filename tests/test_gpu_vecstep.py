@@ -332,3 +332,37 @@ def test_fused_mlp_identity_with_asymmetric_weights(eng):
     xp = torch.zeros(77, 256, device="cuda")
     xp[:, :41] = x
     assert torch.equal(mu, xp @ pi.means.weight.t()) and torch.equal(val, (xp @ vf.network_out.weight.t()).reshape(-1))
+
+
+def test_device_rollout_full_size_properties(oracle):
+    """Config 3 at full size (4096 environments x 400 steps, time limit 100): size-independent properties
+    of the buffer the device rollout fills, and its hand-over to K6 (the return scan of the buffer equals
+    the oracle's scan of the same arrays, bit for bit, with the float64 rewards)."""
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    from olympic_hip.rollout import PPORollout
+    N, T, max_len = 4096, 400, 100
+    torch.manual_seed(1)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    env = _make_env(N, 32, seed=7, p_bad=1.0 / 300)
+    buf = env.device_rollout(pi, vf, T, max_len, graph=True)
+    info = env._dev_rollout.last_info
+    last = (buf.flags & _abi.FLAG_LAST).bool()
+    absorbing = (buf.flags & _abi.FLAG_ABSORBING).bool()
+    assert bool(last[-1].all()) and not bool((absorbing & ~last).any())
+    # no episode segment is longer than the time limit: every window of max_len steps holds a cut
+    run = torch.zeros(N, dtype=torch.int32, device="cuda")
+    longest = torch.zeros(N, dtype=torch.int32, device="cuda")
+    for t in range(T):
+        run = torch.where(last[t], torch.zeros_like(run), run + 1)
+        longest = torch.maximum(longest, run)
+    assert int(longest.max()) <= max_len - 1
+    assert info["resets"] == N + int(last[:-1].sum()) and info["side_rows"] == int((last & ~absorbing).sum())
+    r = buf.rewards
+    assert r.dtype == torch.float64 and bool(torch.isfinite(r).all()) and float(r.min()) >= -0.3 - 1e-9 and float(r.max()) <= 1.0 + 1e-9
+    assert torch.equal(buf.next_values[:-1][~last[:-1]], buf.values[1:][~last[:-1]])
+    assert bool(torch.isfinite(buf.states).all()) and bool((buf.states[:, :, :4].norm(dim=-1) - 1).abs().max() < 1e-5)   # unit quaternion
+    ret, adv = PPORollout(env.eng, gamma=0.99, eps=1e-5).finish(buf, normalize=False)
+    sl = slice(100, 164)
+    e_ret, e_adv = oracle.return_scan_r64(0.99, buf.rewards[:, sl].cpu().numpy(), buf.values[:, sl].cpu().numpy(),
+                                          buf.next_values[:, sl].cpu().numpy(), buf.flags[:, sl].cpu().numpy())
+    assert np.array_equal(ret[:, sl].cpu().numpy(), e_ret) and np.array_equal(adv[:, sl].cpu().numpy(), e_adv)
