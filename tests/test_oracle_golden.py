@@ -171,6 +171,33 @@ def test_gae_matches_restated_mushroom(oracle):
         assert np.array_equal(ret[:, n], e_ret[:, 0])
 
 
+def test_gae_equals_its_definition(oracle):
+    """Independent of the recursion: A_t = sum_l (gamma*lam)^l delta_{t+l} over the rest of the segment,
+    delta_k = r_k + gamma*(1 - absorbing_k)*v_next_k - v_k (Schulman et al. 2016, eq. 16; the segment ends
+    at the first `last` flag or with the buffer), evaluated in float64."""
+    rng = np.random.default_rng(5)
+    T, N, gamma, lam = 120, 6, 0.99, 0.97
+    r = rng.uniform(-0.3, 1, (T, N)).astype(np.float32)
+    v = rng.normal(0, 1, (T, N)).astype(np.float32)
+    vn = rng.normal(0, 1, (T, N)).astype(np.float32)
+    last = rng.uniform(size=(T, N)) < 0.05
+    absorbing = last & (rng.uniform(size=(T, N)) < 0.5)
+    flags = (last * _abi.FLAG_LAST + absorbing * _abi.FLAG_ABSORBING).astype(np.uint8)
+    ret, adv = oracle.return_scan(_abi.SCAN_GAE, gamma, lam, r, v, vn, flags)
+    delta = r.astype(np.float64) + gamma * np.where(absorbing, 0.0, vn.astype(np.float64)) - v
+    want = np.zeros((T, N))
+    for n in range(N):
+        for t in range(T):
+            k, w = t, 1.0
+            while True:
+                want[t, n] += w * delta[k, n]
+                if last[k, n] or k == T - 1:
+                    break
+                k, w = k + 1, w * gamma * lam
+    np.testing.assert_allclose(adv, want, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ret, want + v, rtol=0, atol=2e-5)
+
+
 def test_gae_hand_computed_toy(oracle):
     # 3 steps, no episode end inside, gamma=.5, lam=.5, v=0 everywhere, v_next=0:
     # adv2 = r2 = 4 ; adv1 = r1 + .25*adv2 = 3 ; adv0 = r0 + .25*adv1 = 1.75
@@ -548,3 +575,44 @@ def test_vec_step_reset_matches_reference_reset(golden, oracle):
     check_a3_reset_fixture(g, state, ro["state"])
     assert (ro["pool_count"] == 1).all() and ro["ctr"].tolist() == [0, 0]
     assert set(np.unique(g["mode"])) == {_abi.MODE_STANDING, _abi.MODE_FORWARD} and set(np.unique(g["phase"])) == {0, 44}
+
+
+def test_rotation_restatement_against_scipy(golden, oracle):
+    """transforms3d is absent, so the goldens ran the reference against tests/golden/_ref_stubs.py's
+    restatement of it (parity unpinned).  scipy's Rotation is an independent implementation of the same
+    conventions (extrinsic x-y-z = transforms3d 'sxyz', scalar-last quaternions): it has to agree with the
+    stubs, with the oracle's obs quaternion (quat2euler -> euler2quat with yaw dropped,
+    StickFigureA3.py:160-161) and with the host yaw used at reset (a3.yaw_of_quat)."""
+    import os
+    import sys
+    from scipy.spatial.transform import Rotation
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import _ref_stubs as rs
+    from olympic_hip.a3 import yaw_of_quat
+    rng = np.random.default_rng(21)
+    n = 400
+    rpy = np.stack([rng.uniform(-np.pi, np.pi, n), rng.uniform(-1.5, 1.5, n), rng.uniform(-np.pi, np.pi, n)], 1)
+    R = Rotation.from_euler("xyz", rpy)
+    xyzw = R.as_quat()
+    wxyz = np.concatenate([xyzw[:, 3:], xyzw[:, :3]], 1)
+    for i in range(n):
+        m = rs._euler2mat(*rpy[i])
+        np.testing.assert_allclose(m, R[i].as_matrix(), atol=1e-14)
+        np.testing.assert_allclose(rs._quat2mat(wxyz[i] * rng.uniform(0.5, 2.0)), R[i].as_matrix(), atol=1e-14)
+        q = rs._euler2quat(*rpy[i])
+        assert min(np.abs(q - wxyz[i]).max(), np.abs(q + wxyz[i]).max()) < 1e-14
+        np.testing.assert_allclose(rs._mat2euler(m), rpy[i], atol=1e-12)
+        np.testing.assert_allclose(rs._quat2euler(wxyz[i]), R[i].as_euler("xyz"), atol=1e-12)
+        assert abs(yaw_of_quat(wxyz[i]) - rpy[i, 2]) < 1e-12
+    # the oracle's obs[0:4]: the body quaternion with its yaw removed = scipy's (roll, pitch, 0)
+    c = a3_analytic_cases()
+    st = {k: v.copy() for k, v in c["state"].items()}
+    obs = oracle.a3_step(specs.A3Spec(mass=41.5), golden("a3_task.npz")["clock_lut"], c["inputs"], st)["obs"]
+    body = c["inputs"]["qpos"][:, 3:7]
+    e = Rotation.from_quat(np.concatenate([body[:, 1:], body[:, :1]], 1)).as_euler("xyz")
+    regular = np.abs(np.abs(e[:, 1]) - np.pi / 2) > 1e-6          # scipy warns / differs in the gimbal branch
+    flat = Rotation.from_euler("xyz", np.stack([e[:, 0], e[:, 1], np.zeros(len(e))], 1)).as_quat()
+    flat = np.concatenate([flat[:, 3:], flat[:, :3]], 1)
+    got = obs[:, :4].astype(np.float64)
+    err = np.minimum(np.abs(got - flat).max(1), np.abs(got + flat).max(1))
+    assert regular.sum() > 490 and err[regular].max() < 1e-6     # obs is float32
