@@ -132,8 +132,10 @@ class Ranks:
 
 
 def timed_region(rk, stream, warmup, steps, step):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides.
-    Returns (wall seconds, max over ranks; HIP-event ms per step on the kernels' stream)."""
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides.  The clock
+    starts after the common barrier and stops when this rank's device has drained; the maximum over ranks
+    (taken after the closing barrier) is the job's time, so the closing collective's own latency is not
+    billed to the K steps.  Returns (wall seconds, HIP-event ms per step on the kernels' stream)."""
     from olympic_hip._ffi import HipTimer
     torch = rk.torch
     for i in range(warmup):
@@ -146,8 +148,8 @@ def timed_region(rk, stream, warmup, steps, step):
         step(i)
     timer.stop(stream())
     torch.cuda.synchronize(rk.dev)
+    wall = time.perf_counter() - t0          # this rank's K steps are complete; the job's time is the slowest rank's
     rk.barrier()
-    wall = time.perf_counter() - t0
     return rk.max_over_ranks(wall), timer.elapsed_ms() / max(steps, 1)
 
 
