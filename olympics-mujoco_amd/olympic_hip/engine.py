@@ -395,16 +395,26 @@ class Engine:
                       ptr(in_mean), ptr(in_std), ptr(packed), self._s())
         return packed
 
+    def _mlp_floats(self, in_dim, out_dim):
+        key = (int(in_dim), int(out_dim))
+        cache = self.__dict__.setdefault("_mlp_sizes", {})
+        if key not in cache:
+            from ._ffi import lib
+            cache[key] = int(lib().oly_mlp_packed_floats(key[0], 256, key[1]))
+        return cache[key]
+
     def mlp_forward2(self, x, packed_a, out_a, y_a, packed_b=None, out_b=0, y_b=None, normalize_a=False,
                      normalize_b=False):
         """y_a = net_a(x) and (optionally) y_b = net_b(x) in one launch; x [N,in] f32."""
         N, in_dim = (int(v) for v in x.shape)
         f32, dv = torch.float32, self.device
         _req(x, "x", (N, in_dim), f32, dv)
-        _req(packed_a, "packed_a", packed_a.shape, f32, dv)
+        # the kernel derives every offset inside a packed stream from (in_dim, out): a stream packed for
+        # another shape must be refused here, not read out of bounds there
+        _req(packed_a, "packed_a", (self._mlp_floats(in_dim, out_a),), f32, dv)
         _req(y_a, "y_a", (N, int(out_a)), f32, dv)
         if packed_b is not None:
-            _req(packed_b, "packed_b", packed_b.shape, f32, dv)
+            _req(packed_b, "packed_b", (self._mlp_floats(in_dim, out_b),), f32, dv)
             _req(y_b, "y_b", (N, int(out_b)), f32, dv)
         self.ctx.call("oly_mlp_forward2", N, in_dim, ptr(x), ptr(packed_a), int(out_a), int(bool(normalize_a)), ptr(y_a),
                       ptr(packed_b), int(out_b), int(bool(normalize_b)), ptr(y_b), self._s())

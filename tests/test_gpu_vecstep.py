@@ -366,3 +366,39 @@ def test_device_rollout_full_size_properties(oracle):
     e_ret, e_adv = oracle.return_scan_r64(0.99, buf.rewards[:, sl].cpu().numpy(), buf.values[:, sl].cpu().numpy(),
                                           buf.next_values[:, sl].cpu().numpy(), buf.flags[:, sl].cpu().numpy())
     assert np.array_equal(ret[:, sl].cpu().numpy(), e_ret) and np.array_equal(adv[:, sl].cpu().numpy(), e_adv)
+
+
+def test_vec_step_and_mlp_argument_errors(eng, golden):
+    """Error behaviour at the boundary: wrong shapes / dtypes are refused before anything is launched,
+    an unconfigured context says what is missing, unsupported MLP shapes are OLY_ERANGE."""
+    from olympic_hip.engine import Engine, OlyError
+    spec = specs.A3Spec(mass=41.5)
+    blocks, state, ro, _ = _host_rollout(spec, 40, 2, 3, 2, 2, seed=1)
+    d_blocks, d_state, d_ro = _to_device(eng, blocks, state, ro)
+    eng.a3_vec_prepare(d_blocks, d_state, d_ro)                       # the well-formed case is accepted
+    bad = dict(d_ro, buf_rewards=d_ro["buf_rewards"].float())         # rewards travel as float64
+    with pytest.raises(OlyError, match="buf_rewards"):
+        eng.a3_vec_prepare(d_blocks, d_state, bad)
+    bad = dict(d_ro, ctr=d_ro["ctr"][:-2].clone())                    # one counter pair per workgroup
+    with pytest.raises(OlyError, match="ctr"):
+        eng.a3_vec_prepare(d_blocks, d_state, bad)
+    bad = dict(d_ro, eps=None)                                        # stochastic rollout needs its noise
+    with pytest.raises(OlyError, match="eps"):
+        eng.a3_vec_prepare(d_blocks, d_state, bad)
+    bad = dict(d_blocks, geom2=d_blocks["geom2"][:, :, :-1].contiguous())
+    with pytest.raises(OlyError, match="geom2"):
+        eng.a3_vec_prepare(bad, d_state, d_ro)
+    fresh = Engine(0)
+    with pytest.raises(OlyError, match="before a3_configure"):
+        fresh.a3_vec_prepare(d_blocks, d_state, d_ro)
+    fresh.a3_configure(spec, golden("a3_task.npz")["clock_lut"])
+    with pytest.raises(OlyError, match="contact_configure"):
+        fresh.a3_vec_prepare(d_blocks, d_state, d_ro)
+    z = lambda *s: torch.zeros(s, device="cuda")
+    with pytest.raises(OlyError, match="unsupported MLP shape"):
+        eng.mlp_pack(z(128, 41), z(128), z(128, 128), z(128), z(12, 128), z(12))       # hidden must be 256
+    with pytest.raises(OlyError, match="unsupported MLP shape"):
+        eng.mlp_pack(z(256, 80), z(256), z(256, 256), z(256), z(12, 256), z(12))       # in_dim > 64
+    pk = eng.mlp_pack(z(256, 41), z(256), z(256, 256), z(256), z(12, 256), z(12))
+    with pytest.raises(OlyError, match="packed_a"):
+        eng.mlp_forward2(z(8, 40), pk, 12, z(8, 12))                                     # packed for in_dim 41
