@@ -98,7 +98,8 @@ class Ranks:
         self.dist = None
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
-        if self.world > 1:
+        # under torchrun a process group is always formed (a one-rank launch exercises the same RCCL calls)
+        if self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if args.backend == "nccl":

@@ -27,9 +27,9 @@ def gather_stats(stats3):
     of 24 bytes per rank, RCCL over xGMI with backend "nccl".  The consumer (oly_adv_normalize_parts)
     adds the triples by a balanced pairwise tree in rank order on the device, so no host arithmetic
     sits between the collective and the normalisation."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not is_dist():
         return stats3.reshape(1, 3)
-    world = dist.get_world_size()
+    world = dist.get_world_size()          # a one-rank group still goes through the collective
     if dist.get_backend() == "gloo" and stats3.is_cuda:          # rehearsal backend: bounce through the host
         host = stats3.detach().cpu().contiguous()
         out = torch.empty(world * 3, dtype=torch.float64)
@@ -66,7 +66,7 @@ def mean_std_from_stats(stats3, ddof):
 def broadcast_parameters(modules, src=0):
     """One learner replicated on every rank: copy rank `src`'s parameters and buffers to all ranks
     (the reference has ONE policy / critic that every ray worker receives, rl/algos/ppo.py:200-207)."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not is_dist():
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
@@ -77,7 +77,7 @@ def allreduce_gradients(params):
     """Mean of the gradients over ranks in ONE fused all-reduce (policy + critic ~ 160 k floats = 0.6 MB:
     latency-bound on xGMI, so a single flat buffer).  With equal shard sizes the mean of the per-rank
     minibatch means is the gradient of the global minibatch the reference's single learner would see."""
-    if not is_dist() or dist.get_world_size() == 1:
+    if not is_dist():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:

@@ -69,3 +69,33 @@ def test_bench_fails_loudly_when_a_rank_fails():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device",
                           "--config", "5", "--steps", "2"], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0                        # --share-device without gloo is refused before any GPU work
+
+
+def _torchrun_one_rank(script_args, timeout=600):
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), *script_args],
+                          capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_rccl_collectives_with_one_rank():
+    """The box has one GPU, so RCCL cannot be run across ranks here; a ONE-rank "nccl" group still sends
+    every collective of the multi-GPU path through RCCL on the device (what the driver's N > 1 runs use)."""
+    out = _torchrun_one_rank([os.path.join(ROOT, "tests", "_rccl_one_rank_worker.py")])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["backend"] == "nccl" and line["world"] == 1
+    assert line["stats"][0][0] == 50 * 1024 and line["norm_err"] < 1e-5
+    assert line["grads_unchanged"] and line["max"] == 1.5
+
+
+@pytest.mark.parametrize("config", [2, 5])
+def test_bench_under_torchrun_uses_rccl(config):
+    """The driver's launch line with one rank: bench.py forms an "nccl" group (barrier with device_ids,
+    MAX over ranks, config 5's all-gather) and prints the contract's JSON line."""
+    out = _torchrun_one_rank([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", str(config), "--steps", "5",
+                              "--warmup", "2", "--T", "100", "--no-cpu-baseline", "--no-per-step"])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"].startswith("env-sharded x1")
