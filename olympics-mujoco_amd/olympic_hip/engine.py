@@ -409,8 +409,7 @@ class Engine:
         N, in_dim = (int(v) for v in x.shape)
         f32, dv = torch.float32, self.device
         _req(x, "x", (N, in_dim), f32, dv)
-        # the kernel derives every offset inside a packed stream from (in_dim, out): a stream packed for
-        # another shape must be refused here, not read out of bounds there
+        # the raw pointers carry no length: a buffer that is not a whole packed stream is refused here
         _req(packed_a, "packed_a", (self._mlp_floats(in_dim, out_a),), f32, dv)
         _req(y_a, "y_a", (N, int(out_a)), f32, dv)
         if packed_b is not None:
