@@ -17,6 +17,75 @@
 
 #include "oly_common.h"
 
+// Persistent worker pool shared by both batchers.  A vec step is short (tens of microseconds of GPU work
+// between two physics phases), so a condition-variable wake of every worker per step costs as much as the
+// physics stand-in itself: workers therefore poll the generation counter for a bounded time after each
+// job (they are still hot when the next step arrives) and only then block; the caller polls the pending
+// counter the same way.  Long gaps (the policy update) put the workers to sleep.
+struct WorkerPool {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_go;
+  std::atomic<long> generation{0};
+  std::atomic<int> pending{0};
+  std::atomic<int> sleepers{0};
+  std::atomic<bool> stop{false};
+  static constexpr int kSpinUs = 200;
+
+  static double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+  static void relax() { __builtin_ia32_pause(); }
+
+  template <class Job>
+  void start(int n, Job job) {
+    for (int id = 0; id < n; ++id)
+      threads.emplace_back([this, job, id] {
+        long seen = 0;
+        for (;;) {
+          const double t0 = now();
+          int polls = 0;
+          while (generation.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_acquire)) {
+            relax();
+            if ((++polls & 63) == 0 && (now() - t0) * 1e6 > kSpinUs) {
+              std::unique_lock<std::mutex> lk(mu);
+              sleepers.fetch_add(1);
+              cv_go.wait(lk, [&] { return stop.load() || generation.load() != seen; });
+              sleepers.fetch_sub(1);
+            }
+          }
+          if (stop.load(std::memory_order_acquire)) return;
+          seen = generation.load(std::memory_order_acquire);
+          job(id);
+          pending.fetch_sub(1, std::memory_order_release);
+        }
+      });
+  }
+  // run one job on every worker and wait for all of them
+  void run() {
+    pending.store((int)threads.size(), std::memory_order_relaxed);
+    generation.fetch_add(1);                       // seq_cst: pairs with the sleeper's increment-then-check
+    if (sleepers.load() > 0) {
+      std::lock_guard<std::mutex> lk(mu);
+      cv_go.notify_all();
+    }
+    int polls = 0;
+    while (pending.load(std::memory_order_acquire) != 0) {
+      relax();
+      if ((++polls & 1023) == 0) std::this_thread::yield();
+    }
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop.store(true, std::memory_order_release);
+    }
+    cv_go.notify_all();
+    for (auto& t : threads) t.join();
+    threads.clear();
+  }
+};
+
 struct oly_batcher {
   oly_ctx* ctx;
   int N, nq, nv, nu, n_act, n_threads;
@@ -25,6 +94,10 @@ struct oly_batcher {
   void* user;
   double *h_qpos, *h_qvel, *h_ctrl;        // pinned host
   double *d_qpos, *d_qvel, *d_ctrl, *d_prev;  // device
+  // mapped mode: the kernels address the pinned staging directly (device aliases of h_*), so a step
+  // is two launches and one synchronise with no copy commands in between
+  int mapped;
+  double *m_qpos, *m_qvel, *m_ctrl;
   // use_foot_forces: W substep contact snapshots per env
   int W, C;
   oly_physics_contacts_fn cfn;
@@ -38,12 +111,7 @@ struct oly_batcher {
   double *h_grfw, *d_grfw;                 // pinned / device [W,N,n_grf]
   std::vector<std::vector<unsigned char>> scratch;   // one env's slot slab per worker thread
   // thread pool
-  std::vector<std::thread> workers;
-  std::mutex mu;
-  std::condition_variable cv_go, cv_done;
-  long generation;
-  int pending;
-  bool stop;
+  WorkerPool pool;
   double timing[3];
 };
 
@@ -128,22 +196,9 @@ void run_range(oly_batcher* b, int lo, int hi, int id) {
 }
 
 void worker_main(oly_batcher* b, int id) {
-  long seen = 0;
   const int per = (b->N + b->n_threads - 1) / b->n_threads;
   const int lo = id * per, hi = lo + per < b->N ? lo + per : b->N;
-  for (;;) {
-    {
-      std::unique_lock<std::mutex> lk(b->mu);
-      b->cv_go.wait(lk, [&] { return b->stop || b->generation != seen; });
-      if (b->stop) return;
-      seen = b->generation;
-    }
-    if (lo < hi) run_range(b, lo, hi, id);
-    {
-      std::lock_guard<std::mutex> lk(b->mu);
-      if (--b->pending == 0) b->cv_done.notify_one();
-    }
-  }
+  if (lo < hi) run_range(b, lo, hi, id);
 }
 
 double now_s() {
@@ -169,11 +224,11 @@ extern "C" int oly_batcher_create(oly_batcher** out, oly_ctx* ctx, int N, int n_
   if (n_threads == 0) n_threads = hw ? (int)hw : 1;
   if (n_threads > N) n_threads = N;
   b->n_threads = n_threads;
-  b->generation = 0; b->pending = 0; b->stop = false;
   b->h_qpos = b->h_qvel = b->h_ctrl = nullptr;
   b->d_qpos = b->d_qvel = b->d_ctrl = b->d_prev = nullptr;
   b->W = b->C = 0; b->cfn = nullptr; b->cuser = nullptr; b->h_con = b->d_con = nullptr; b->d_grf = nullptr;
   b->packed = 0; b->h_grfw = b->d_grfw = nullptr;
+  b->mapped = 0; b->m_qpos = b->m_qvel = b->m_ctrl = nullptr;
   const size_t sq = sizeof(double) * N * b->nq, sv = sizeof(double) * N * b->nv, sc = sizeof(double) * N * b->nu;
   bool ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_qpos), sq, hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc(reinterpret_cast<void**>(&b->h_qvel), sv, hipHostMallocDefault) == hipSuccess &&
@@ -188,19 +243,14 @@ extern "C" int oly_batcher_create(oly_batcher** out, oly_ctx* ctx, int N, int n_
   }
   memset(b->h_qpos, 0, sq); memset(b->h_qvel, 0, sv); memset(b->h_ctrl, 0, sc);
   (void)hipMemset(b->d_prev, 0, sizeof(double) * N);
-  for (int i = 0; i < n_threads; ++i) b->workers.emplace_back(worker_main, b, i);
+  b->pool.start(n_threads, [b](int id) { worker_main(b, id); });
   *out = b;
   return OLY_OK;
 }
 
 extern "C" void oly_batcher_destroy(oly_batcher* b) {
   if (!b) return;
-  {
-    std::lock_guard<std::mutex> lk(b->mu);
-    b->stop = true;
-  }
-  b->cv_go.notify_all();
-  for (auto& t : b->workers) t.join();
+  b->pool.shutdown();
   if (b->h_qpos) (void)hipHostFree(b->h_qpos);
   if (b->h_qvel) (void)hipHostFree(b->h_qvel);
   if (b->h_ctrl) (void)hipHostFree(b->h_ctrl);
@@ -265,6 +315,18 @@ extern "C" int oly_batcher_enable_contacts_packed(oly_batcher* b, int W, int C, 
   return OLY_OK;
 }
 
+extern "C" int oly_batcher_set_mapped(oly_batcher* b, int on) {
+  if (!b) return OLY_EINVAL;
+  oly_ctx* ctx = b->ctx;
+  if (on && !b->m_qpos) {
+    OLY_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&b->m_qpos), b->h_qpos, 0));
+    OLY_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&b->m_qvel), b->h_qvel, 0));
+    OLY_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&b->m_ctrl), b->h_ctrl, 0));
+  }
+  b->mapped = on & 3;   // bit 0: controls down, bit 1: state rows up
+  return OLY_OK;
+}
+
 extern "C" double* oly_batcher_qpos(oly_batcher* b) { return b ? b->h_qpos : nullptr; }
 extern "C" double* oly_batcher_qvel(oly_batcher* b) { return b ? b->h_qvel : nullptr; }
 extern "C" double* oly_batcher_prev(oly_batcher* b) { return b ? b->d_prev : nullptr; }
@@ -289,23 +351,20 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
   hipStream_t s = oly_s(stream);
   const double t0 = now_s();
   // (1) controls: device K5 -> pinned host, fp64 (what data.ctrl holds)
-  int rc = oly_il_ctrl(ctx, b->N, action, b->d_ctrl, OLY_OUT_CTRL_F64, stream);
+  int rc = oly_il_ctrl(ctx, b->N, action, (b->mapped & 1) ? b->m_ctrl : b->d_ctrl, OLY_OUT_CTRL_F64, stream);
   if (rc) return rc;
-  OLY_HIP(ctx, hipMemcpyAsync(b->h_ctrl, b->d_ctrl, sizeof(double) * b->N * b->nu, hipMemcpyDeviceToHost, s));
+  if (!(b->mapped & 1))
+    OLY_HIP(ctx, hipMemcpyAsync(b->h_ctrl, b->d_ctrl, sizeof(double) * b->N * b->nu, hipMemcpyDeviceToHost, s));
   OLY_HIP(ctx, hipStreamSynchronize(s));
   const double t1 = now_s();
   // (2) physics on the host threads
-  {
-    std::unique_lock<std::mutex> lk(b->mu);
-    b->pending = b->n_threads;
-    ++b->generation;
-    b->cv_go.notify_all();
-    b->cv_done.wait(lk, [&] { return b->pending == 0; });
-  }
+  b->pool.run();
   const double t2 = now_s();
   // (3) state rows up, post-physics path on the device
-  OLY_HIP(ctx, hipMemcpyAsync(b->d_qpos, b->h_qpos, sizeof(double) * b->N * b->nq, hipMemcpyHostToDevice, s));
-  OLY_HIP(ctx, hipMemcpyAsync(b->d_qvel, b->h_qvel, sizeof(double) * b->N * b->nv, hipMemcpyHostToDevice, s));
+  if (!(b->mapped & 2)) {
+    OLY_HIP(ctx, hipMemcpyAsync(b->d_qpos, b->h_qpos, sizeof(double) * b->N * b->nq, hipMemcpyHostToDevice, s));
+    OLY_HIP(ctx, hipMemcpyAsync(b->d_qvel, b->h_qvel, sizeof(double) * b->N * b->nv, hipMemcpyHostToDevice, s));
+  }
   const double* grf = nullptr;
   if (b->cfn && b->packed) {
     const size_t K = (size_t)ctx->il_host.n_grf;
@@ -324,7 +383,8 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
   } else if (ctx->il_host.n_grf > 0) {
     OLY_FAIL(ctx, OLY_ENOTCONF, "oly_batcher_step: the model has foot-force columns; call oly_batcher_enable_contacts");
   }
-  rc = oly_il_step(ctx, 1, b->N, b->d_qpos, b->d_qvel, nullptr, grf, b->d_prev, b->d_prev, obs, reward,
+  rc = oly_il_step(ctx, 1, b->N, (b->mapped & 2) ? b->m_qpos : b->d_qpos, (b->mapped & 2) ? b->m_qvel : b->d_qvel, nullptr, grf,
+                   b->d_prev, b->d_prev, obs, reward,
                    absorbing, fall_code, nullptr, out_flags & ~OLY_OUT_CTRL_F64, stream);
   const double t3 = now_s();
   b->timing[0] = t1 - t0; b->timing[1] = t2 - t1; b->timing[2] = t3 - t2;
@@ -344,16 +404,12 @@ struct oly_a3_batcher {
   size_t slab_bytes;
   size_t off[16];              // byte offsets of the 16 readback arrays inside the slab
   double *h_target, *d_target;  // [N,nu]
+  double* m_target;             // device alias of h_target (mapped mode: no D2H copy command)
   // K3 outputs (device)
   int32_t *d_nr, *d_nl;
   double *d_grf_r, *d_grf_l, *d_minz;
   uint8_t* d_bad;
-  std::vector<std::thread> workers;
-  std::mutex mu;
-  std::condition_variable cv_go, cv_done;
-  long generation;
-  int pending;
-  bool stop;
+  WorkerPool pool;
   double timing[3];
 };
 
@@ -375,25 +431,12 @@ void a3_slots(const oly_a3_batcher* b, unsigned char* base, int e, oly_a3_readba
 void a3_hold_state(int, const double*, const oly_a3_readback*, void*) {}
 
 void a3_worker(oly_a3_batcher* b, int id) {
-  long seen = 0;
   const int per = (b->N + b->n_threads - 1) / b->n_threads;
   const int lo = id * per, hi = lo + per < b->N ? lo + per : b->N;
-  for (;;) {
-    {
-      std::unique_lock<std::mutex> lk(b->mu);
-      b->cv_go.wait(lk, [&] { return b->stop || b->generation != seen; });
-      if (b->stop) return;
-      seen = b->generation;
-    }
-    for (int e = lo; e < hi; ++e) {
-      oly_a3_readback rb;
-      a3_slots(b, b->h_slab, e, &rb);
-      b->fn(e, b->h_target + (size_t)e * b->nu, &rb, b->user);
-    }
-    {
-      std::lock_guard<std::mutex> lk(b->mu);
-      if (--b->pending == 0) b->cv_done.notify_one();
-    }
+  for (int e = lo; e < hi; ++e) {
+    oly_a3_readback rb;
+    a3_slots(b, b->h_slab, e, &rb);
+    b->fn(e, b->h_target + (size_t)e * b->nu, &rb, b->user);
   }
 }
 
@@ -417,7 +460,6 @@ extern "C" int oly_a3_batcher_create(oly_a3_batcher** out, oly_ctx* ctx, int N, 
   if (n_threads == 0) n_threads = hw ? (int)hw : 1;
   if (n_threads > N) n_threads = N;
   b->n_threads = n_threads;
-  b->generation = 0; b->pending = 0; b->stop = false;
   const size_t w8[11] = {(size_t)h.nq, (size_t)h.nv, (size_t)h.nu, (size_t)h.nu, 3, 3, 3, 3, 3, 4, 3};
   size_t o = 0;
   auto put = [&](int k, size_t bytes) { b->off[k] = o; o = (o + bytes + 15) & ~(size_t)15; };
@@ -428,7 +470,7 @@ extern "C" int oly_a3_batcher_create(oly_a3_batcher** out, oly_ctx* ctx, int N, 
   put(A_F6, sizeof(double) * N * C * 6);
   put(A_CZ, sizeof(double) * N * C);
   b->slab_bytes = o;
-  b->h_slab = b->d_slab = nullptr; b->h_target = b->d_target = nullptr;
+  b->h_slab = b->d_slab = nullptr; b->h_target = b->d_target = nullptr; b->m_target = nullptr;
   b->d_nr = b->d_nl = nullptr; b->d_grf_r = b->d_grf_l = b->d_minz = nullptr; b->d_bad = nullptr;
   bool ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_slab), o, hipHostMallocDefault) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&b->d_slab), o) == hipSuccess &&
@@ -446,19 +488,14 @@ extern "C" int oly_a3_batcher_create(oly_a3_batcher** out, oly_ctx* ctx, int N, 
   }
   memset(b->h_slab, 0, o);
   memset(b->h_target, 0, sizeof(double) * N * h.nu);
-  for (int i = 0; i < n_threads; ++i) b->workers.emplace_back(a3_worker, b, i);
+  b->pool.start(n_threads, [b](int id) { a3_worker(b, id); });
   *out = b;
   return OLY_OK;
 }
 
 extern "C" void oly_a3_batcher_destroy(oly_a3_batcher* b) {
   if (!b) return;
-  {
-    std::lock_guard<std::mutex> lk(b->mu);
-    b->stop = true;
-  }
-  b->cv_go.notify_all();
-  for (auto& t : b->workers) t.join();
+  b->pool.shutdown();
   if (b->h_slab) (void)hipHostFree(b->h_slab);
   if (b->d_slab) (void)hipFree(b->d_slab);
   if (b->h_target) (void)hipHostFree(b->h_target);
@@ -480,6 +517,13 @@ extern "C" int oly_a3_batcher_upload(oly_a3_batcher* b, oly_stream stream) {
   return OLY_OK;
 }
 
+extern "C" int oly_a3_batcher_set_mapped(oly_a3_batcher* b, int on) {
+  if (!b) return OLY_EINVAL;
+  b->m_target = nullptr;
+  if (on & 1) OLY_HIP(b->ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&b->m_target), b->h_target, 0));
+  return OLY_OK;
+}
+
 extern "C" int oly_a3_batcher_last_timing(const oly_a3_batcher* b, double out3[3]) {
   if (!b || !out3) return OLY_EINVAL;
   for (int i = 0; i < 3; ++i) out3[i] = b->timing[i];
@@ -497,18 +541,13 @@ extern "C" int oly_a3_batcher_step(oly_a3_batcher* b, const float* action, const
   const double t0 = now_s();
   double t1 = t0, t2 = t0;
   if (with_physics) {
-    int rc = oly_a3_pd_target(ctx, b->N, action, b->d_target, stream);
+    int rc = oly_a3_pd_target(ctx, b->N, action, b->m_target ? b->m_target : b->d_target, stream);
     if (rc) return rc;
-    OLY_HIP(ctx, hipMemcpyAsync(b->h_target, b->d_target, sizeof(double) * b->N * b->nu, hipMemcpyDeviceToHost, s));
+    if (!b->m_target)
+      OLY_HIP(ctx, hipMemcpyAsync(b->h_target, b->d_target, sizeof(double) * b->N * b->nu, hipMemcpyDeviceToHost, s));
     OLY_HIP(ctx, hipStreamSynchronize(s));
     t1 = now_s();
-    {
-      std::unique_lock<std::mutex> lk(b->mu);
-      b->pending = b->n_threads;
-      ++b->generation;
-      b->cv_go.notify_all();
-      b->cv_done.wait(lk, [&] { return b->pending == 0; });
-    }
+    b->pool.run();
     t2 = now_s();
   }
   OLY_HIP(ctx, hipMemcpyAsync(b->d_slab, b->h_slab, b->slab_bytes, hipMemcpyHostToDevice, s));

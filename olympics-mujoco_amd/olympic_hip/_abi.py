@@ -131,6 +131,7 @@ SIGNATURES = {
     "oly_batcher_set_prev": (C.c_int, [vp, vp, vp]),
     "oly_batcher_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "oly_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "oly_batcher_set_mapped": (C.c_int, [vp, C.c_int]),
     "oly_batcher_enable_contacts": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "oly_batcher_enable_contacts_packed": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "oly_il_grf_window": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
@@ -140,6 +141,7 @@ SIGNATURES = {
     "oly_a3_batcher_upload": (C.c_int, [vp, vp]),
     "oly_a3_batcher_step": (C.c_int, [vp, vp, C.POINTER(A3State), vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "oly_a3_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "oly_a3_batcher_set_mapped": (C.c_int, [vp, C.c_int]),
     "oly_traj_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "oly_traj_reset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "oly_traj_next": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),

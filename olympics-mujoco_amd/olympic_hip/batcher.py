@@ -44,6 +44,16 @@ class HostBatcher:
         self.absorbing = torch.empty(self.N, dtype=torch.uint8, device=dev)
         self.fall_code = torch.empty(self.N, dtype=torch.uint8, device=dev)
 
+    def set_mapped(self, on=True):
+        """Let the kernels address the pinned staging directly instead of issuing copy commands
+        (oly_batcher_set_mapped).  True: controls always, state rows when a step moves less than 4 MB of
+        them (beyond that the copy engine is faster than the kernel's own PCIe reads); False: copies; an int
+        is passed through as the bit mask (1 controls, 2 state rows)."""
+        if on is True:
+            on = 1 | (2 if self.N * (self.spec.nq + self.spec.nv) * 8 <= (4 << 20) else 0)
+        check(self.eng.ctx.handle, lib().oly_batcher_set_mapped(self._h, int(on)), "oly_batcher_set_mapped")
+        return self
+
     def enable_contacts(self, n_intermediate, max_contacts, physics, packed=False):
         """packed=True: the worker threads reduce each environment's contact slots to the first-contact
         force of every sensor pair on the host (oly_batcher_enable_contacts_packed): same observations,
@@ -149,6 +159,11 @@ class A3HostBatcher:
         self.rew6 = torch.empty((self.N, 6), dtype=torch.float32, device=dev)
         self.reward = torch.empty(self.N, dtype=torch.float32, device=dev)
         self.done = torch.empty(self.N, dtype=torch.uint8, device=dev)
+
+    def set_mapped(self, on=True):
+        """PD targets are stored straight into the pinned host rows (no D2H copy command)."""
+        check(self.eng.ctx.handle, lib().oly_a3_batcher_set_mapped(self._h, int(on)), "oly_a3_batcher_set_mapped")
+        return self
 
     def slots(self, env):
         """numpy views of env's pinned staging rows (write a reset state here, then upload())."""

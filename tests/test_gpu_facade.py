@@ -348,14 +348,15 @@ def test_gail_fit_reward_and_advantage_pipeline(golden, oracle):
 
 
 # ----------------------------------------------------------------- next row f1: host batcher
-def test_host_batcher_kinematic_and_callback(oracle):
+@pytest.mark.parametrize("mapped", [False, True], ids=["copies", "mapped"])
+def test_host_batcher_kinematic_and_callback(oracle, mapped):
     from olympic_hip.batcher import HostBatcher
     from olympic_hip.engine import Engine
     sp = specs.unitree_h1("walk")
     eng = Engine(0).il_configure(sp)
     N = 777
     qpos, qvel, act = h1_synthetic_block(sp, 3, N, seed=31, fall_frac="wide")
-    b = HostBatcher(eng, N, n_threads=4, dt=0.01, obs_f64=True)
+    b = HostBatcher(eng, N, n_threads=4, dt=0.01, obs_f64=True).set_mapped(mapped)
     b.qpos[:], b.qvel[:] = qpos[0], qvel[0]
     prev = np.linspace(0.5, 2.0, N)
     b.set_prev(prev)
@@ -378,7 +379,7 @@ def test_host_batcher_kinematic_and_callback(oracle):
     def phys(env, ctrl, qp, qv):
         seen[env] = ctrl.copy()
         qp[2] = -1.0                                           # pelvis height out of range: fallen
-    b2 = HostBatcher(eng, 5, n_threads=2, physics=phys)
+    b2 = HostBatcher(eng, 5, n_threads=2, physics=phys).set_mapped(mapped)
     a = torch.as_tensor(act[0][:5]).cuda()
     obs, rew, ab = b2.step(a)
     torch.cuda.synchronize()
@@ -665,7 +666,8 @@ def test_examples_run(tmp_path):
     assert r.returncode == 0 and "discriminator reward mean" in r.stdout and " std 1.0000" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
-def test_a3_host_batcher_replays_golden_sequence(golden):
+@pytest.mark.parametrize("mapped", [False, True], ids=["copies", "mapped"])
+def test_a3_host_batcher_replays_golden_sequence(golden, mapped):
     """oly_a3_batcher_*: host thread pool + pinned staging + one H2D copy + K3 + K2 per step.  A
     Python physics callback plays the fixture's recorded readback (what a MuJoCo callback would
     write after its PD substeps) and checks the PD targets it receives; results equal the
@@ -694,7 +696,7 @@ def test_a3_host_batcher_replays_golden_sequence(golden):
                   "head_pos", "geom1", "geom2", "force6", "cpos_z"):
             slots[n][...] = g[n][e, k]
         slots["ncon"][0] = g["ncon"][e, k]
-    b = A3HostBatcher(eng, E, C_, physics, n_threads=2, obs_f64=True)
+    b = A3HostBatcher(eng, E, C_, physics, n_threads=2, obs_f64=True).set_mapped(mapped)
     act = torch.zeros((E, 12), device="cuda")
     for k in range(K):
         step_no["k"] = k

@@ -21,10 +21,11 @@ def main():
     sp = specs.unitree_h1("walk")
     eng = Engine(0).il_configure(sp)
     out = {}
-    for N in (4096, 32768):
-        for th in (1, 16):
+    for N, th, mapped in ((4096, 1, 0), (4096, 16, 0), (32768, 1, 0), (32768, 16, 0), (4096, 16, 1), (4096, 16, 2), (4096, 16, 3),
+                          (32768, 16, 1), (32768, 16, 3)):
+        if True:
             qpos, qvel, act = h1_synthetic_block(sp, 1, N, seed=1)
-            b = HostBatcher(eng, N, n_threads=th, dt=0.01)
+            b = HostBatcher(eng, N, n_threads=th, dt=0.01).set_mapped(int(mapped))
             b.qpos[:], b.qvel[:] = qpos[0], qvel[0]
             a = torch.as_tensor(act[0]).cuda()
             for _ in range(20):
@@ -39,7 +40,7 @@ def main():
                     acc[k] += v
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            out[f"N{N}_threads{th}"] = dict(us_per_vec_step=dt / K * 1e6, env_steps_per_s=N * K / dt,
+            out[f"N{N}_threads{th}" + (f"_mapped{mapped}" if mapped else "")] = dict(us_per_vec_step=dt / K * 1e6, env_steps_per_s=N * K / dt,
                                             split_us={k: v / K * 1e6 for k, v in acc.items()},
                                             pcie_bytes_per_step=N * (8 * 11 + 8 * 34))
             b.close()
@@ -49,8 +50,8 @@ def main():
     a3 = specs.A3Spec(mass=41.5)
     eng.a3_configure(a3, np.zeros((4, a3.period)))
     eng.contact_configure(np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32), 0, 7, 10)
-    for N in (4096, 32768):
-        b = A3HostBatcher(eng, N, 16, None, n_threads=16)
+    for N, mapped in ((4096, 0), (4096, 1), (32768, 0), (32768, 1)):
+        b = A3HostBatcher(eng, N, 16, None, n_threads=16).set_mapped(mapped)
         rng = np.random.default_rng(0)
         for e in range(0, N, max(1, N // 64)):                  # a few populated envs; the rest stay zero
             sl = b.slots(e)
@@ -75,7 +76,7 @@ def main():
                 acc[k] += v
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out[f"A3_N{N}_threads16"] = dict(us_per_vec_step=dt / K * 1e6, env_steps_per_s=N * K / dt,
+        out[f"A3_N{N}_threads16" + ("_mapped" if mapped else "")] = dict(us_per_vec_step=dt / K * 1e6, env_steps_per_s=N * K / dt,
                                          split_us={k: v / K * 1e6 for k, v in acc.items()},
                                          pcie_bytes_per_step=N * (8 * 12 + 1788))
         b.close()
