@@ -108,17 +108,32 @@ __global__ __launch_bounds__(THREADS) void reparam_kernel(long n, const float* _
     z[i] = mu[i] + expf(logvar[i] / 2.0f) * eps[i];
 }
 
-__global__ __launch_bounds__(THREADS) void reward_kernel(long n, const float* __restrict__ d,
+__device__ __forceinline__ float reward_of(float d) {
+  // numpy evaluates every step in float32 (gail_TRPO.py:320-327 on the network's float32 output), and so
+  // does this: expf / logf are the <= 1 ulp device functions, the same class of error as numpy's own
+  // float32 exp / log; the 1 - p cancellation amplifies either to the tolerance the tests state.
+  // (Round 1 took exp / log in fp64: 27 % of the HBM peak, fp64-transcendental-bound.)
+  const float e = expf(-d);
+  const float p = 1.0f / (1.0f + e);
+  const float q = 1.0f - p + 1e-8f;
+  return -logf(q);
+}
+
+// vec4: both pointers 16-byte aligned; the n % 4 tail goes through the scalar lanes of the last pass
+__global__ __launch_bounds__(THREADS) void reward_kernel(long n, int vec4, const float* __restrict__ d,
                                                          float* __restrict__ r) {
   const long stride = (long)gridDim.x * THREADS;
-  for (long i = (long)blockIdx.x * THREADS + threadIdx.x; i < n; i += stride) {
-    // numpy evaluates every step in float32; exp/log are taken in fp64 and narrowed so that the
-    // fp32 intermediate is the correctly rounded one (the 1 - p cancellation amplifies any error).
-    const float e = (float)exp(-(double)d[i]);
-    const float p = 1.0f / (1.0f + e);
-    const float q = 1.0f - p + 1e-8f;
-    r[i] = -(float)log((double)q);
+  const long tid = (long)blockIdx.x * THREADS + threadIdx.x;
+  long done = 0;
+  if (vec4) {
+    const long n4 = n >> 2;
+    for (long i = tid; i < n4; i += stride) {
+      const float4 x = reinterpret_cast<const float4*>(d)[i];
+      reinterpret_cast<float4*>(r)[i] = make_float4(reward_of(x.x), reward_of(x.y), reward_of(x.z), reward_of(x.w));
+    }
+    done = n4 << 2;
   }
+  for (long i = done + tid; i < n; i += stride) r[i] = reward_of(d[i]);
 }
 
 inline int blocks_for(long n) {
@@ -184,8 +199,9 @@ extern "C" int oly_disc_reward(oly_ctx* ctx, int64_t B, const float* logits, flo
   if (!ctx) return OLY_EINVAL;
   if (B < 0 || (B > 0 && (!logits || !reward))) OLY_FAIL(ctx, OLY_EINVAL, "oly_disc_reward: bad argument");
   if (B == 0) return OLY_OK;
-  hipLaunchKernelGGL(reward_kernel, dim3(blocks_for(B)), dim3(THREADS), 0, oly_s(stream), (long)B, logits,
-                     reward);
+  const int vec4 = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(reward)) & 15) == 0;
+  hipLaunchKernelGGL(reward_kernel, dim3(blocks_for(vec4 ? (B + 3) / 4 : B)), dim3(THREADS), 0, oly_s(stream), (long)B,
+                     vec4, logits, reward);
   OLY_LAUNCH_CHECK(ctx, "reward_kernel");
   return OLY_OK;
 }

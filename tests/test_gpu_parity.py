@@ -389,6 +389,23 @@ def test_disc_golden(eng, golden, oracle):
     np.testing.assert_allclose(z, oracle.disc_reparam(g["mu"], g["logvar"], g["eps"]), rtol=3e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("n,offset", [(1, 0), (3, 0), (4, 0), (4099, 0), (4099, 1), (65536, 0), (65537, 3)])
+def test_disc_reward_vector_and_scalar_paths(eng, oracle, n, offset):
+    """float4 body + scalar tail, and the scalar kernel for buffers that are not 16-byte aligned: same
+    float32 formula as the oracle (device expf / logf vs glibc's: the stated float32 tolerance)."""
+    rng = np.random.default_rng(n + offset)
+    d = np.concatenate([rng.normal(0, 4, n - min(n, 3)), [-30.0, 0.0, 25.0][:min(n, 3)]]).astype(np.float32)
+    buf, out = dev(np.zeros(n + 8, np.float32)), dev(np.full(n + 8, 7.0, np.float32))
+    buf[offset:offset + n] = dev(d)
+    r = host(eng.disc_reward(buf[offset:offset + n], out[offset:offset + n]))
+    want = oracle.disc_reward(d)
+    p = 1.0 / (1.0 + np.exp(-d.astype(np.float64)))
+    tol = 4 * 2.0 ** -24 / (1 - p + 1e-8) + 4e-7 * np.abs(want) + 1e-7
+    assert (np.abs(r - want) <= tol).all() and np.isfinite(r).all()
+    o = host(out)
+    assert (o[:offset] == 7.0).all() and (o[offset + n:] == 7.0).all()          # nothing outside the slice
+
+
 def test_vail_reward_end_to_end(eng, golden):
     """mask+standardise (HIP) -> encoder/decoder GEMMs (torch-ROCm) -> reparam + reward (HIP)
     reproduces the reference VariationalNet + make_discrim_reward."""
