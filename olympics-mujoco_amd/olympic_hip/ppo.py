@@ -430,6 +430,15 @@ class PPO:
         capturable = use_graph or next(policy.parameters()).is_cuda
         self.actor_optimizer = optim.Adam(policy.parameters(), lr=self.lr, eps=self.eps, capturable=capturable)
         self.critic_optimizer = optim.Adam(critic.parameters(), lr=self.lr, eps=self.eps, capturable=capturable)
+        if getattr(self, "tuned_gemms", False) and next(policy.parameters()).is_cuda:
+            # The update phase is PyTorch's.  hipBLASLt's default pick for the weight-gradient
+            # GEMMs ([256, B] x [B, 256]) is a 32 x 64 macro tile; torch's TunableOp times the candidates once
+            # per GEMM shape and keeps the fastest: 2.70 -> 1.92 ms per 65536-row update on MI355X.  Opt-in:
+            # tuning costs a few seconds per process and changes the GEMMs' summation order.
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(True)
+            os.makedirs(self.save_path, exist_ok=True)
+            torch.cuda.tunable.set_filename(os.path.join(self.save_path, "tunableop_results.csv"))
         env = env_fn()
         from . import dist as odist
         multi_rank = odist.is_dist() and torch.distributed.get_world_size() > 1

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--rollout", default="host", choices=["host", "device"],
                     help="host: one env.step per python iteration (K5, K3, K2 launches); device: one fused K10 launch "
                          "per vec step, replayed from a HIP graph, resets on the device")
+    ap.add_argument("--tuned-gemms", action="store_true", help="PPO.tuned_gemms: torch TunableOp for the update GEMMs")
     args = ap.parse_args()
     N, T = args.N, args.T
     gen = torch.Generator(device="cuda").manual_seed(1)
@@ -80,12 +81,13 @@ def main():
     ppo.fused_loss, ppo.use_graph = args.mode != "torch_losses", args.mode == "fused_graph"
     ppo.use_graph_rollout = args.mode == "fused_graph"
     ppo.use_device_rollout = args.rollout == "device"
+    ppo.tuned_gemms = args.tuned_gemms
     torch.manual_seed(0)
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
     hist = ppo.train(Env, pi, vf, n_itr=args.itr, verbose=False)
     last = hist[-1]
     steady = hist[1:] or hist
-    out = dict(config=dict(N=N, T=T, minibatch=args.minibatch, epochs=args.epochs, mode=args.mode, physics="synthetic replay"),
+    out = dict(config=dict(N=N, T=T, minibatch=args.minibatch, epochs=args.epochs, mode=args.mode, physics="synthetic replay", tuned_gemms=args.tuned_gemms),
                sample_s=float(np.mean([h["sample_s"] for h in steady])),
                optim_s=float(np.mean([h["optim_s"] for h in steady])),
                env_steps_per_iteration=N * T,

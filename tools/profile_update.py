@@ -13,6 +13,8 @@ from olympic_hip.engine import Engine  # noqa: E402
 from olympic_hip.ppo import PPO, GraphedUpdate, MLPCritic, MLPGaussianActor  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+if len(sys.argv) > 2:                 # "cublas" (= rocBLAS) or "cublaslt" (= hipBLASLt, torch's default here)
+    torch.backends.cuda.preferred_blas_library(sys.argv[2])
 eng = Engine(0)
 dev = eng.device
 torch.manual_seed(0)
@@ -35,4 +37,4 @@ R = 20
 for i in range(R):
     gu(obs, act, ret, adv, perm[(i % 4) * B:(i % 4 + 1) * B])
 torch.cuda.synchronize()
-print("ms per update:", 1e3 * (time.perf_counter() - t0) / R)
+print("blas:", torch.backends.cuda.preferred_blas_library(), "ms per update:", 1e3 * (time.perf_counter() - t0) / R)
