@@ -222,7 +222,9 @@ class A3DeviceRollout:
         return self._fw
 
     def _graph(self, one_step, U, fw):
-        key = (U, id(fw), self._shape)
+        # the launch arguments a capture bakes in: buffers (shape key), the forward object, its input-normalisation
+        # switches (the critic normalises only in eval mode: a train()/eval() flip needs a new capture)
+        key = (U, id(fw), self._shape, getattr(fw, "norm_a", None), getattr(fw, "norm_c", None))
         if key not in self._graphs:
             from .ppo import _graph_streams
             side, cap = _graph_streams(self.eng.device)
@@ -266,12 +268,13 @@ class A3DeviceRollout:
         self._nv_flat.index_put_((lin,), v_side)
         # one host round trip per rollout: pool cursors (to refill the consumed records), the readback
         # cursor, and the side-list high-water mark
-        host = torch.cat([self.pool_count, self.side_count.max().reshape(1), self.ctr[1:2]]).cpu().numpy()
-        consumed, hw, k = host[:N], int(host[N]), int(host[N + 1])
+        host = torch.cat([self.pool_count, self.side_count.max().reshape(1), self.ctr[1:2],
+                          valid.sum().to(torch.int32).reshape(1)]).cpu().numpy()
+        consumed, hw, k, side_rows = host[:N], int(host[N]), int(host[N + 1]), int(host[N + 2])
         if hw > self.slots:
             raise OlyError(f"bootstrap side list overflow: {hw} cuts in one environment, {self.slots} slots")
         self.last_info = dict(resets=int(consumed.sum()), reused_records=int(np.maximum(consumed - self.depth, 0).sum()),
-                              side_rows=int(valid.sum().item()))
+                              side_rows=side_rows)
         phys = getattr(self.env, "physics", None)
         if phys is not None and hasattr(phys, "k"):
             phys.k = k % int(self.blocks["qpos"].shape[0])
