@@ -402,3 +402,53 @@ def test_vec_step_and_mlp_argument_errors(eng, golden):
     pk = eng.mlp_pack(z(256, 41), z(256), z(256, 256), z(256), z(12, 256), z(12))
     with pytest.raises(OlyError, match="packed_a"):
         eng.mlp_forward2(z(8, 41), pk[:-4].clone(), 12, z(8, 12))                        # not a whole packed stream
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_vec_step_random_configurations(eng, golden, oracle, seed):
+    """Differential fuzz over the launch shape: environments not a multiple of the 16-env workgroup, one
+    readback row (K = 1), one-step trajectories (every step cuts and resets), a one-record reset ring (records
+    re-used), 1 to 40 contact slots, deterministic and stochastic policies.  Integer state, flags, cursors and
+    actions bit-exact, float64 values to 1e-11, observations to one float32 ulp."""
+    cfg = np.random.default_rng(1000 + seed)
+    spec = specs.A3Spec(mass=41.5)
+    lut = golden("a3_task.npz")["clock_lut"]
+    N = int(cfg.choice([1, 2, 15, 16, 17, 63, 65, 130, 257, 1023]))
+    K = int(cfg.choice([1, 2, 7]))
+    T = int(cfg.integers(1, 8))
+    max_len = int(cfg.choice([1, 2, 3, 50]))
+    depth = int(cfg.choice([1, 2, 5]))
+    C = int(cfg.choice([1, 3, 16, 17, 40]))
+    det = bool(cfg.integers(0, 2))
+    blocks, state, ro, rng = _host_rollout(spec, N, K, T, max_len, depth, seed=seed, det=det, p_bad=0.1, p_low=0.05)
+    if C != 16:
+        blocks = a3_synthetic_blocks(N, K, seed=seed, C=C, p_bad=0.1, p_low=0.05)
+        blocks["ncon"] = rng.integers(0, C + 1, blocks["ncon"].shape).astype(np.int32)
+    d_blocks, d_state, d_ro = _to_device(eng, blocks, state, ro)
+    launch = eng.a3_vec_prepare(d_blocks, d_state, d_ro)
+    h = lambda t_: t_.cpu().numpy()
+    for step in range(-1, T):
+        fl = _abi.VSTEP_RESET_ALL if step < 0 else 0
+        if step >= 0:
+            ro["mu"][...] = rng.normal(0, 0.3, (N, spec.nu)).astype(np.float32)
+            ro["value"][...] = rng.normal(0, 1, N).astype(np.float32)
+            d_ro["state"].copy_(dev(ro["state"]))
+            launch(0, dev(ro["mu"]), dev(ro["value"]))
+        else:
+            launch(fl)
+        oracle.a3_vec_step(spec, lut, CONTACT, blocks, state, ro, fl)
+        what = (seed, step, dict(N=N, K=K, T=T, max_len=max_len, depth=depth, C=C, det=det))
+        for k in ("phase", "t1", "t2", "reached_frames", "target_reached", "mode", "seq_len"):
+            assert np.array_equal(h(d_state[k]), state[k]), (k, what)
+        for k in ("traj_len", "side_count", "side_t", "pool_count", "buf_flags"):
+            assert np.array_equal(h(d_ro[k]), ro[k]), (k, what)
+        assert np.array_equal(h(d_ro["buf_actions"]), ro["buf_actions"]), what
+        assert np.array_equal(h(d_ro["pd_target"]), ro["pd_target"]), what
+        np.testing.assert_allclose(h(d_state["sequence"]), state["sequence"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(h(d_state["goal"]), state["goal"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(h(d_ro["buf_rewards"]), ro["buf_rewards"], rtol=1e-11, atol=1e-13)
+        for k in ("state", "buf_states", "side_obs"):
+            a, b = h(d_ro[k]), ro[k]
+            assert np.abs(a - b).max() <= np.spacing(np.float32(1.0)) * max(1.0, np.abs(b).max()), (k, what)
+    c = h(d_ro["ctr"]).reshape(-1, 2)
+    assert (c[:, 0] == ro["ctr"][0]).all() and (c[:, 1] == ro["ctr"][1]).all()
