@@ -452,3 +452,24 @@ def test_vec_step_random_configurations(eng, golden, oracle, seed):
             assert np.abs(a - b).max() <= np.spacing(np.float32(1.0)) * max(1.0, np.abs(b).max()), (k, what)
     c = h(d_ro["ctr"]).reshape(-1, 2)
     assert (c[:, 0] == ro["ctr"][0]).all() and (c[:, 1] == ro["ctr"][1]).all()
+
+
+@pytest.mark.parametrize("in_dim,out_a,out_b,N", [(1, 1, 1, 5), (7, 32, 1, 33), (40, 5, 32, 64), (64, 12, 1, 97),
+                                                  (63, 31, 2, 200), (33, 1, 17, 31)])
+def test_fused_mlp_other_dimensions_vs_oracle(eng, oracle, in_dim, out_a, out_b, N):
+    """Every supported width (input up to 64, heads up to 32 columns, zero-padded inside the packed stream),
+    two different heads in one launch, with and without input normalisation: bit-exact against the oracle."""
+    rng = np.random.default_rng(in_dim * 100 + out_a)
+    f = lambda *s: rng.normal(0, 0.4, s).astype(np.float32)
+    nets = []
+    for out in (out_a, out_b):
+        nets.append([f(256, in_dim), f(256), f(256, 256) * 0.2, f(256), f(out, 256) * 0.2, f(out)])
+    mean, std = f(in_dim), (rng.uniform(0.5, 1.5, in_dim)).astype(np.float32)
+    x = f(N, in_dim) * 3
+    pk_a = eng.mlp_pack(*[dev(a) for a in nets[0]], dev(mean), dev(std))
+    pk_b = eng.mlp_pack(*[dev(a) for a in nets[1]])
+    ya = torch.full((N, out_a), 9.0, device="cuda")
+    yb = torch.full((N, out_b), 9.0, device="cuda")
+    eng.mlp_forward2(dev(x), pk_a, out_a, ya, pk_b, out_b, yb, normalize_a=True, normalize_b=False)
+    assert np.array_equal(ya.cpu().numpy(), oracle.mlp_forward(x, *nets[0], in_mean=mean, in_std=std))
+    assert np.array_equal(yb.cpu().numpy(), oracle.mlp_forward(x, *nets[1]))
