@@ -327,13 +327,16 @@ def test_adv_normalize_parts(eng, oracle):
     rank-order tree = the oracle's; 1 part = oly_adv_normalize."""
     rng = np.random.default_rng(8)
     x = rng.normal(0.2, 1.7, 400 * 1024).astype(np.float32)
-    for parts in (1, 2, 3, 8):
+    for parts in (1, 2, 3, 8, 37, 64):                       # 64 = OLY_MAX_STAT_PARTS
         shards = np.array_split(x, parts)
         p3 = np.stack([host(eng.adv_stats(dev(s))) for s in shards])
         for ddof, eps in ((1, 1e-5), (0, 1e-8)):
             got = host(eng.adv_normalize(dev(x), dev(p3) if parts > 1 else dev(p3[0]), ddof, eps))
             assert np.array_equal(got, oracle.adv_normalize_parts(x, p3, ddof, eps))
             np.testing.assert_allclose(got, (x - x.mean()) / (x.std(ddof=ddof) + eps), rtol=2e-5, atol=2e-6)
+    from olympic_hip._ffi import OlyError
+    with pytest.raises(OlyError, match="parts"):
+        eng.adv_normalize(dev(x), dev(np.zeros((65, 3))), 1, 1e-5)
 
 
 # --------------------------------------------------------------------------------- K7
