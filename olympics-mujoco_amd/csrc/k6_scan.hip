@@ -346,6 +346,146 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wide shapes (N >= 128 environments per CU): one LANE per environment, no LDS, no barriers.
+// With thousands of waves the occupancy hides the latency that the pipelined kernel needs mover
+// waves for, and nothing waits for a workgroup's chain wave.  Per lane a software pipeline over
+// chunks of LU steps: flags two chunks ahead, rewards / values one chunk ahead, and next_val
+// ONLY where the flags say it is read (RETURN mode: cut steps that are not terminal): every lane
+// issues the load, lanes that do not need it present an out-of-range buffer offset, which costs no
+// memory traffic.  All loads and stores are branch-free buffer operations (range-checked by the
+// hardware), so the loop is straight-line code and the waits are counted (vmcnt(n)), not drained.
+// Same arithmetic, same order as the other two kernels: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+constexpr int LANE_THREADS = 256;
+constexpr int LU = 8;
+
+template <int MODE, bool REW64>
+__global__ __launch_bounds__(LANE_THREADS) void scan_lane_kernel(int T, int N, double gamma, double lam,
+                                                                 const void* __restrict__ rew_,
+                                                                 const float* __restrict__ val,
+                                                                 const float* __restrict__ next_val,
+                                                                 const uint8_t* __restrict__ flags,
+                                                                 float* __restrict__ ret, float* __restrict__ adv,
+                                                                 double* __restrict__ stats_ws) {
+  using rew_t = typename std::conditional<REW64, double, float>::type;
+  constexpr unsigned OOB = 0x80000000u;     // beyond every num_records (the host keeps the buffers below 2 GiB)
+  const size_t total = (size_t)T * N;
+  const __amdgpu_buffer_rsrc_t rs_rew = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(rew_), 0, (int)(total * sizeof(rew_t)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(val), 0, (int)(total * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(next_val), 0, (int)(total * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_fl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(flags), 0, (int)total, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ret = __builtin_amdgcn_make_buffer_rsrc(ret, 0, (int)(total * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_adv = __builtin_amdgcn_make_buffer_rsrc(adv, 0, (int)(total * 4), 0x00020000);
+  const int n = blockIdx.x * LANE_THREADS + threadIdx.x;
+  const bool env_ok = n < N;
+  const int nchunks = (T + LU - 1) / LU;
+  const float g32 = (float)gamma;
+  const float gl32 = (float)(gamma * lam);
+
+  // element index of step u of chunk c (t = T-1 - (c*LU + u)), OOB for steps before 0 / envs beyond N
+  auto elem = [&](int c, int u, bool& ok) -> unsigned {
+    const int t = T - 1 - (c * LU + u);
+    ok = env_ok && t >= 0;
+    return (unsigned)t * (unsigned)N + (unsigned)n;
+  };
+  struct Main { rew_t r[LU]; float v[LU], nv[LU]; unsigned fl[LU]; };   // fl: the chunk's flags, so the flag registers are free again
+  auto load_flags = [&](int c, unsigned (&f)[LU]) {
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      bool ok;
+      const unsigned e = elem(c, u, ok);
+      unsigned x = __builtin_amdgcn_raw_buffer_load_b8(rs_fl, ok ? e : OOB, 0, 0);
+      if (T - 1 - (c * LU + u) == T - 1) x |= OLY_FLAG_LAST;          // the block end cuts every environment
+      f[u] = x;
+    }
+  };
+  auto load_main = [&](int c, const unsigned (&f)[LU], Main& m) {
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      bool ok;
+      const unsigned e = elem(c, u, ok);
+      if (REW64) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        m.r[u] = (rew_t)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_rew, ok ? e * 8u : OOB, 0, 0));
+      } else {
+        m.r[u] = (rew_t)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rew, ok ? e * 4u : OOB, 0, 0));
+      }
+      m.v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_val, ok ? e * 4u : OOB, 0, 0));
+      m.fl[u] = f[u];
+      const bool need_nv = MODE == OLY_SCAN_GAE ? true : ((f[u] & OLY_FLAG_LAST) && !(f[u] & OLY_FLAG_ABSORBING));
+      m.nv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_nv, (ok && need_nv) ? e * 4u : OOB, 0, 0));
+    }
+  };
+  double R = 0.0;
+  float a_next = 0.f;
+  double acc_s = 0.0, acc_ss = 0.0;
+  auto compute = [&](int c, const Main& m) {
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      bool ok;
+      const unsigned e = elem(c, u, ok);
+      const bool last = (m.fl[u] & OLY_FLAG_LAST) != 0, ab = (m.fl[u] & OLY_FLAG_ABSORBING) != 0;
+      float rt, at;
+      if (MODE == OLY_SCAN_RETURN) {
+        const float p = g32 * ((last && !ab) ? m.nv[u] : 0.f);
+        const double cut = (double)p + (double)m.r[u];
+        const double run = gamma * R + (double)m.r[u];
+        const double Rn = last ? cut : run;
+        R = ok ? Rn : R;
+        rt = (float)Rn;
+        at = rt - m.v[u];
+      } else {
+        float a_cut = (float)m.r[u] - m.v[u];
+        if (!ab) a_cut += g32 * m.nv[u];
+        const float a_run = (float)m.r[u] + g32 * m.nv[u] - m.v[u] + gl32 * a_next;
+        at = last ? a_cut : a_run;
+        a_next = ok ? at : a_next;
+        rt = at + m.v[u];
+      }
+      const unsigned off = ok ? e * 4u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rt), rs_ret, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, at), rs_adv, off, 0, 0);
+      if (stats_ws && ok) {
+        const double a = (double)at;
+        acc_s += a;
+        acc_ss += a * a;
+      }
+    }
+  };
+
+  unsigned fA[LU], fB[LU];
+  Main mA, mB;
+  // Issue order per chunk c: main(c+1) [needs flags(c+1), issued one chunk ago], flags(c+2), then the
+  // arithmetic and the stores of chunk c [needs main(c), issued one chunk ago].  In-order completion makes
+  // every wait a counted one: at most 56 younger operations stay in flight (vmcnt holds 63).
+  load_flags(0, fA);
+  load_flags(1, fB);
+  load_main(0, fA, mA);
+  for (int c = 0; c < nchunks; c += 2) {
+    load_main(c + 1, fB, mB);       // flags(c+1) -> fB consumed (copied into mB.fl)
+    load_flags(c + 2, fA);          // fA held flags(c): already copied into mA.fl
+    compute(c, mA);
+    load_main(c + 2, fA, mA);
+    load_flags(c + 3, fB);
+    compute(c + 1, mB);
+  }
+  if (stats_ws) {
+    __shared__ double sh[2 * LANE_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double ws_ = wave_sum(acc_s), wss_ = wave_sum(acc_ss);
+    if (lane == 0) { sh[2 * w] = ws_; sh[2 * w + 1] = wss_; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double ts = 0.0, tss = 0.0;
+      for (int i = 0; i < LANE_THREADS / 64; ++i) { ts += sh[2 * i]; tss += sh[2 * i + 1]; }
+      stats_ws[2 * blockIdx.x] = ts;
+      stats_ws[2 * blockIdx.x + 1] = tss;
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -405,9 +545,34 @@ extern "C" int oly_return_scan_stats(oly_ctx* ctx, int mode_flags, int T, int N,
   if (!rew || !val || !next_val || !flags || !ret || !adv)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_return_scan: NULL pointer");
   static const int variant = [] { const char* e = getenv("OLY_K6_VARIANT"); return e ? atoi(e) : 1; }();  // 1 auto, 3 force the fallback
+  static const int pipe_cfg = [] { const char* e = getenv("OLY_K6_PIPE"); return e ? atoi(e) : 0; }();   // 0 auto; 7 forces the lane kernel
+  // the lane-per-environment kernel addresses its buffers through 32-bit buffer offsets: each below 2 GiB
+  const bool fits32 = (size_t)T * (size_t)N * (rew64 ? 8 : 4) < ((size_t)1 << 31);
+  // measured on MI355X (tools/time_k6_wide.py): RETURN mode gains 17-32 % from N = 256 environments per CU up
+  // (next_val is fetched at the cut steps only); GAE reads next_val everywhere and stays on the pipelined kernel
+  if (variant == 1 && fits32 &&
+      (pipe_cfg == 7 || (pipe_cfg == 0 && mode == OLY_SCAN_RETURN && N >= 256 * ctx->num_cu))) {
+    const int nblocks = (N + LANE_THREADS - 1) / LANE_THREADS;
+    double* ws = (stats3_out && (size_t)nblocks * 2 * sizeof(double) <= ctx->stats_ws_bytes) ? ctx->stats_ws : nullptr;
+    dim3 g(nblocks), b(LANE_THREADS);
+    if (mode == OLY_SCAN_RETURN && rew64)
+      hipLaunchKernelGGL((scan_lane_kernel<OLY_SCAN_RETURN, true>), g, b, 0, oly_s(stream), T, N, gamma, lam, rew, val,
+                         next_val, flags, ret, adv, ws);
+    else if (mode == OLY_SCAN_RETURN)
+      hipLaunchKernelGGL((scan_lane_kernel<OLY_SCAN_RETURN, false>), g, b, 0, oly_s(stream), T, N, gamma, lam, rew, val,
+                         next_val, flags, ret, adv, ws);
+    else
+      hipLaunchKernelGGL((scan_lane_kernel<OLY_SCAN_GAE, false>), g, b, 0, oly_s(stream), T, N, gamma, lam, rew, val,
+                         next_val, flags, ret, adv, ws);
+    OLY_LAUNCH_CHECK(ctx, "scan_lane_kernel");
+    if (stats3_out) {
+      if (ws) return oly_stats_finish(ctx, nblocks, (int64_t)T * N, stats3_out, stream);
+      return oly_adv_stats(ctx, (int64_t)T * N, adv, stats3_out, stream);
+    }
+    return OLY_OK;
+  }
   if (variant == 1 && N % 4 == 0 && wide_ok(rew, val, next_val, flags, ret, adv)) {
     // three LDS buffers of [PT][EPW] (constant fp64/fp32 + value f32 + select u8)
-    static const int pipe_cfg = [] { const char* e = getenv("OLY_K6_PIPE"); return e ? atoi(e) : 0; }();
     int nblocks = 0;
     double* ws = nullptr;
 #define OLY_PIPE_LAUNCH(ID, NT, DP, EPW, PTT)                                                            \

@@ -2,6 +2,7 @@
 inputs, against the golden vectors, and - at full BASELINE sizes - through size-independent
 properties.  Bars: integers / flags / indices bit-exact; floating point within the tolerance
 written next to each check."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -320,6 +321,37 @@ def test_scan_fused_statistics(eng, oracle, mode, T, N):
     st2 = torch.zeros(3, dtype=torch.float64, device="cuda")
     eng.return_scan(mode, 0.99, 0.97, dev(r), dev(v), dev(vn), dev(flags), stats3=st2)
     assert torch.equal(st, st2)                                  # deterministic
+
+
+def test_scan_lane_kernel_on_every_scan_case():
+    """The lane-per-environment scan (taken by default from 256 environments per CU, i.e. shapes no test here
+    reaches) forced onto every scan test of this file: OLY_K6_PIPE is read once per process, hence the child."""
+    import subprocess
+    import sys
+    env = dict(os.environ, OLY_K6_PIPE="7")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "scan and not lane_kernel", "-p", "no:cacheprovider"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+def test_scan_lane_kernel_wide_shape(eng, oracle):
+    """A shape the default dispatch sends to the lane kernel ([24, 70000]: N >= 256 per CU), float64 rewards and
+    fused statistics, against the oracle (bit-exact returns / advantages)."""
+    rng = np.random.default_rng(77)
+    T, N = 24, 70000
+    r = rng.normal(0.3, 1, (T, N))
+    v, vn = (rng.normal(0, 1, (T, N)).astype(np.float32) for _ in range(2))
+    last = rng.uniform(size=(T, N)) < 0.05
+    flags = (last * _abi.FLAG_LAST + (last & (rng.uniform(size=(T, N)) < 0.5)) * _abi.FLAG_ABSORBING).astype(np.uint8)
+    st = torch.zeros(3, dtype=torch.float64, device="cuda")
+    ret, adv = eng.return_scan(_abi.SCAN_RETURN, 0.99, 1.0, dev(r), dev(v), dev(vn), dev(flags), stats3=st)
+    e_ret, e_adv = oracle.return_scan_r64(0.99, r, v, vn, flags)
+    assert np.array_equal(host(ret), e_ret) and np.array_equal(host(adv), e_adv)
+    got = host(st)
+    assert got[0] == T * N
+    np.testing.assert_allclose(got[1:], oracle.adv_stats(e_adv)[1:], rtol=1e-12, atol=1e-9)
 
 
 def test_adv_normalize_parts(eng, oracle):

@@ -6,7 +6,7 @@ from olympic_hip.engine import Engine
 from olympic_hip._ffi import HipTimer
 eng = Engine(0); dev = eng.device
 out = {}
-for (T, N) in ((400, 262144), (400, 32768), (400, 4096)):
+for (T, N) in ((400, 524288), (400, 262144), (400, 131072), (400, 65536), (400, 32768), (400, 4096)):
     torch.manual_seed(0)
     r = torch.rand((T, N), device=dev); v = torch.randn((T, N), device=dev); nv = torch.randn((T, N), device=dev)
     fl = ((torch.rand((T, N), device=dev) < 0.003).to(torch.uint8) * 3)
