@@ -407,7 +407,6 @@ __global__ __launch_bounds__(LANE_THREADS) void scan_lane_kernel(int T, int N, d
       bool ok;
       const unsigned e = elem(c, u, ok);
       if (REW64) {
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         m.r[u] = (rew_t)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_rew, ok ? e * 8u : OOB, 0, 0));
       } else {
         m.r[u] = (rew_t)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rew, ok ? e * 4u : OOB, 0, 0));
