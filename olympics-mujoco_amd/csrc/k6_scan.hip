@@ -21,6 +21,22 @@ namespace {
 // tile of rew/val/next_val/flags with scalar loads (any alignment, any N) while wave 0 runs the
 // sequential recurrence over the current tile out of LDS.
 // ---------------------------------------------------------------------------------------
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+typedef double nt_f64x2 __attribute__((ext_vector_type(2)));
+// streaming (non-temporal) 16-byte accesses of the pipelined kernel's movers: every byte is touched once
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 nt_load2(const double* p) {
+  const nt_f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f64x2*>(p));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void nt_store4(float* p, float a, float b, float c, float d) {
+  nt_f32x4 v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<nt_f32x4*>(p));
+}
+
 constexpr int TT = 64;          // time steps per tile
 constexpr int SCAN_THREADS = 256;
 
@@ -180,15 +196,15 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
       if (g < PIPE_GROUPS && t >= 0 && n0 + 4 * c4 < N) {
         const size_t e = (size_t)t * N + n0 + 4 * c4;
         if (REW64) {
-          const double2 lo = *reinterpret_cast<const double2*>(rew + e);
-          const double2 hi = *reinterpret_cast<const double2*>(rew + e + 2);
+          const double2 lo = nt_load2(reinterpret_cast<const double*>(rew + e));
+          const double2 hi = nt_load2(reinterpret_cast<const double*>(rew + e + 2));
           R.r[j][0] = (rew_t)lo.x; R.r[j][1] = (rew_t)lo.y; R.r[j][2] = (rew_t)hi.x; R.r[j][3] = (rew_t)hi.y;
         } else {
-          const float4 r4 = *reinterpret_cast<const float4*>(rew + e);
+          const float4 r4 = nt_load4(reinterpret_cast<const float*>(rew + e));
           R.r[j][0] = (rew_t)r4.x; R.r[j][1] = (rew_t)r4.y; R.r[j][2] = (rew_t)r4.z; R.r[j][3] = (rew_t)r4.w;
         }
-        R.v[j] = *reinterpret_cast<const float4*>(val + e);
-        R.nv[j] = *reinterpret_cast<const float4*>(next_val + e);
+        R.v[j] = nt_load4(val + e);
+        R.nv[j] = nt_load4(next_val + e);
         R.f[j] = *reinterpret_cast<const uchar4*>(flags + e);
       }
     }
@@ -261,8 +277,8 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
             ro[q] = ao[q] + vv[q];
           }
         }
-        *reinterpret_cast<float4*>(ret + e) = make_float4(ro[0], ro[1], ro[2], ro[3]);
-        *reinterpret_cast<float4*>(adv + e) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+        nt_store4(ret + e, ro[0], ro[1], ro[2], ro[3]);
+        nt_store4(adv + e, ao[0], ao[1], ao[2], ao[3]);
         if (stats_ws) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -360,6 +376,9 @@ __global__ __launch_bounds__(NTHREADS) void scan_pipe_kernel(int T, int N, doubl
 // ---------------------------------------------------------------------------------------------
 constexpr int LANE_THREADS = 256;
 constexpr int LU = 8;
+// cache policy of the lane kernel's buffer operations: nt (2).  Every byte is touched once; measured against
+// the default policy at [400, 262144]: 0.344 -> 0.319 ms (f32 rewards), 0.442 -> 0.397 ms (f64 + statistics)
+constexpr int LANE_AUX = 2;
 
 template <int MODE, bool REW64>
 __global__ __launch_bounds__(LANE_THREADS) void scan_lane_kernel(int T, int N, double gamma, double lam,
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(LANE_THREADS) void scan_lane_kernel(int T, int N, d
     for (int u = 0; u < LU; ++u) {
       bool ok;
       const unsigned e = elem(c, u, ok);
-      unsigned x = __builtin_amdgcn_raw_buffer_load_b8(rs_fl, ok ? e : OOB, 0, 0);
+      unsigned x = __builtin_amdgcn_raw_buffer_load_b8(rs_fl, ok ? e : OOB, 0, LANE_AUX);
       if (T - 1 - (c * LU + u) == T - 1) x |= OLY_FLAG_LAST;          // the block end cuts every environment
       f[u] = x;
     }
@@ -407,14 +426,14 @@ __global__ __launch_bounds__(LANE_THREADS) void scan_lane_kernel(int T, int N, d
       bool ok;
       const unsigned e = elem(c, u, ok);
       if (REW64) {
-        m.r[u] = (rew_t)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_rew, ok ? e * 8u : OOB, 0, 0));
+        m.r[u] = (rew_t)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_rew, ok ? e * 8u : OOB, 0, LANE_AUX));
       } else {
-        m.r[u] = (rew_t)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rew, ok ? e * 4u : OOB, 0, 0));
+        m.r[u] = (rew_t)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rew, ok ? e * 4u : OOB, 0, LANE_AUX));
       }
-      m.v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_val, ok ? e * 4u : OOB, 0, 0));
+      m.v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_val, ok ? e * 4u : OOB, 0, LANE_AUX));
       m.fl[u] = f[u];
       const bool need_nv = MODE == OLY_SCAN_GAE ? true : ((f[u] & OLY_FLAG_LAST) && !(f[u] & OLY_FLAG_ABSORBING));
-      m.nv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_nv, (ok && need_nv) ? e * 4u : OOB, 0, 0));
+      m.nv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_nv, (ok && need_nv) ? e * 4u : OOB, 0, LANE_AUX));
     }
   };
   double R = 0.0;
@@ -444,8 +463,8 @@ __global__ __launch_bounds__(LANE_THREADS) void scan_lane_kernel(int T, int N, d
         rt = at + m.v[u];
       }
       const unsigned off = ok ? e * 4u : OOB;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rt), rs_ret, off, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, at), rs_adv, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rt), rs_ret, off, 0, LANE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, at), rs_adv, off, 0, LANE_AUX);
       if (stats_ws && ok) {
         const double a = (double)at;
         acc_s += a;
