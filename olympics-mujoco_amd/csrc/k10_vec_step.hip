@@ -135,8 +135,30 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   int g1_0 = -1, g2_0 = -1;
   double f0[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pz0 = 0.0;
   int dst_b = -1;
+  // the environment's NEXT reset record (header + its rows of the local step sequence), fetched for every
+  // environment whether it will reset or not: behind `need_reset` these were two more exposed memory
+  // latencies on the slowest workgroup of nearly every launch (some environment resets almost every step)
+  int rec_mode = OLY_MODE_STANDING, rec_phase = 0, rec_len = 1;
+  double rec_seq[(OLY_MAX_SEQ + SLOTS - 1) / SLOTS][4];
+#pragma unroll
+  for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q)
+    rec_seq[q][0] = rec_seq[q][1] = rec_seq[q][2] = rec_seq[q][3] = 0.0;
   if (env_ok) {
-    nc_raw = p.b.ncon[kN + n];
+    rc = p.ro.pool_count[n];
+    const oly_a3_reset_record* rec = p.ro.pool + (size_t)n * p.ro.pool_depth + (unsigned)rc % (unsigned)p.ro.pool_depth;
+    rec_mode = rec->mode;
+    rec_phase = rec->phase;
+    rec_len = rec->seq_len;
+#pragma unroll
+    for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
+      const int r = slot + SLOTS * q;
+      if (r < OLY_MAX_SEQ) {
+        rec_seq[q][0] = rec->seq[r][0]; rec_seq[q][1] = rec->seq[r][1];
+        rec_seq[q][2] = rec->seq[r][2]; rec_seq[q][3] = rec->seq[r][3];
+      }
+    }
+    // (everything above and the task state below is addressed without the step / readback counters, so it is
+    // in flight before their values are needed; the readback rows, which need `kk`, follow)
     phase0 = p.st.phase[n];
     t1 = p.st.t1[n];
     t2 = p.st.t2[n];
@@ -144,7 +166,9 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
     mode = p.st.mode[n];
     seq_len = p.st.seq_len[n];
     tlen = p.ro.traj_len[n];
-    rc = p.ro.pool_count[n];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) vs[q] = p.st.sequence[(size_t)n * OLY_MAX_SEQ * 4 + slot + SLOTS * q];
+    nc_raw = p.b.ncon[kN + n];
     const size_t r3 = (kN + n) * 3, r4 = (kN + n) * 4;
     if (slot < 4) va = p.b.root_quat[r4 + slot];
     else if (slot < 7) va = p.b.root_pos[r3 + slot - 4];
@@ -159,8 +183,6 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
       v_len = p.b.act_len[(kN + n) * nu + slot];
       v_vel = p.b.act_vel[(kN + n) * nu + slot];
     }
-#pragma unroll
-    for (int q = 0; q < 5; ++q) vs[q] = p.st.sequence[(size_t)n * OLY_MAX_SEQ * 4 + slot + SLOTS * q];
     if (slot < C) {
       const size_t e0 = (kN + n) * C + slot;
       g1_0 = p.b.geom1[e0];
@@ -365,13 +387,11 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   const double roll_x = regular ? Rb[2][2] : Rb[1][1];
 
   // env.reset(): the next pool record (mode / phase / local sequence), drawn on the host
-  const oly_a3_reset_record* rec = nullptr;
   int new_mode = mode, new_phase = 0, new_len = seq_len;
   if (need_reset) {
-    rec = p.ro.pool + (size_t)n * p.ro.pool_depth + (unsigned)rc % (unsigned)p.ro.pool_depth;
-    new_mode = rec->mode;
-    new_phase = rec->phase;
-    new_len = min(max(rec->seq_len, 1), OLY_MAX_SEQ);
+    new_mode = rec_mode;
+    new_phase = rec_phase;
+    new_len = min(max(rec_len, 1), OLY_MAX_SEQ);
   }
   // root yaw for transform_sequence: quat2euler(root xquat)[2] = mat2euler's ak
   const double cyr = sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
@@ -553,10 +573,13 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
       const double cyw = se[L_R2 + 2 * 5 + 1], syw = se[L_R2 + 2 * 5];
       const double mid0 = (lf0 + rf0) / 2, mid1 = (lf1 + rf1) / 2;
       double* seq_out = const_cast<double*>(p.st.sequence) + (size_t)n * OLY_MAX_SEQ * 4;
-      for (int r = slot; r < OLY_MAX_SEQ; r += SLOTS) {
+#pragma unroll
+      for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
+        const int r = slot + SLOTS * q;
+        if (r >= OLY_MAX_SEQ) continue;
         double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
         if (r < new_len) {
-          const double x = rec->seq[r][0], y = rec->seq[r][1], z = rec->seq[r][2], th = rec->seq[r][3];
+          const double x = rec_seq[q][0], y = rec_seq[q][1], z = rec_seq[q][2], th = rec_seq[q][3];
           o0 = mid0 + x * cyw - y * syw;
           o1 = mid1 + x * syw + y * cyw;
           o2 = z;
