@@ -22,6 +22,10 @@ constexpr double PI = 3.141592653589793;
 struct A3Args {
   const A3Dev* md;
   int N;
+  // where the base quaternion / base angular velocity of env n sit inside in.qpos / in.qvel: row stride and
+  // offset in doubles.  (nq, 3) / (nv, 3) for the full rows of the C ABI; (4, 0) / (3, 0) for the host batcher's
+  // compact staging, which ships only the seven numbers get_obs reads.
+  int qpos_stride, qpos_off, qvel_stride, qvel_off;
   oly_a3_inputs in;
   oly_a3_state st;
   void* obs;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(THREADS) void a3_step_kernel(A3Args p) {
   using obs_t = typename std::conditional<OBS64, double, float>::type;
   obs_t* s_obs = reinterpret_cast<obs_t*>(lds_raw);  // [THREADS][n_obs]
   const A3Dev* __restrict__ m = p.md;
-  const int n_obs = m->n_obs, nu = m->nu, nq = m->nq, nv = m->nv, period = m->period;
+  const int n_obs = m->n_obs, nu = m->nu, period = m->period;
   const int tid = threadIdx.x;
   const int n0 = blockIdx.x * THREADS;
   const int n = n0 + tid;
@@ -192,8 +196,8 @@ __global__ __launch_bounds__(THREADS) void a3_step_kernel(A3Args p) {
     p.done[n] = (uint8_t)(((rp2 - foot_z) < 0.6) || p.in.bad[n]);
 
     // ---- get_obs (root part; motor columns are filled cooperatively below)
-    const double* qpos = p.in.qpos + (size_t)n * nq;
-    const double* qvel = p.in.qvel + (size_t)n * nv;
+    const double* qpos = p.in.qpos + (size_t)n * p.qpos_stride + p.qpos_off - 3;
+    const double* qvel = p.in.qvel + (size_t)n * p.qvel_stride + p.qvel_off - 3;
     double bq[4] = {qpos[3], qpos[4], qpos[5], qpos[6]};
     double Rb[3][3];
     quat2mat(bq, Rb);
@@ -286,8 +290,19 @@ extern "C" int oly_a3_configure(oly_ctx* ctx, const oly_a3_model* m) {
   return OLY_OK;
 }
 
+int oly_a3_step_strided(oly_ctx* ctx, int N, const oly_a3_inputs* in, const oly_a3_state* st, void* obs,
+                        float* rew6, float* reward, uint8_t* done, int out_flags, int compact_base,
+                        oly_stream stream);
+
 extern "C" int oly_a3_step(oly_ctx* ctx, int N, const oly_a3_inputs* in, const oly_a3_state* st, void* obs,
                            float* rew6, float* reward, uint8_t* done, int out_flags, oly_stream stream) {
+  return oly_a3_step_strided(ctx, N, in, st, obs, rew6, reward, done, out_flags, 0, stream);
+}
+
+// compact_base != 0: in->qpos is [N,4] (the base quaternion qpos[3:7]) and in->qvel [N,3] (qvel[3:6])
+int oly_a3_step_strided(oly_ctx* ctx, int N, const oly_a3_inputs* in, const oly_a3_state* st, void* obs,
+                        float* rew6, float* reward, uint8_t* done, int out_flags, int compact_base,
+                        oly_stream stream) {
   if (!ctx) return OLY_EINVAL;
   if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_step before oly_a3_configure");
   if (N < 0 || !in || !st) OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_step: bad argument");
@@ -302,6 +317,8 @@ extern "C" int oly_a3_step(oly_ctx* ctx, int N, const oly_a3_inputs* in, const o
   A3Args a;
   a.md = ctx->a3_dev; a.N = N; a.in = *in; a.st = *st; a.obs = obs; a.rew6 = rew6; a.reward = reward;
   a.done = done;
+  a.qpos_stride = compact_base ? 4 : ctx->a3_host.nq; a.qpos_off = compact_base ? 0 : 3;
+  a.qvel_stride = compact_base ? 3 : ctx->a3_host.nv; a.qvel_off = compact_base ? 0 : 3;
   const size_t lds = ((out_flags & OLY_OUT_OBS_F64) ? sizeof(double) : sizeof(float)) * THREADS * ctx->a3_host.n_obs;
   dim3 grid((N + THREADS - 1) / THREADS), block(THREADS);
   if (out_flags & OLY_OUT_OBS_F64)

@@ -19,6 +19,10 @@ namespace {
 constexpr int THREADS = 256;
 constexpr int SLOTS = 16;
 
+// CSR = false: padded slots, contact i of env n at [n, i] of geom1 / geom2 / force6 / pos_z.
+// CSR = true:  compact records (oly_contact_record, 64 B), contact i of env n at rec[coff[n] + i]: what the
+//              host batcher ships when only the used slots cross PCIe; geom1 = coff, force6 = the records.
+template <bool CSR>
 __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, int C,
                                                           const int* __restrict__ ncon,
                                                           const int* __restrict__ geom1,
@@ -50,20 +54,21 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
       bool is_r = false, is_l = false;
       double nrm = 0.0, pz = 0.0;
       if (env_ok && i < nc) {
-        const size_t e = (size_t)n * C + i;
-        const int g1 = geom1[e], g2 = geom2[e];
+        const size_t e = CSR ? (size_t)geom1[n] + i : (size_t)n * C + i;
+        const oly_contact_record* rec = reinterpret_cast<const oly_contact_record*>(force6) + e;
+        const int g1 = CSR ? rec->geom1 : geom1[e], g2 = CSR ? rec->geom2 : geom2[e];
         if (g1 >= 0 && g1 < cd.ngeom && g2 >= 0 && g2 < cd.ngeom) {
           const int b1 = cd.geom_bodyid[g1], b2 = cd.geom_bodyid[g2];
           is_r = (b1 == cd.floor_body) && (b2 == cd.rfoot_body);
           is_l = (b1 == cd.floor_body) && (b2 == cd.lfoot_body);
         }
         if (is_r || is_l) {
-          const double* f = force6 + e * 6;
+          const double* f = CSR ? rec->force6 : force6 + e * 6;
           double s = 0.0;
 #pragma unroll
           for (int k = 0; k < 6; ++k) s += f[k] * f[k];
           nrm = sqrt(s);
-          pz = pos_z[e];
+          pz = CSR ? rec->pos_z : pos_z[e];
         }
       }
       // ballots over the whole wave, then this env's 16-bit field
@@ -230,10 +235,30 @@ extern "C" int oly_contact_reduce(oly_ctx* ctx, int N, int C, const int32_t* nco
   long waves = ((long)N + 3) / 4;
   long blocks = (waves * 64 + THREADS - 1) / THREADS;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(contact_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->contact,
+  hipLaunchKernelGGL(contact_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->contact,
                      N, C, ncon, geom1, geom2, force6, pos_z, n_r, n_l, idx_r, idx_l, grf_r, grf_l, min_z,
                      bad);
   OLY_LAUNCH_CHECK(ctx, "contact_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_contact_reduce_csr(oly_ctx* ctx, int N, int C, const int32_t* ncon, const int32_t* coff,
+                                      const oly_contact_record* records, int32_t* n_r, int32_t* n_l,
+                                      double* grf_r, double* grf_l, double* min_z, uint8_t* bad,
+                                      oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->contact_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_contact_reduce_csr before oly_contact_configure");
+  if (N < 0 || C <= 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_contact_reduce_csr: bad N or C");
+  if (N == 0) return OLY_OK;
+  if (!ncon || !coff || !records || !n_r || !n_l || !grf_r || !grf_l || !min_z || !bad)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_contact_reduce_csr: NULL pointer");
+  long waves = ((long)N + 3) / 4;
+  long blocks = (waves * 64 + THREADS - 1) / THREADS;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(contact_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->contact,
+                     N, C, ncon, coff, nullptr, reinterpret_cast<const double*>(records), nullptr, n_r, n_l,
+                     nullptr, nullptr, grf_r, grf_l, min_z, bad);
+  OLY_LAUNCH_CHECK(ctx, "contact_kernel<csr>");
   return OLY_OK;
 }
 

@@ -97,6 +97,9 @@ struct oly_ctx {
 
 // K7's finishing step over ctx->stats_ws[0 .. 2*nblocks) -> (n, sum, sumsq); used by K6's fused statistics
 int oly_stats_finish(oly_ctx* ctx, int nblocks, int64_t n, double* stats3_out, oly_stream stream);
+// oly_a3_step over the host batcher's compact staging (compact_base: qpos = [N,4] base quaternion, qvel = [N,3])
+int oly_a3_step_strided(oly_ctx* ctx, int N, const oly_a3_inputs* in, const oly_a3_state* st, void* obs, float* rew6,
+                        float* reward, uint8_t* done, int out_flags, int compact_base, oly_stream stream);
 
 static inline hipStream_t oly_s(oly_stream s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -67,6 +67,11 @@ class A3Blocks(C.Structure):
     _fields_ = [("K", C.c_int32), ("C", C.c_int32)] + [(n, vp) for n in A3_BLOCK_F64 + A3_BLOCK_TAIL]
 
 
+class ContactRecord(C.Structure):
+    """oly_contact_record (64 bytes): one used contact slot of the compact (CSR) contact form."""
+    _fields_ = [("geom1", C.c_int32), ("geom2", C.c_int32), ("force6", C.c_double * 6), ("pos_z", C.c_double)]
+
+
 class A3ResetRecord(C.Structure):
     """oly_a3_reset_record: one pre-drawn WalkingTask.reset (656 bytes)."""
     _fields_ = [("mode", C.c_int32), ("phase", C.c_int32), ("seq_len", C.c_int32), ("pad", C.c_int32),
@@ -142,6 +147,7 @@ SIGNATURES = {
     "oly_a3_batcher_step": (C.c_int, [vp, vp, C.POINTER(A3State), vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "oly_a3_batcher_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "oly_a3_batcher_set_mapped": (C.c_int, [vp, C.c_int]),
+    "oly_a3_batcher_set_compact": (C.c_int, [vp, C.c_int]),
     "oly_traj_upload": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "oly_traj_reset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "oly_traj_next": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
@@ -151,6 +157,7 @@ SIGNATURES = {
     "oly_expert_dataset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "oly_contact_configure": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
     "oly_contact_reduce": (C.c_int, [vp, C.c_int, C.c_int] + [vp] * 13 + [vp]),
+    "oly_contact_reduce_csr": (C.c_int, [vp, C.c_int, C.c_int] + [vp] * 10),
     "oly_a3_configure": (C.c_int, [vp, C.POINTER(A3Model)]),
     "oly_a3_step": (C.c_int, [vp, C.c_int, C.POINTER(A3Inputs), C.POINTER(A3State), vp, vp, vp, vp,
                               C.c_int, vp]),

@@ -165,6 +165,12 @@ class A3HostBatcher:
         check(self.eng.ctx.handle, lib().oly_a3_batcher_set_mapped(self._h, int(on)), "oly_a3_batcher_set_mapped")
         return self
 
+    def set_compact(self, on=True):
+        """Only what the kernels read crosses PCIe (oly_a3_batcher_set_compact): the seven base numbers of
+        qpos / qvel, the actuator / site rows and the USED contact slots; same results."""
+        check(self.eng.ctx.handle, lib().oly_a3_batcher_set_compact(self._h, int(bool(on))), "oly_a3_batcher_set_compact")
+        return self
+
     def slots(self, env):
         """numpy views of env's pinned staging rows (write a reset state here, then upload())."""
         rb = _abi.A3Readback()

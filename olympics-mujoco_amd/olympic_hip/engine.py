@@ -239,6 +239,25 @@ class Engine:
                       ptr(o["grf_l"]), ptr(o["min_z"]), ptr(o["bad"]), self._s())
         return o
 
+    def contact_reduce_csr(self, ncon, coff, records, max_contacts):
+        """oly_contact_reduce over compact storage: env n's contacts are records[coff[n] : coff[n] + min(ncon[n], C)];
+        records: uint8 device tensor holding oly_contact_record's (64 bytes each)."""
+        if not self.contact_ok:
+            raise OlyError("contact_reduce_csr before contact_configure")
+        dv = self.device
+        N = int(ncon.shape[0])
+        _req(ncon, "ncon", (N,), torch.int32, dv)
+        _req(coff, "coff", (N,), torch.int32, dv)
+        _req(records, "records", records.shape, torch.uint8, dv)
+        if records.dim() != 1 or records.numel() % C.sizeof(_abi.ContactRecord):
+            raise OlyError("records: expected a flat uint8 tensor of whole 64-byte records")
+        o = dict(n_r=self._new((N,), torch.int32), n_l=self._new((N,), torch.int32),
+                 grf_r=self._new((N,), torch.float64), grf_l=self._new((N,), torch.float64),
+                 min_z=self._new((N,), torch.float64), bad=self._new((N,), torch.uint8))
+        self.ctx.call("oly_contact_reduce_csr", N, int(max_contacts), ptr(ncon), ptr(coff), ptr(records), ptr(o["n_r"]),
+                      ptr(o["n_l"]), ptr(o["grf_r"]), ptr(o["grf_l"]), ptr(o["min_z"]), ptr(o["bad"]), self._s())
+        return o
+
     # -------------------------------------------------------------- K2
     _A3_IN = dict(qpos=("nq", torch.float64), qvel=("nv", torch.float64), act_len=("nu", torch.float64),
                   act_vel=("nu", torch.float64), lf_pos=(3, torch.float64), rf_pos=(3, torch.float64),

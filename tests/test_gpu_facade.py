@@ -666,8 +666,8 @@ def test_examples_run(tmp_path):
     assert r.returncode == 0 and "discriminator reward mean" in r.stdout and " std 1.0000" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("mapped", [False, True], ids=["copies", "mapped"])
-def test_a3_host_batcher_replays_golden_sequence(golden, mapped):
+@pytest.mark.parametrize("mapped,compact", [(False, False), (True, False), (True, True)], ids=["copies", "mapped", "compact"])
+def test_a3_host_batcher_replays_golden_sequence(golden, mapped, compact):
     """oly_a3_batcher_*: host thread pool + pinned staging + one H2D copy + K3 + K2 per step.  A
     Python physics callback plays the fixture's recorded readback (what a MuJoCo callback would
     write after its PD substeps) and checks the PD targets it receives; results equal the
@@ -696,7 +696,7 @@ def test_a3_host_batcher_replays_golden_sequence(golden, mapped):
                   "head_pos", "geom1", "geom2", "force6", "cpos_z"):
             slots[n][...] = g[n][e, k]
         slots["ncon"][0] = g["ncon"][e, k]
-    b = A3HostBatcher(eng, E, C_, physics, n_threads=2, obs_f64=True).set_mapped(mapped)
+    b = A3HostBatcher(eng, E, C_, physics, n_threads=2, obs_f64=True).set_mapped(mapped).set_compact(compact)
     act = torch.zeros((E, 12), device="cuda")
     for k in range(K):
         step_no["k"] = k

@@ -541,6 +541,35 @@ def test_contacts_shapes(eng, oracle, N, C):
         assert np.array_equal(host(o[k]), e[k]), k
 
 
+@pytest.mark.parametrize("N,C", [(1, 16), (130, 16), (4096, 16), (777, 5), (300, 40)])
+def test_contact_reduce_csr_equals_the_padded_form(eng, N, C):
+    """oly_contact_reduce_csr (compact 64-byte records behind per-env offsets: what the RL host batcher ships in
+    compact mode) against oly_contact_reduce on the same contacts in padded slots: counts, force sums, minimum
+    height and the bad flag bit-identical, including environments with more contacts than the C slots."""
+    import ctypes
+    rng = np.random.default_rng(N + C)
+    ncon = rng.integers(0, C + 3, N).astype(np.int32)                # some beyond C: bad, truncated to C
+    ncon[rng.uniform(size=N) < 0.1] = 0
+    g1 = rng.choice([0, 0, 0, 3], (N, C)).astype(np.int32)
+    g2 = rng.choice([7, 8, 10, 2, 99, -1], (N, C)).astype(np.int32)
+    f6 = rng.normal(0, 100, (N, C, 6))
+    pz = rng.normal(0, 0.05, (N, C))
+    eng.contact_configure(np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32), 0, 7, 10)
+    ref = eng.contact_reduce(dev(ncon), dev(g1), dev(g2), dev(f6), dev(pz), want_idx=False)
+    used = np.clip(ncon, 0, C)
+    coff = (np.cumsum(used) - used).astype(np.int32)
+    rec = np.zeros(int(used.sum()) + 1, np.dtype([("g1", "<i4"), ("g2", "<i4"), ("f", "<f8", 6), ("z", "<f8")]))
+    assert rec.dtype.itemsize == ctypes.sizeof(_abi.ContactRecord) == 64
+    for n in range(N):
+        k = used[n]
+        sl = slice(coff[n], coff[n] + k)
+        rec["g1"][sl], rec["g2"][sl], rec["f"][sl], rec["z"][sl] = g1[n, :k], g2[n, :k], f6[n, :k], pz[n, :k]
+    got = eng.contact_reduce_csr(dev(ncon), dev(coff), dev(rec.view(np.uint8).reshape(-1)), C)
+    for k in ("n_r", "n_l", "grf_r", "grf_l", "min_z", "bad"):
+        assert torch.equal(got[k], ref[k]), k
+    assert int(ref["bad"].sum()) > 0 or N == 1
+
+
 def test_contacts_more_than_the_staged_slots(eng):
     """ncon > C (or < 0): the surplus contacts were never staged, so the environment is flagged as
     a bad collision instead of being reduced as if it had C contacts; the staged slots

@@ -50,15 +50,17 @@ def main():
     a3 = specs.A3Spec(mass=41.5)
     eng.a3_configure(a3, np.zeros((4, a3.period)))
     eng.contact_configure(np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32), 0, 7, 10)
-    for N, mapped in ((4096, 0), (4096, 1), (32768, 0), (32768, 1)):
-        b = A3HostBatcher(eng, N, 16, None, n_threads=16).set_mapped(mapped)
+    for N, mapped, compact in ((4096, 0, 0), (4096, 1, 0), (4096, 1, 1), (32768, 0, 0), (32768, 1, 1)):
+        b = A3HostBatcher(eng, N, 16, None, n_threads=16).set_mapped(mapped).set_compact(compact)
         rng = np.random.default_rng(0)
-        for e in range(0, N, max(1, N // 64)):                  # a few populated envs; the rest stay zero
+        nc_all = np.minimum(rng.poisson(4, N), 16)                 # config 3: ncon ~ Poisson(4) clipped to the slots
+        for e in range(N):
             sl = b.slots(e)
             sl["root_quat"][:] = [1, 0, 0, 0]
-            sl["ncon"][0] = 3
-            sl["geom2"][:3] = [7, 11, 8]
-            sl["force6"][:3] = rng.normal(0, 100, (3, 6))
+            k_ = int(nc_all[e])
+            sl["ncon"][0] = k_
+            sl["geom2"][:k_] = 7 + 3 * (np.arange(k_) % 2)            # right / left foot alternately
+            sl["force6"][:k_] = rng.normal(0, 100, (k_, 6))
         z = lambda dt, *sh: torch.zeros((N,) + sh, dtype=dt, device="cuda")
         st = dict(phase=z(torch.int32), t1=z(torch.int32), t2=z(torch.int32) + 1, reached_frames=z(torch.int32),
                   target_reached=z(torch.uint8), mode=z(torch.int32) + 2, seq_len=z(torch.int32) + 20,
@@ -76,7 +78,7 @@ def main():
                 acc[k] += v
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out[f"A3_N{N}_threads16" + ("_mapped" if mapped else "")] = dict(us_per_vec_step=dt / K * 1e6, env_steps_per_s=N * K / dt,
+        out[f"A3_N{N}_threads16" + ("_mapped" if mapped else "") + ("_compact" if compact else "")] = dict(us_per_vec_step=dt / K * 1e6, env_steps_per_s=N * K / dt,
                                          split_us={k: v / K * 1e6 for k, v in acc.items()},
                                          pcie_bytes_per_step=N * (8 * 12 + 1788))
         b.close()
