@@ -257,7 +257,34 @@ def per_step_block(rk, eng, spec, N):
     out["h1_graph_of_10_steps"] = {"us_per_vec_step": us10, "env_steps_per_s": N / (us10 * 1e-6),
                                    "launches_per_step": 1, "note": "ten consecutive vec steps per graph replay"}
     out["config3_a3_ppo_sampling"] = config3_sampling(N, rk.dev)
+    try:
+        out["h1_through_the_host_batcher"] = h1_host_batcher(eng, spec, N, qpos_h, qvel_h, act)
+    except Exception as e:                                   # never take the headline line down
+        out["h1_through_the_host_batcher"] = {"error": repr(e)[:200]}
     return out
+
+
+def h1_host_batcher(eng, spec, N, qpos_h, qvel_h, act, reps=300):
+    """PCIe INCLUDED (never `value`): the C++ host batcher's vec step - controls to the host, the physics
+    stand-in (qpos += dt * qvel) on the worker threads, state rows to the device, K1 - with mapped staging."""
+    import torch
+    from olympic_hip.batcher import HostBatcher
+    b = HostBatcher(eng, N, n_threads=min(16, os.cpu_count() or 1), dt=0.01).set_mapped(True)
+    try:
+        b.qpos[:], b.qvel[:] = qpos_h[0], qvel_h[0]
+        a = act[0].contiguous()
+        for _ in range(20):
+            b.step(a)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            b.step(a)
+        torch.cuda.synchronize()
+        us = 1e6 * (time.perf_counter() - t0) / reps
+    finally:
+        b.close()
+    return {"us_per_vec_step": us, "env_steps_per_s": N / (us * 1e-6), "pcie_bytes_per_step": N * 8 * (spec.nq + spec.nv + spec.nu),
+            "note": "host memory in the loop: PCIe- and sync-bound by construction; physics is a kinematic stand-in"}
 
 
 def config3_sampling(N, dev, T=400, reps=3):
