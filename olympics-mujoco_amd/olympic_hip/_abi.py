@@ -179,6 +179,9 @@ SIGNATURES = {
     "oly_disc_standardize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "oly_disc_reparam": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp]),
     "oly_disc_reward": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    "oly_disc_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "oly_disc_pack": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 12),
+    "oly_disc_forward": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int] + [vp] * 12),
     "oly_grf_configure": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     "oly_il_ground_forces": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "oly_rollout_cuts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

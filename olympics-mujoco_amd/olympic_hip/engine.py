@@ -572,6 +572,60 @@ class Engine:
         self.ctx.call("oly_disc_reward", C.c_int64(logits.numel()), ptr(logits), ptr(reward), self._s())
         return reward
 
+    # -------------------------------------------------------------- K12 (fused discriminator forward)
+    def disc_pack(self, enc_w0, enc_b0, enc_w1, enc_b1, mu_w, mu_b, lv_w, lv_b, dec_w, dec_b, packed=None):
+        """torch parameters of the variational discriminator in -> 256 -> 128 -> (mu, logvar) 128 -> 1
+        -> packed operand stream of oly_disc_forward."""
+        from ._ffi import lib
+        f32, dv = torch.float32, self.device
+        H, in_dim = (int(v) for v in enc_w0.shape)
+        E, Z = int(enc_w1.shape[0]), int(mu_w.shape[0])
+        n = int(lib().oly_disc_packed_floats(in_dim, H, E, Z))
+        if n < 0:
+            raise OlyError(f"disc_pack: unsupported discriminator shape {in_dim} -> {H} -> {E} -> {Z} -> 1")
+        for t, name, shape in ((enc_w0, "enc_w0", (H, in_dim)), (enc_b0, "enc_b0", (H,)), (enc_w1, "enc_w1", (E, H)),
+                               (enc_b1, "enc_b1", (E,)), (mu_w, "mu_w", (Z, E)), (mu_b, "mu_b", (Z,)),
+                               (lv_w, "lv_w", (Z, E)), (lv_b, "lv_b", (Z,)), (dec_w, "dec_w", (1, Z)),
+                               (dec_b, "dec_b", (1,))):
+            _req(t, name, shape, f32, dv)
+        packed = _req(packed if packed is not None else self._new((n,), f32), "packed", (n,), f32, dv)
+        self.ctx.call("oly_disc_pack", in_dim, H, E, Z, ptr(enc_w0), ptr(enc_b0), ptr(enc_w1), ptr(enc_b1), ptr(mu_w),
+                      ptr(mu_b), ptr(lv_w), ptr(lv_b), ptr(dec_w), ptr(dec_b), ptr(packed), self._s())
+        return packed
+
+    def disc_forward(self, x, packed, mask=None, mean=None, std=None, colstats=None, eps=None, want=("reward",),
+                     out=None):
+        """make_discrim_reward for x [B,Dx] f32 in one launch.  want: any of reward / logits / mu / logvar.
+        Standardisation from mean / std [D] f64, or from the running colstats [3,D] of col_stats, or none."""
+        from ._ffi import lib
+        f32, dv = torch.float32, self.device
+        B, Dx = (int(v) for v in x.shape)
+        D = Dx if mask is None else int(mask.shape[0])
+        _req(x, "x", (B, Dx), f32, dv)
+        _req(mask, "mask", (D,), torch.int32, dv, optional=True)
+        if (mean is None) != (std is None) or (mean is not None and colstats is not None):
+            raise OlyError("disc_forward: give mean and std together, or colstats, or neither")
+        _req(colstats, "colstats", (3, D), torch.float64, dv, optional=True)
+        _req(mean, "mean", (D,), torch.float64, dv, optional=True)
+        _req(std, "std", (D,), torch.float64, dv, optional=True)
+        cache = self.__dict__.setdefault("_disc_sizes", {})
+        if D not in cache:
+            cache[D] = int(lib().oly_disc_packed_floats(D, 256, 128, 128))
+        _req(packed, "packed", (cache[D],), f32, dv)        # the raw pointer carries no length
+        _req(eps, "eps", (B, 128), f32, dv, optional=True)
+        shapes = dict(reward=(B,), logits=(B,), mu=(B, 128), logvar=(B, 128))
+        out = dict(out or {})
+        for k in want:
+            if k not in shapes:
+                raise OlyError(f"disc_forward: unknown output {k!r}")
+            out[k] = _req(out.get(k) if out.get(k) is not None else self._new(shapes[k], f32), k, shapes[k], f32, dv)
+        if not want:
+            raise OlyError("disc_forward: no output requested")
+        g = lambda k: ptr(out[k]) if k in want else None
+        self.ctx.call("oly_disc_forward", C.c_int64(B), Dx, D, ptr(x), ptr(mask), ptr(mean), ptr(std), ptr(colstats),
+                      ptr(packed), ptr(eps), g("reward"), g("logits"), g("mu"), g("logvar"), self._s())
+        return out
+
     # -------------------------------------------------------------- K9
     def signed_perm(self, x, src, sign, out=None):
         B, D = int(x.shape[0]), int(x.shape[1])

@@ -5,10 +5,12 @@
   GAIL.make_discrim_reward     imitation_lib/imitation/gail_TRPO.py:320-327
   prepare_discrim_inputs       gail_TRPO.py:297-313 (state mask)
 
-The MLP GEMMs (32->256->128->(128,128)->1 for UnitreeH1, examples/imitation_learning/
-utils.py:151-161) run in PyTorch-ROCm (MFMA); mask + standardise, the reparameterisation and
-the reward epilogue are HIP kernels; the statistics live on the device (no CPU bounce as in
-networks.py:70).  The reparameterisation noise is an INPUT so results are reproducible.
+The reward path (mask + standardise, 32->256->128->(128,128)->1 for UnitreeH1, examples/
+imitation_learning/utils.py:151-161, reparameterisation, reward formula) is ONE launch on the f32
+matrix cores (K12, oly_disc_forward) after the statistics update (oly_col_stats); the statistics
+live on the device (no CPU bounce as in networks.py:70).  The discriminator's TRAINING forward /
+backward stays in PyTorch-ROCm.  The reparameterisation noise is an INPUT so results are
+reproducible.
 """
 import numpy as np
 import torch
@@ -83,20 +85,68 @@ class DiscriminatorReward:
                                                                    device=engine.device)
         dim = net.encoder[0].in_features
         self.stand = standardizer or DeviceStandardizer(engine, dim)
+        self._packed, self._packed_ver = None, None
+        self._identity_mask = state_mask is not None and np.array_equal(np.asarray(state_mask), np.arange(dim))
+
+    # ---- fused path (K12)
+    def _params(self):
+        n = self.net
+        return [n.encoder[0].weight, n.encoder[0].bias, n.encoder[1].weight, n.encoder[1].bias, n.mu_out.weight,
+                n.mu_out.bias, n.logvar_out.weight, n.logvar_out.bias, n.decoder.weight, n.decoder.bias]
+
+    @property
+    def fused(self):
+        n = self.net
+        return (len(n.encoder) == 2 and n.encoder[0].in_features <= 64 and n.encoder[0].out_features == 256
+                and n.encoder[1].out_features == 128 and n.mu_out.out_features == 128)
+
+    def packed(self):
+        """The MFMA operand stream of the current weights; re-packed (one launch) whenever an optimiser step
+        or a load has touched a parameter."""
+        ps = self._params()
+        ver = tuple((p.data_ptr(), p._version) for p in ps)
+        if ver != self._packed_ver:
+            self._packed = self.eng.disc_pack(*[p.detach().to(torch.float32).contiguous() for p in ps],
+                                              packed=self._packed)
+            self._packed_ver = ver
+        return self._packed
+
+    def _update_statistics(self, x):
+        """Standardizer.forward's update_mean_std on the masked batch (networks.py:70,76-81)."""
+        whole = self.mask is None or (self._identity_mask and x.shape[1] == self.mask.numel())
+        self.stand.update_mean_std(x if whole else x[:, self.mask.long()].contiguous())
+        return None if whole else self.mask
 
     @torch.no_grad()
-    def logits(self, x, eps):
+    def forward(self, x, eps, want=("reward",), out=None):
+        """Statistics update + oly_disc_forward: any of reward / logits / mu / logvar for x [B,Dx]."""
+        mask = self._update_statistics(x)
+        return self.eng.disc_forward(x, self.packed(), mask=mask, colstats=self.stand.colstats, eps=eps, want=want,
+                                     out=out)
+
+    # ---- layer-by-layer path (PyTorch GEMMs + K8 kernels): other network shapes, and the cross-check
+    @torch.no_grad()
+    def logits_unfused(self, x, eps):
         xs = self.stand.forward(x, self.mask)
         mu, logvar = self.net.encode(xs)
         z = self.eng.disc_reparam(mu.contiguous(), logvar.contiguous(), eps)
         return self.net.decoder(z).reshape(-1).contiguous(), mu, logvar
 
     @torch.no_grad()
+    def logits(self, x, eps):
+        if not self.fused:
+            return self.logits_unfused(x, eps)
+        o = self.forward(x, eps, want=("logits", "mu", "logvar"))
+        return o["logits"], o["mu"], o["logvar"]
+
+    @torch.no_grad()
     def __call__(self, x, eps=None, generator=None):
         if eps is None:
             eps = torch.randn((x.shape[0], self.net.mu_out.out_features), dtype=torch.float32,
                               device=x.device, generator=generator)
-        d, _, _ = self.logits(x, eps)
+        if self.fused:
+            return self.forward(x, eps)["reward"]
+        d, _, _ = self.logits_unfused(x, eps)
         return self.eng.disc_reward(d)
 
 

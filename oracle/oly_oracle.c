@@ -850,6 +850,111 @@ int oly_disc_reward_cpu(int64_t B, const float* logits, float* reward) {
   return OLY_OK;
 }
 
+/* ============================================================================== K12 */
+
+/* exp in float32 from fma / rint / exponent arithmetic only (the same operations, in the same order, as
+   exp32 of csrc/k12_disc_forward.hip, so both return the same bits): n = rint(x log2 e), r = x - n ln2 by the
+   two-constant Cody-Waite split, e^r = 1 + (r + r^2 P(r)) with a degree-5 minimax P, scaled by 2^n in two
+   exact steps.  <= 1 ulp of exp (test_oracle_golden.py::test_exp32_against_fp64_exp), the error class of
+   torch's float32 exp that reparameterize (networks.py:21-24) calls.                                     */
+static float oly_pow2i(int e) {
+  union { uint32_t u; float f; } c;
+  c.u = (uint32_t)(e + 127) << 23;
+  return c.f;
+}
+float oly_exp32_cpu(float x) {
+  if (x != x) return x;
+  if (x > 88.72283935546875f) return INFINITY;
+  if (x < -103.97208404541016f) return 0.0f;
+  const float n = rintf(x * 1.4426950408889634f);
+  float r = fmaf(n, -0.693145751953125f, x);
+  r = fmaf(n, -1.428606765330187045e-06f, r);
+  float u = 0.000198527617612853646278381f;
+  u = fmaf(u, r, 0.00139304355252534151077271f);
+  u = fmaf(u, r, 0.00833336077630519866943359f);
+  u = fmaf(u, r, 0.0416664853692054748535156f);
+  u = fmaf(u, r, 0.166666671633720397949219f);
+  u = fmaf(u, r, 0.5f);
+  u = 1.0f + fmaf(r * r, u, r);
+  const int q = (int)n, q1 = q >> 1;
+  return (u * oly_pow2i(q1)) * oly_pow2i(q - q1);
+}
+
+/* GAIL.make_discrim_reward (gail_TRPO.py:320-327) through VAIL.discrim_output (vail_TRPO.py:18-21),
+   prepare_discrim_inputs (gail_TRPO.py:297-313), VariationalNet.forward (networks.py:258-284):
+   Standardizer.forward's (x - mean) / std (networks.py:68-74; statistics given), encoder in -> 256 -> 128 with
+   ReLU after both layers (examples/imitation_learning/utils.py:157-159), mu / logvar heads, reparameterize
+   (networks.py:21-24) with the caller's eps, decoder 128 -> 1, reward formula.  Linear layers as the f32
+   matrix cores evaluate them: fmaf chain over k ascending from 0, bias after the chain; the decoder is the
+   chain over k < 64 plus the chain over 64 <= k < 128, then the bias.  The reward takes numpy's float32
+   steps with each transcendental correctly rounded (through fp64).
+   outputs (each may be NULL): reward [B], logits [B], mu [B,128], logvar [B,128].                       */
+int oly_disc_forward_cpu(int64_t B, int Dx, int D, const float* x, const int32_t* mask, const double* mean,
+                         const double* sd, const double* colstats, const float* enc_w0, const float* enc_b0, const float* enc_w1,
+                         const float* enc_b1, const float* mu_w, const float* mu_b, const float* lv_w,
+                         const float* lv_b, const float* dec_w, const float* dec_b, const float* eps,
+                         float* reward, float* logits, float* mu_out, float* logvar_out) {
+  enum { H1 = 256, H2 = 128, Z = 128 };
+  if (D <= 0 || D > 64 || (!mask && D != Dx) || ((mean == NULL) != (sd == NULL)) || (mean && colstats)) return OLY_EINVAL;
+  double cmean[64], csd[64];
+  if (colstats) {
+    /* Standardizer.update_mean_std (networks.py:76-81) on the running sums; _sumsq and _count start at
+       1e-2 (networks.py:54-56), the variance is floored at 1e-2                                        */
+    for (int k = 0; k < D; ++k) {
+      const double cnt = colstats[k] + 1e-2;
+      cmean[k] = colstats[D + k] / cnt;
+      csd[k] = sqrt(fmax((colstats[2 * D + k] + 1e-2) / cnt - cmean[k] * cmean[k], 1e-2));
+    }
+    mean = cmean;
+    sd = csd;
+  }
+  for (int64_t n = 0; n < B; ++n) {
+    float xs[64], h1[H1], h2[H2], z[Z];
+    for (int k = 0; k < D; ++k) {
+      const int c = mask ? mask[k] : k;
+      if (c < 0 || c >= Dx) return OLY_ERANGE;
+      float v = x[(size_t)n * Dx + c];
+      if (mean) v = (float)(((double)v - mean[k]) / sd[k]);
+      xs[k] = v;
+    }
+    for (int j = 0; j < H1; ++j) {
+      float acc = 0.0f;
+      for (int k = 0; k < D; ++k) acc = fmaf(xs[k], enc_w0[(size_t)j * D + k], acc);
+      const float v = acc + enc_b0[j];
+      h1[j] = (v > 0.0f || v != v) ? v : 0.0f;
+    }
+    for (int j = 0; j < H2; ++j) {
+      float acc = 0.0f;
+      for (int k = 0; k < H1; ++k) acc = fmaf(h1[k], enc_w1[(size_t)j * H1 + k], acc);
+      const float v = acc + enc_b1[j];
+      h2[j] = (v > 0.0f || v != v) ? v : 0.0f;
+    }
+    for (int j = 0; j < Z; ++j) {
+      float am = 0.0f, al = 0.0f;
+      for (int k = 0; k < H2; ++k) {
+        am = fmaf(h2[k], mu_w[(size_t)j * H2 + k], am);
+        al = fmaf(h2[k], lv_w[(size_t)j * H2 + k], al);
+      }
+      const float m = am + mu_b[j], lv = al + lv_b[j];
+      z[j] = eps ? m + oly_exp32_cpu(lv / 2.0f) * eps[(size_t)n * Z + j] : m;
+      if (mu_out) mu_out[(size_t)n * Z + j] = m;
+      if (logvar_out) logvar_out[(size_t)n * Z + j] = lv;
+    }
+    float lo = 0.0f, hi = 0.0f;
+    for (int k = 0; k < 64; ++k) lo = fmaf(z[k], dec_w[k], lo);
+    for (int k = 64; k < 128; ++k) hi = fmaf(z[k], dec_w[k], hi);
+    const float d = (lo + hi) + dec_b[0];
+    if (logits) logits[n] = d;
+    if (reward) {
+      const float e = (float)exp(-(double)d);
+      const float p = 1.0f / (1.0f + e);
+      const float q = 1.0f - p + 1e-8f;
+      reward[n] = -(float)log((double)q);
+    }
+  }
+  return OLY_OK;
+}
+
 /* Normalize._obfilt, rl/envs/normalize.py:139-147 (obs f32 in, statistics f64). */
 int oly_obs_filter_cpu(int B, int D, const float* x, const double* mean, const double* var,
                        double eps, double clip, float* out) {

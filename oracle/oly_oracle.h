@@ -86,6 +86,13 @@ int oly_disc_reparam_cpu(int64_t n, const float* mu, const float* logvar, const 
                          float* z);
 int oly_disc_reward_cpu(int64_t B, const float* logits, float* reward);
 
+float oly_exp32_cpu(float x);
+int oly_disc_forward_cpu(int64_t B, int Dx, int D, const float* x, const int32_t* mask, const double* mean,
+                         const double* sd, const double* colstats, const float* enc_w0, const float* enc_b0, const float* enc_w1,
+                         const float* enc_b1, const float* mu_w, const float* mu_b, const float* lv_w,
+                         const float* lv_b, const float* dec_w, const float* dec_b, const float* eps,
+                         float* reward, float* logits, float* mu_out, float* logvar_out);
+
 int oly_il_ground_forces_cpu(int ngeom, const int32_t* geom_group, int n_pairs, const int32_t* pair_a,
                              const int32_t* pair_b, int W, int N, int C, const int32_t* ncon,
                              const int32_t* geom1, const int32_t* geom2, const double* force6,

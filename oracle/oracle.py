@@ -309,6 +309,37 @@ def disc_reward(logits):
     return r
 
 
+def exp32(x):
+    """The float32 exp of the fused discriminator (K12), elementwise."""
+    L = lib()
+    L.oly_exp32_cpu.restype, L.oly_exp32_cpu.argtypes = C.c_float, [C.c_float]
+    x = np.asarray(x, np.float32)
+    return np.array([L.oly_exp32_cpu(float(v)) for v in x.reshape(-1)], np.float32).reshape(x.shape)
+
+
+def disc_forward(x, weights, mask=None, mean=None, std=None, eps=None, colstats=None):
+    """make_discrim_reward of the variational discriminator as oly_disc_forward evaluates it.
+    weights: dict enc_w0, enc_b0, enc_w1, enc_b1, mu_w, mu_b, lv_w, lv_b, dec_w, dec_b (torch layouts).
+    -> dict reward [B], logits [B], mu [B,128], logvar [B,128]."""
+    x = _c(x, np.float32)
+    B, Dx = x.shape
+    mask = _c(mask, np.int32)
+    D = Dx if mask is None else len(mask)
+    w = {k: _c(weights[k], np.float32) for k in ("enc_w0", "enc_b0", "enc_w1", "enc_b1", "mu_w", "mu_b", "lv_w", "lv_b",
+                                                 "dec_w", "dec_b")}
+    assert w["enc_w0"].shape == (256, D) and w["enc_w1"].shape == (128, 256) and w["mu_w"].shape == (128, 128)
+    assert w["lv_w"].shape == (128, 128) and w["dec_w"].size == 128
+    eps = _c(eps, np.float32)
+    assert eps is None or eps.shape == (B, 128)
+    out = dict(reward=np.empty(B, np.float32), logits=np.empty(B, np.float32), mu=np.empty((B, 128), np.float32),
+               logvar=np.empty((B, 128), np.float32))
+    _chk(lib().oly_disc_forward_cpu(C.c_int64(B), Dx, D, _p(x), _p(mask), _p(_c(mean, np.float64)), _p(_c(std, np.float64)),
+                                    _p(_c(colstats, np.float64)), _p(w["enc_w0"]), _p(w["enc_b0"]), _p(w["enc_w1"]), _p(w["enc_b1"]), _p(w["mu_w"]),
+                                    _p(w["mu_b"]), _p(w["lv_w"]), _p(w["lv_b"]), _p(w["dec_w"]), _p(w["dec_b"]), _p(eps),
+                                    _p(out["reward"]), _p(out["logits"]), _p(out["mu"]), _p(out["logvar"])), "disc_forward")
+    return out
+
+
 def obs_filter(x, mean, var, eps=1e-8, clip=10.0):
     x = _c(x, np.float32)
     mean, var = _c(mean, np.float64), _c(var, np.float64)

@@ -465,6 +465,157 @@ def test_vail_reward_end_to_end(eng, golden):
     np.testing.assert_allclose(r[ok], g["reward"][ok], rtol=5e-3, atol=5e-3)
 
 
+# --------------------------------------------------------------------------------- K12
+def _disc_weights(rng, D, scale=1.0):
+    """Random discriminator of the reference's shape; logvar head large enough that exp32 matters."""
+    f = lambda *s: (rng.normal(0, 1, s) * scale).astype(np.float32)
+    return dict(enc_w0=f(256, D) / np.float32(np.sqrt(D)), enc_b0=f(256) * np.float32(0.1),
+                enc_w1=f(128, 256) / np.float32(16), enc_b1=f(128) * np.float32(0.1),
+                mu_w=f(128, 128) / np.float32(11), mu_b=f(128) * np.float32(0.1),
+                lv_w=f(128, 128) / np.float32(11), lv_b=f(128) * np.float32(0.1),
+                dec_w=f(1, 128) / np.float32(11), dec_b=f(1))
+
+
+_DISC_KEYS = ("enc_w0", "enc_b0", "enc_w1", "enc_b1", "mu_w", "mu_b", "lv_w", "lv_b", "dec_w", "dec_b")
+
+
+def _disc_pack(eng, w):
+    return eng.disc_pack(*[dev(w[k]) for k in _DISC_KEYS])
+
+
+@pytest.mark.parametrize("B,Dx,D,stats", [(1, 32, 32, "meanstd"), (31, 32, 32, "colstats"), (32, 32, 32, "none"),
+                                          (33, 32, 32, "meanstd"), (512, 36, 30, "meanstd"), (4099, 32, 32, "colstats"),
+                                          (777, 40, 34, "colstats"), (300, 64, 64, "meanstd"), (65, 7, 5, "none")])
+def test_disc_forward_vs_oracle(eng, oracle, B, Dx, D, stats):
+    """K12 against its oracle twin: every output BIT-EXACT (f32 fma chains on the matrix cores, the fixed
+    exp32, the fp64-rounded reward steps), over ragged tiles, both layer-1 widths, a state mask, the three
+    standardisation modes and the no-noise forward."""
+    rng = np.random.default_rng(B * 131 + D)
+    w = _disc_weights(rng, D)
+    x = rng.normal(0.3, 2.0, (B, Dx)).astype(np.float32)
+    mask = None if D == Dx else np.sort(rng.choice(Dx, D, replace=False)).astype(np.int32)
+    eps = rng.normal(0, 1, (B, 128)).astype(np.float32)
+    kw, okw = {}, {}
+    if stats == "meanstd":
+        mean, std = rng.normal(0.3, 0.2, D), rng.uniform(0.5, 2.5, D)
+        kw, okw = dict(mean=dev(mean), std=dev(std)), dict(mean=mean, std=std)
+    elif stats == "colstats":
+        xm = x if mask is None else x[:, mask]
+        cs = np.stack([np.full(D, float(B)), xm.astype(np.float64).sum(0), (xm.astype(np.float64) ** 2).sum(0)])
+        kw, okw = dict(colstats=dev(cs)), dict(colstats=cs)
+    packed = _disc_pack(eng, w)
+    want = ("reward", "logits", "mu", "logvar")
+    for e in (eps, None):
+        o = eng.disc_forward(dev(x), packed, mask=None if mask is None else dev(mask), eps=None if e is None else dev(e),
+                             want=want, **kw)
+        ref = oracle.disc_forward(x, w, mask=mask, eps=e, **okw)
+        for k in want:
+            assert np.array_equal(host(o[k]), ref[k]), (k, e is None)
+    # outputs are optional and independent: the reward alone equals the reward of the full call
+    r = eng.disc_forward(dev(x), packed, mask=None if mask is None else dev(mask), eps=dev(eps), **kw)["reward"]
+    assert np.array_equal(host(r), oracle.disc_forward(x, w, mask=mask, eps=eps, **okw)["reward"])
+
+
+def test_disc_forward_golden(eng, golden, oracle):
+    """K12 on the reference run of vail_disc.npz (VariationalNet + Standardizer + make_discrim_reward executed
+    by gen_golden.py): logits within the summation-order tolerance of the Linear layers, reward within that
+    plus the stated float32 tolerance of the formula; and the statistics-from-running-sums mode."""
+    g = golden("vail_disc.npz")
+    packed = _disc_pack(eng, g)
+    o = eng.disc_forward(dev(g["x"]), packed, mask=dev(np.arange(32, dtype=np.int32)), mean=dev(g["st_mean"]),
+                         std=dev(g["st_std"]), eps=dev(g["eps"]), want=("reward", "logits", "mu", "logvar"))
+    ref = oracle.disc_forward(g["x"], g, mask=np.arange(32), mean=g["st_mean"], std=g["st_std"], eps=g["eps"])
+    for k in ref:
+        assert np.array_equal(host(o[k]), ref[k]), k
+    d = g["d"].reshape(-1)
+    np.testing.assert_allclose(host(o["mu"]), g["mu"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(host(o["logvar"]), g["logvar"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(host(o["logits"]), d, rtol=2e-5, atol=2e-6)
+    p = 1.0 / (1.0 + np.exp(-d.astype(np.float64)))
+    tol = (2e-6 + 2e-5 * np.abs(d)) + 4 * 2.0 ** -24 / (1 - p + 1e-8) + 4e-7 * np.abs(g["reward"]) + 1e-7
+    assert (np.abs(host(o["reward"]) - g["reward"]) <= tol).all()
+    cs = eng.col_stats(dev(g["x"]))                      # Standardizer.forward: update, then standardise
+    o2 = eng.disc_forward(dev(g["x"]), packed, colstats=cs, eps=dev(g["eps"]), want=("logits",))
+    np.testing.assert_allclose(host(o2["logits"]), d, rtol=1e-4, atol=1e-5)
+    assert np.array_equal(host(o2["logits"]), oracle.disc_forward(g["x"], g, colstats=host(cs), eps=g["eps"])["logits"])
+
+
+def test_disc_forward_edge_values(eng, oracle):
+    """NaN / infinity rows stay confined to their own sample, saturated logits give the clamped rewards
+    (-log(1e-8) and -log(1 + 1e-8) = 0 in float32), a huge logvar overflows like exp does."""
+    rng = np.random.default_rng(5)
+    w = _disc_weights(rng, 32)
+    x = rng.normal(0, 1, (70, 32)).astype(np.float32)
+    x[3, 5], x[40, 0], x[41, 31] = np.nan, np.inf, -1e30
+    eps = rng.normal(0, 1, (70, 128)).astype(np.float32)
+    for scale in (1.0, 60.0):                             # 60: |d| in the hundreds, logvar / 2 beyond +-88
+        ws = dict(w, dec_w=w["dec_w"] * np.float32(scale), lv_w=w["lv_w"] * np.float32(scale))
+        o = eng.disc_forward(dev(x), _disc_pack(eng, ws), eps=dev(eps), want=("reward", "logits", "mu", "logvar"))
+        ref = oracle.disc_forward(x, ws, eps=eps)
+        for k in ref:
+            assert np.array_equal(host(o[k]), ref[k], equal_nan=True), (k, scale)
+        good = np.ones(70, bool)
+        good[[3, 40]] = False
+        assert np.isfinite(host(o["mu"])[good]).all() and np.isnan(host(o["logits"])[3])
+
+
+def test_disc_forward_full_size_properties(eng, oracle):
+    """BASELINE config 4 at full size ([400, 4096] samples through one launch): samples are independent, so
+    (a) any row subset run alone reproduces its rows bit for bit, (b) a row permutation permutes the outputs,
+    (c) 2048 random rows equal the oracle."""
+    rng = np.random.default_rng(11)
+    B = 400 * 4096
+    w = _disc_weights(rng, 32)
+    packed = _disc_pack(eng, w)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((B, 32), device="cuda", generator=g) * 1.5 + 0.2
+    eps = torch.randn((B, 128), device="cuda", generator=g)
+    cs = eng.col_stats(x)
+    want = ("reward", "logits")
+    full = eng.disc_forward(x, packed, colstats=cs, eps=eps, want=want)
+    r, d = host(full["reward"]), host(full["logits"])
+    assert np.isfinite(r).all() and (r >= 0).all()
+    lo, hi = 123 * 32 + 7, 123 * 32 + 7 + 100001                      # an unaligned row range
+    part = eng.disc_forward(x[lo:hi].contiguous(), packed, colstats=cs, eps=eps[lo:hi].contiguous(), want=want)
+    assert np.array_equal(host(part["reward"]), r[lo:hi]) and np.array_equal(host(part["logits"]), d[lo:hi])
+    perm = torch.randperm(B, device="cuda", generator=g)
+    pp = eng.disc_forward(x[perm].contiguous(), packed, colstats=cs, eps=eps[perm].contiguous(), want=want)
+    assert np.array_equal(host(pp["reward"]), r[host(perm)])
+    idx = np.sort(rng.choice(B, 2048, replace=False))
+    ref = oracle.disc_forward(host(x[idx]), w, colstats=host(cs), eps=host(eps[idx]))
+    assert np.array_equal(ref["logits"], d[idx]) and np.array_equal(ref["reward"], r[idx])
+
+
+def test_discriminator_reward_fused_matches_layer_by_layer(eng, golden):
+    """gail.DiscriminatorReward: the fused launch against the PyTorch-GEMM path it replaces (summation order
+    of the Linear layers is the only difference), with the running statistics updated once per call by both,
+    and a re-pack after an optimiser step."""
+    from olympic_hip.gail import DiscriminatorReward, VariationalDiscriminator
+    g = golden("vail_disc.npz")
+    net = VariationalDiscriminator().load_reference_arrays(g).cuda()
+    fused = DiscriminatorReward(eng, net, state_mask=np.arange(32))
+    plain = DiscriminatorReward(eng, net, state_mask=np.arange(32))
+    assert fused.fused
+    x, eps = dev(g["x"]), dev(g["eps"])
+    for it in range(2):                                    # the second call standardises with two batches of statistics
+        r = host(fused(x, eps))
+        d_ref, _, _ = plain.logits_unfused(x, eps)
+        r_ref = host(eng.disc_reward(d_ref))
+        assert np.array_equal(host(fused.stand.colstats), host(plain.stand.colstats))
+        pr = 1.0 / (1.0 + np.exp(-host(d_ref).astype(np.float64)))
+        tol = 2e-5 + 4 * 2.0 ** -24 / (1 - pr + 1e-8) + 4e-7 * np.abs(r_ref) + 1e-7
+        assert (np.abs(r - r_ref) <= tol).all()
+        if it == 0:
+            np.testing.assert_allclose(r, g["reward"], rtol=5e-3, atol=5e-3)
+    with torch.no_grad():
+        net.decoder.bias.add_(0.5)                         # what an optimiser step does: in-place, version bump
+    r2 = host(fused(x, eps))
+    plain.logits_unfused(x, eps)
+    assert np.abs(r2 - r).max() > 1e-3
+    d3, _, _ = plain.logits_unfused(x, eps)                # both standardisers have seen four batches now
+    np.testing.assert_allclose(host(fused.logits(x, eps)[0]), host(d3), rtol=2e-5, atol=5e-6)
+
+
 # --------------------------------------------------------------------------------- K4
 def test_traj_golden(eng, golden):
     g = golden("trajectory.npz")

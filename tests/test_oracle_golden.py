@@ -399,6 +399,60 @@ def test_vail_forward_end_to_end(golden, oracle):
     np.testing.assert_allclose(d.numpy(), g["d"], rtol=1e-3, atol=1e-3)
 
 
+# --------------------------------------------------------------------------------- K12
+def test_exp32_against_fp64_exp(oracle):
+    """The fixed float32 exp of the fused discriminator: <= 1 ulp of exp over the whole range, exact
+    limits, monotone ends (the error class of the torch.exp that reparameterize calls)."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-104.0, 88.7, 60000), rng.normal(0, 2, 60000), rng.normal(0, 0.05, 20000),
+                        [0.0, -0.0, 88.72283, 88.72284, -103.9720, -103.9721, -87.5, 1e-30, -1e-30]]).astype(np.float32)
+    y = oracle.exp32(x)
+    ref = np.exp(x.astype(np.float64))
+    spacing = np.spacing(np.clip(ref, 2.0 ** -149, 3.4e38).astype(np.float32)).astype(np.float64)
+    fin = np.isfinite(y)
+    assert (np.abs(y[fin].astype(np.float64) - ref[fin]) <= 1.0 * spacing[fin]).all()
+    assert (ref[~fin] > 3.4028234e38).all()                            # infinity only where exp overflows float32
+    sp = oracle.exp32(np.array([np.nan, np.inf, -np.inf, 100.0, -120.0], np.float32))
+    assert np.isnan(sp[0]) and sp[1] == np.inf and sp[2] == 0.0 and sp[3] == np.inf and sp[4] == 0.0
+    assert oracle.exp32(np.zeros(1, np.float32))[0] == 1.0
+
+
+def test_disc_forward_oracle_against_the_reference_network(golden, oracle):
+    """oly_disc_forward_cpu (the fused kernel's arithmetic) on the inputs of the reference run:
+    VariationalNet + Standardizer forward + make_discrim_reward, executed by gen_golden.py."""
+    g = golden("vail_disc.npz")
+    o = oracle.disc_forward(g["x"], g, mask=np.arange(32), mean=g["st_mean"], std=g["st_std"], eps=g["eps"])
+    # Linear layers: fma chains in k order vs the reference's BLAS summation order
+    np.testing.assert_allclose(o["mu"], g["mu"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(o["logvar"], g["logvar"], rtol=1e-4, atol=2e-6)
+    d = g["d"].reshape(-1)
+    np.testing.assert_allclose(o["logits"], d, rtol=2e-5, atol=2e-6)
+    # reward: the difference in d (<= 2e-6 + 2e-5 |d|) passes through dr/dd = sigmoid(d) <= 1, plus the
+    # float32 steps of the formula, amplified by the 1 - p cancellation (see test_disc_reward)
+    p = 1.0 / (1.0 + np.exp(-d.astype(np.float64)))
+    tol = (2e-6 + 2e-5 * np.abs(d)) + 4 * 2.0 ** -24 / (1 - p + 1e-8) + 4e-7 * np.abs(g["reward"]) + 1e-7
+    assert (np.abs(o["reward"] - g["reward"]) <= tol).all()
+    # the same statistics derived from the running sums (Standardizer.update_mean_std on x)
+    cs = oracle.col_stats(g["x"])
+    o2 = oracle.disc_forward(g["x"], g, colstats=cs, eps=g["eps"])
+    np.testing.assert_allclose(o2["logits"], d, rtol=1e-4, atol=1e-5)
+    # composition of the separately pinned pieces: standardise -> the same chains on pre-standardised input
+    xs = oracle.disc_standardize(g["x"], None, g["st_mean"], g["st_std"])
+    o3 = oracle.disc_forward(xs, g, eps=g["eps"])
+    for k in o:
+        assert np.array_equal(o[k], o3[k]), k
+    # deterministic forward (no noise): z = mu
+    o4 = oracle.disc_forward(xs, g)
+    assert np.array_equal(o4["mu"], o["mu"]) and not np.array_equal(o4["logits"], o["logits"])
+    lo = np.zeros(len(xs), np.float32)
+    hi = np.zeros(len(xs), np.float32)
+    w = g["dec_w"].reshape(-1)
+    for k in range(64):
+        lo = np.float32(np.float64(o4["mu"][:, k]) * np.float64(w[k]) + np.float64(lo))       # fma: one rounding
+        hi = np.float32(np.float64(o4["mu"][:, 64 + k]) * np.float64(w[64 + k]) + np.float64(hi))
+    assert np.array_equal(o4["logits"], (lo + hi) + g["dec_b"][0])
+
+
 # ------------------------------------------------------------------------------ K9 / normalisers
 def test_ppo_loss_terms_match_reference_update_policy(golden, oracle):
     """oly_ppo_loss_cpu / oly_mirror_loss_cpu on the reference's own update_policy outputs
