@@ -603,8 +603,10 @@ def test_discriminator_reward_fused_matches_layer_by_layer(eng, golden):
         r_ref = host(eng.disc_reward(d_ref))
         assert np.array_equal(host(fused.stand.colstats), host(plain.stand.colstats))
         pr = 1.0 / (1.0 + np.exp(-host(d_ref).astype(np.float64)))
-        tol = 2e-5 + 4 * 2.0 ** -24 / (1 - pr + 1e-8) + 4e-7 * np.abs(r_ref) + 1e-7
-        assert (np.abs(r - r_ref) <= tol).all()
+        # the two paths differ in the summation order of the Linear layers: |delta d| <= 5e-6 + 3e-5 |d| goes
+        # through dr/dd = sigmoid(d) <= 1; then the float32 steps of the formula (see test_disc_golden)
+        tol = (5e-6 + 3e-5 * np.abs(host(d_ref))) + 4 * 2.0 ** -24 / (1 - pr + 1e-8) + 4e-7 * np.abs(r_ref) + 1e-7
+        assert (np.abs(r - r_ref) <= tol).all(), np.abs(r - r_ref).max()
         if it == 0:
             np.testing.assert_allclose(r, g["reward"], rtol=5e-3, atol=5e-3)
     with torch.no_grad():
@@ -613,7 +615,7 @@ def test_discriminator_reward_fused_matches_layer_by_layer(eng, golden):
     plain.logits_unfused(x, eps)
     assert np.abs(r2 - r).max() > 1e-3
     d3, _, _ = plain.logits_unfused(x, eps)                # both standardisers have seen four batches now
-    np.testing.assert_allclose(host(fused.logits(x, eps)[0]), host(d3), rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(host(fused.logits(x, eps)[0]), host(d3), rtol=2e-5, atol=1e-4)   # |d| up to 200: cancellation
 
 
 # --------------------------------------------------------------------------------- K4
