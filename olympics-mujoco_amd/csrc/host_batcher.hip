@@ -105,6 +105,8 @@ struct oly_batcher {
   unsigned char *h_con, *d_con;            // one slab: ncon [W,N] | geom1 [W,N,C] | geom2 | force6 [W,N,C,6]
   size_t con_bytes, off_g1, off_g2, off_f6;
   double* d_grf;                           // [N, n_grf] window mean
+  uint8_t* d_over;                         // [N] overflow bytes of oly_il_ground_forces (the host check below decides)
+  std::atomic<int> overflow_env;           // first environment whose contacts overflowed the C staged slots, or -1
   // packed mode: the worker reduces each env's slots to the first-contact force of every sensor pair
   // right after its physics callback (per-thread scratch slots), only [W,N,n_grf] doubles cross PCIe
   int packed;
@@ -125,28 +127,41 @@ void kinematic_step(int, const double*, double* qpos, double* qvel, void* user) 
 
 // One env's W contact snapshots -> per-substep ground-force vector: for every sensor pair the FIRST
 // contact between its two collision groups (either geom order), its force[:3]; zeros without one.
-// The host twin of il_grf_kernel's filter (UnitreeH1._get_ground_forces, UnitreeH1.py:113-123).
-void pack_env(const oly_batcher* b, int e, const int32_t* ncon, const int32_t* g1, const int32_t* g2,
-              const double* f6) {
+// The host twin of il_grf_kernel's filter (UnitreeH1._get_ground_forces, UnitreeH1.py:113-123), including its
+// overflow rule: the callback reports the RAW data.ncon; a substep with more contacts than the C slots it
+// could fill is still exact when every sensor pair has its first contact among them, otherwise (or with a
+// negative count) the environment is recorded in overflow_env and the step fails with OLY_ERANGE.
+// out == nullptr: detection only (slot mode, where the device kernel does the reduction).
+void pack_env(oly_batcher* b, int e, const oly_il_contacts& oc, double* out_base) {
   const oly_ctx* ctx = b->ctx;
   const int P = ctx->grf.n_pairs, K = 3 * P, C = b->C;
   for (int w = 0; w < b->W; ++w) {
-    double* out = b->h_grfw + ((size_t)w * b->N + e) * K;
-    for (int k = 0; k < K; ++k) out[k] = 0.0;
-    int nc = ncon[w];
-    nc = nc < 0 ? 0 : (nc > C ? C : nc);
+    const int nc_raw = oc.ncon[(size_t)w * oc.ncon_stride];
+    if (!out_base && nc_raw >= 0 && nc_raw <= C) continue;
+    double* out = out_base ? out_base + ((size_t)w * b->N + e) * K : nullptr;
+    if (out) for (int k = 0; k < K; ++k) out[k] = 0.0;
+    const int nc = nc_raw < 0 ? 0 : (nc_raw > C ? C : nc_raw);
+    const int32_t *g1 = oc.geom1 + (size_t)w * oc.geom_stride, *g2 = oc.geom2 + (size_t)w * oc.geom_stride;
+    const double* f6 = oc.force6 + (size_t)w * oc.force_stride;
+    bool over = nc_raw < 0;
     for (int p = 0; p < P; ++p) {
+      bool found = false;
       for (int i = 0; i < nc; ++i) {
-        const int a = g1[(size_t)w * C + i], c2 = g2[(size_t)w * C + i];
+        const int a = g1[i], c2 = g2[i];
         const int ga = (a >= 0 && a < ctx->grf.ngeom) ? ctx->grf_group_host[a] : -1;
         const int gb = (c2 >= 0 && c2 < ctx->grf.ngeom) ? ctx->grf_group_host[c2] : -1;
         if (ga < 0 || gb < 0) continue;
         if ((ga == ctx->grf.pair_a[p] && gb == ctx->grf.pair_b[p]) || (ga == ctx->grf.pair_b[p] && gb == ctx->grf.pair_a[p])) {
-          const double* f = f6 + ((size_t)w * C + i) * 6;
-          out[3 * p] = f[0]; out[3 * p + 1] = f[1]; out[3 * p + 2] = f[2];
+          if (out) { const double* f = f6 + (size_t)i * 6; out[3 * p] = f[0]; out[3 * p + 1] = f[1]; out[3 * p + 2] = f[2]; }
+          found = true;
           break;
         }
       }
+      if (!found && nc_raw > C) over = true;
+    }
+    if (over) {
+      int none = -1;
+      b->overflow_env.compare_exchange_strong(none, e);
     }
   }
 }
@@ -170,7 +185,7 @@ void run_range(oly_batcher* b, int lo, int hi, int id) {
       oc.force_stride = (long)(C * 6);
       b->cfn(e, b->h_ctrl + (size_t)e * b->nu, b->h_qpos + (size_t)e * b->nq, b->h_qvel + (size_t)e * b->nv, &oc,
              b->cuser);
-      pack_env(b, e, ncon, oc.geom1, oc.geom2, oc.force6);
+      pack_env(b, e, oc, b->h_grfw);
     }
     return;
   }
@@ -187,6 +202,7 @@ void run_range(oly_batcher* b, int lo, int hi, int id) {
       oc.force_stride = (long)(N * C * 6);
       b->cfn(e, b->h_ctrl + (size_t)e * b->nu, b->h_qpos + (size_t)e * b->nq, b->h_qvel + (size_t)e * b->nv, &oc,
              b->cuser);
+      pack_env(b, e, oc, nullptr);          // overflow detection only: a count compare unless a substep overflowed
     }
     return;
   }
@@ -227,6 +243,7 @@ extern "C" int oly_batcher_create(oly_batcher** out, oly_ctx* ctx, int N, int n_
   b->h_qpos = b->h_qvel = b->h_ctrl = nullptr;
   b->d_qpos = b->d_qvel = b->d_ctrl = b->d_prev = nullptr;
   b->W = b->C = 0; b->cfn = nullptr; b->cuser = nullptr; b->h_con = b->d_con = nullptr; b->d_grf = nullptr;
+  b->d_over = nullptr; b->overflow_env.store(-1);
   b->packed = 0; b->h_grfw = b->d_grfw = nullptr;
   b->mapped = 0; b->m_qpos = b->m_qvel = b->m_ctrl = nullptr;
   const size_t sq = sizeof(double) * N * b->nq, sv = sizeof(double) * N * b->nv, sc = sizeof(double) * N * b->nu;
@@ -261,6 +278,7 @@ extern "C" void oly_batcher_destroy(oly_batcher* b) {
   if (b->h_con) (void)hipHostFree(b->h_con);
   if (b->d_con) (void)hipFree(b->d_con);
   if (b->d_grf) (void)hipFree(b->d_grf);
+  if (b->d_over) (void)hipFree(b->d_over);
   if (b->h_grfw) (void)hipHostFree(b->h_grfw);
   if (b->d_grfw) (void)hipFree(b->d_grfw);
   delete b;
@@ -284,7 +302,8 @@ extern "C" int oly_batcher_enable_contacts(oly_batcher* b, int W, int C, oly_phy
   b->con_bytes = al(b->off_f6 + sizeof(double) * W * N * C * 6);
   if (hipHostMalloc(reinterpret_cast<void**>(&b->h_con), b->con_bytes, hipHostMallocDefault) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&b->d_con), b->con_bytes) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&b->d_grf), sizeof(double) * N * ctx->il_host.n_grf) != hipSuccess)
+      hipMalloc(reinterpret_cast<void**>(&b->d_grf), sizeof(double) * N * ctx->il_host.n_grf) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_over), N) != hipSuccess)
     OLY_FAIL(ctx, OLY_ENOMEM, "oly_batcher_enable_contacts: allocation failed");
   memset(b->h_con, 0, b->con_bytes);
   b->W = W; b->C = C; b->cuser = user;
@@ -358,8 +377,12 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
   OLY_HIP(ctx, hipStreamSynchronize(s));
   const double t1 = now_s();
   // (2) physics on the host threads
+  b->overflow_env.store(-1);
   b->pool.run();
   const double t2 = now_s();
+  if (const int oe = b->overflow_env.load(); oe >= 0)
+    OLY_FAIL(ctx, OLY_ERANGE, "oly_batcher_step: environment %d has more contacts than the %d staged slots and a sensor pair "
+             "without a contact among them (or a negative count): enable contacts with more slots", oe, b->C);
   // (3) state rows up, post-physics path on the device
   if (!(b->mapped & 2)) {
     OLY_HIP(ctx, hipMemcpyAsync(b->d_qpos, b->h_qpos, sizeof(double) * b->N * b->nq, hipMemcpyHostToDevice, s));
@@ -377,7 +400,7 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
     rc = oly_il_ground_forces(ctx, b->W, b->N, b->C, reinterpret_cast<const int32_t*>(b->d_con),
                               reinterpret_cast<const int32_t*>(b->d_con + b->off_g1),
                               reinterpret_cast<const int32_t*>(b->d_con + b->off_g2),
-                              reinterpret_cast<const double*>(b->d_con + b->off_f6), nullptr, b->d_grf, stream);
+                              reinterpret_cast<const double*>(b->d_con + b->off_f6), nullptr, b->d_grf, b->d_over, stream);
     if (rc) return rc;
     grf = b->d_grf;
   } else if (ctx->il_host.n_grf > 0) {

@@ -120,13 +120,18 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
 // IL ground forces: 16 lanes per environment walk the W substeps in order; per substep the
 // first matching contact of every sensor pair is found by ballot + find-first-set over the
 // 16-lane group (slot order == contact order), lanes 0..2 of the group fetch its force[:3].
+// The reference scans ALL data.ncon contacts (UnitreeH1.py:113-123 -> _get_collision_force); only C slots
+// are staged, so a substep whose raw count exceeds C is exact as long as every sensor pair found its first
+// contact among the staged slots.  Otherwise (a pair without a hit, surplus contacts unseen; or a negative
+// count) the environment's overflow byte is set: the caller must not use its row (the facade raises).
 __global__ __launch_bounds__(THREADS) void il_grf_kernel(GrfDev gd, int W, int N, int C,
                                                          const int* __restrict__ ncon,
                                                          const int* __restrict__ geom1,
                                                          const int* __restrict__ geom2,
                                                          const double* __restrict__ force6,
                                                          double* __restrict__ grf_step,
-                                                         double* __restrict__ grf_mean) {
+                                                         double* __restrict__ grf_mean,
+                                                         uint8_t* __restrict__ overflow) {
   const int lane = threadIdx.x & 63;
   const int slot = lane & (SLOTS - 1);
   const int grp = lane / SLOTS;
@@ -138,8 +143,10 @@ __global__ __launch_bounds__(THREADS) void il_grf_kernel(GrfDev gd, int W, int N
     const long n = base + grp;
     const bool env_ok = n < N;
     double acc = 0.0;  // lane `slot` < ncomp accumulates component `slot` of the window sum
+    bool over = false;
     for (int w = 0; w < W; ++w) {
-      const int nc = env_ok ? min(max(ncon[(size_t)w * N + n], 0), C) : 0;
+      const int nc_raw = env_ok ? ncon[(size_t)w * N + n] : 0;
+      const int nc = min(max(nc_raw, 0), C);
       int first[OLY_MAX_GRF_PAIRS];
 #pragma unroll
       for (int k = 0; k < OLY_MAX_GRF_PAIRS; ++k) first[k] = -1;
@@ -161,6 +168,12 @@ __global__ __launch_bounds__(THREADS) void il_grf_kernel(GrfDev gd, int W, int N
           if (first[k] < 0 && m) first[k] = ps * SLOTS + (__ffsll((long long)m) - 1);
         }
       }
+      if (nc_raw < 0) over = true;
+      if (nc_raw > C) {
+#pragma unroll
+        for (int k = 0; k < OLY_MAX_GRF_PAIRS; ++k)
+          if (k < gd.n_pairs && first[k] < 0) over = true;
+      }
       if (env_ok && slot < ncomp) {
         const int k = slot / 3, c = slot - 3 * k;
         double v = 0.0;
@@ -170,6 +183,7 @@ __global__ __launch_bounds__(THREADS) void il_grf_kernel(GrfDev gd, int W, int N
       }
     }
     if (env_ok && slot < ncomp) grf_mean[(size_t)n * ncomp + slot] = acc / (double)W;
+    if (env_ok && slot == 0) overflow[n] = (uint8_t)over;
   }
 }
 
@@ -286,18 +300,18 @@ extern "C" int oly_grf_configure(oly_ctx* ctx, int ngeom, const int32_t* geom_gr
 
 extern "C" int oly_il_ground_forces(oly_ctx* ctx, int W, int N, int C, const int32_t* ncon,
                                     const int32_t* geom1, const int32_t* geom2, const double* force6,
-                                    double* grf_step, double* grf_mean, oly_stream stream) {
+                                    double* grf_step, double* grf_mean, uint8_t* overflow, oly_stream stream) {
   if (!ctx) return OLY_EINVAL;
   if (!ctx->grf_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_il_ground_forces before oly_grf_configure");
   if (W <= 0 || N < 0 || C <= 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_il_ground_forces: bad W, N or C");
   if (N == 0) return OLY_OK;
-  if (!ncon || !geom1 || !geom2 || !force6 || !grf_mean)
+  if (!ncon || !geom1 || !geom2 || !force6 || !grf_mean || !overflow)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_il_ground_forces: NULL pointer");
   long waves = ((long)N + 3) / 4;
   long blocks = (waves * 64 + THREADS - 1) / THREADS;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(il_grf_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->grf, W, N, C,
-                     ncon, geom1, geom2, force6, grf_step, grf_mean);
+                     ncon, geom1, geom2, force6, grf_step, grf_mean, overflow);
   OLY_LAUNCH_CHECK(ctx, "il_grf_kernel");
   return OLY_OK;
 }

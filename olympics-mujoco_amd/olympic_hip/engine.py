@@ -510,8 +510,12 @@ class Engine:
         self.n_grf_pairs = len(pairs)
         return self
 
-    def il_ground_forces(self, ncon, geom1, geom2, force6, want_steps=False):
-        """[W,N,...] substep contact slots -> dict(mean [N,3P], steps [W,N,3P] or None)."""
+    def il_ground_forces(self, ncon, geom1, geom2, force6, want_steps=False, check=True):
+        """[W,N,...] substep contact slots -> dict(mean [N,3P], steps [W,N,3P] or None, overflow [N] u8).
+        `ncon` is the raw data.ncon.  An environment whose count exceeded the staged slots in a substep where a
+        sensor pair found no contact among them cannot be reproduced (the reference scans every contact,
+        UnitreeH1.py:113-123): with check=True (default; one host round trip) that raises, with check=False
+        the caller owns the `overflow` bytes."""
         if not getattr(self, "n_grf_pairs", 0):
             raise OlyError("il_ground_forces before grf_configure")
         W, N, Cc = (int(v) for v in geom1.shape)
@@ -522,9 +526,14 @@ class Engine:
         k = 3 * self.n_grf_pairs
         mean = self._new((N, k), torch.float64)
         steps = self._new((W, N, k), torch.float64) if want_steps else None
+        over = self._new((N,), torch.uint8)
         self.ctx.call("oly_il_ground_forces", W, N, Cc, ptr(ncon), ptr(geom1), ptr(geom2), ptr(force6), ptr(steps),
-                      ptr(mean), self._s())
-        return dict(mean=mean, steps=steps)
+                      ptr(mean), ptr(over), self._s())
+        if check and N and bool(over.any().item()):
+            bad = torch.nonzero(over).flatten()[:8].tolist()
+            raise OlyError(f"il_ground_forces: more contacts than the {Cc} staged slots and a sensor pair without a "
+                           f"contact among them (or a negative count) in environments {bad}: stage more slots")
+        return dict(mean=mean, steps=steps, overflow=over)
 
     def il_grf_window(self, grf_step, mean=None):
         """[W,N,K] per-substep ground-force rows -> [N,K] window mean (sum in substep order / W)."""

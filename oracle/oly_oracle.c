@@ -1049,21 +1049,27 @@ int oly_ppo_loss_cpu(int B, int A, const float* mu, const float* sd, int sd_mode
 
 /* UnitreeH1._get_ground_forces (UnitreeH1.py:113-123) per substep + RunningAveragedWindow mean
  * (loco_env_base.py:1072-1084,1163-1174), restating mushroom's _get_collision_force: first
- * contact in contact order between the two geom groups (either order), its force[:3]. */
+ * contact in contact order between the two geom groups (either order), its force[:3].
+ * ncon is the raw data.ncon; only C slots are staged.  overflow[n] = 1 when a substep of env n has
+ * ncon > C and a sensor pair without a hit among the staged slots (the reference would have gone
+ * on scanning the surplus), or a negative count. */
 int oly_il_ground_forces_cpu(int ngeom, const int32_t* geom_group, int n_pairs, const int32_t* pair_a,
                              const int32_t* pair_b, int W, int N, int C, const int32_t* ncon,
                              const int32_t* geom1, const int32_t* geom2, const double* force6,
-                             double* grf_step, double* grf_mean) {
+                             double* grf_step, double* grf_mean, uint8_t* overflow) {
   const int ncomp = 3 * n_pairs;
   for (int n = 0; n < N; ++n) {
     double acc[3 * OLY_MAX_GRF_PAIRS] = {0};
+    int over = 0;
     for (int w = 0; w < W; ++w) {
       const size_t row = (size_t)w * N + n;
-      int nc = ncon[row];
-      if (nc < 0) nc = 0;
+      const int nc_raw = ncon[row];
+      int nc = nc_raw;
+      if (nc < 0) { nc = 0; over = 1; }
       if (nc > C) nc = C;
       for (int k = 0; k < n_pairs; ++k) {
         double f[3] = {0.0, 0.0, 0.0};
+        int found = 0;
         for (int i = 0; i < nc; ++i) {
           const int g1 = geom1[row * C + i], g2 = geom2[row * C + i];
           if (g1 < 0 || g1 >= ngeom || g2 < 0 || g2 >= ngeom) continue;
@@ -1071,9 +1077,11 @@ int oly_il_ground_forces_cpu(int ngeom, const int32_t* geom_group, int n_pairs, 
           if (ga < 0 || gb < 0) continue;
           if ((ga == pair_a[k] && gb == pair_b[k]) || (ga == pair_b[k] && gb == pair_a[k])) {
             for (int c = 0; c < 3; ++c) f[c] = force6[(row * C + i) * 6 + c];
+            found = 1;
             break;
           }
         }
+        if (!found && nc_raw > C) over = 1;
         for (int c = 0; c < 3; ++c) {
           if (grf_step) grf_step[row * ncomp + 3 * k + c] = f[c];
           acc[3 * k + c] += f[c];
@@ -1081,6 +1089,7 @@ int oly_il_ground_forces_cpu(int ngeom, const int32_t* geom_group, int n_pairs, 
       }
     }
     for (int j = 0; j < ncomp; ++j) grf_mean[(size_t)n * ncomp + j] = acc[j] / (double)W;
+    if (overflow) overflow[n] = (uint8_t)over;
   }
   return OLY_OK;
 }

@@ -96,7 +96,7 @@ int oly_disc_forward_cpu(int64_t B, int Dx, int D, const float* x, const int32_t
 int oly_il_ground_forces_cpu(int ngeom, const int32_t* geom_group, int n_pairs, const int32_t* pair_a,
                              const int32_t* pair_b, int W, int N, int C, const int32_t* ncon,
                              const int32_t* geom1, const int32_t* geom2, const double* force6,
-                             double* grf_step, double* grf_mean);
+                             double* grf_step, double* grf_mean, uint8_t* overflow);
 int oly_rollout_cuts_cpu(int N, int max_traj_len, int last_step, const uint8_t* done, int32_t* traj_len,
                          uint8_t* flags, int32_t* n_cut);
 int oly_obs_filter_cpu(int B, int D, const float* x, const double* mean, const double* var,

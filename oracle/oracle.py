@@ -392,8 +392,9 @@ def ppo_loss(mu, std, old_mu, old_std, action, adv, ret, value, clip, vf_coeff=0
     return scal, gmu, gsd, gv
 
 
-def il_ground_forces(geom_group, pairs, ncon, geom1, geom2, force6):
-    """-> (grf_step [W,N,3P], grf_mean [N,3P])."""
+def il_ground_forces(geom_group, pairs, ncon, geom1, geom2, force6, want_overflow=False):
+    """-> (grf_step [W,N,3P], grf_mean [N,3P]) (+ overflow [N] u8 with want_overflow: an env whose raw ncon
+    exceeded the staged slots in a substep where a sensor pair found no contact among them)."""
     gg = _c(geom_group, np.int32)
     pa = _c([a for a, _ in pairs], np.int32)
     pb = _c([b for _, b in pairs], np.int32)
@@ -401,9 +402,10 @@ def il_ground_forces(geom_group, pairs, ncon, geom1, geom2, force6):
     W, N, Cc = geom1.shape
     step = np.zeros((W, N, 3 * len(pairs)))
     mean = np.zeros((N, 3 * len(pairs)))
+    over = np.zeros(N, np.uint8)
     _chk(lib().oly_il_ground_forces_cpu(len(gg), _p(gg), len(pairs), _p(pa), _p(pb), W, N, Cc, _p(ncon), _p(geom1),
-                                        _p(geom2), _p(force6), _p(step), _p(mean)), "il_ground_forces")
-    return step, mean
+                                        _p(geom2), _p(force6), _p(step), _p(mean), _p(over)), "il_ground_forces")
+    return (step, mean, over) if want_overflow else (step, mean)
 
 
 def rollout_cuts(done, traj_len, max_traj_len, last_step):

@@ -765,4 +765,22 @@ def test_host_batcher_with_foot_force_contacts(oracle, packed):
         assert np.array_equal(obs.cpu().numpy(), ref["obs"][k])
         assert np.array_equal(ab.cpu().numpy(), ref["absorbing"][k])
         assert ulp_diff(rew.cpu().numpy(), ref["reward"][k]).max() <= 1
+    # raw data.ncon beyond the staged slots (the reference scans every contact, UnitreeH1.py:113-123): exact while both
+    # sensor pairs have their first contact among the slots, an error (never a silently dropped force) otherwise
+    k = K - 1
+    step["k"] = k
+    con["geom2"][k, :, 5, :2] = [22, 12]                               # env 5: foot_r, foot_l in the first two slots
+    con["ncon"][k, 3, 5] = Cc + 7
+    means_k = oracle.il_ground_forces(sp.geom_group, sp.grf_pairs, con["ncon"][k], con["geom1"][k], con["geom2"][k],
+                                      con["force6"][k], want_overflow=True)
+    assert not means_k[2].any()
+    b.set_prev(prev)
+    ref_k = oracle.il_step(sp, qpos[k:k + 1], qvel[k:k + 1], None, prev, grf_mean=means_k[1][None], obs_f64=True)
+    obs, rew, ab = b.step(torch.as_tensor(act[k]).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(obs.cpu().numpy(), ref_k["obs"][0])
+    con["geom2"][k, 3, 7, :] = 22                                      # env 7, substep 3: no foot_l contact in any slot
+    con["ncon"][k, 3, 7] = Cc + 1
+    with pytest.raises(Exception, match="environment 7 has more contacts than the 8 staged slots"):
+        b.step(torch.as_tensor(act[k]).cuda())
     b.close()

@@ -1236,23 +1236,37 @@ def test_obs_filter_and_device_running_mean_std(eng, oracle, golden):
 def test_il_ground_forces_vs_oracle(eng, oracle, W, N, C):
     """First matching contact per sensor pair (either geom order), force[:3], in-order window mean:
     selections are index work (bit-exact), the mean is W in-order adds and one divide (bit-exact)."""
+    from olympic_hip._ffi import OlyError
     rng = np.random.default_rng(W + N + C)
     ngeom = 30
     gg = np.full(ngeom, -1, np.int32)
     gg[0], gg[[7, 8]], gg[[20]], gg[[21]], gg[[22]] = 0, 1, 2, 3, 4
     pairs = [(0, 1), (0, 2), (0, 3), (0, 4)][:1 + (N % 4)]
-    ncon = rng.integers(0, C + 3, (W, N)).astype(np.int32)            # also > C: clamped
+    ncon = rng.integers(0, C + 3, (W, N)).astype(np.int32)            # RAW counts, also > C (only C slots are staged)
+    if N > 2:
+        ncon[0, 1] = -1                                               # a negative count: overflow, reduced as 0 contacts
     g1 = np.where(rng.uniform(size=(W, N, C)) < 0.5, 0, rng.integers(-1, ngeom + 1, (W, N, C))).astype(np.int32)
     g2 = rng.choice([0, 7, 8, 20, 21, 22, 3, 29, -1, ngeom], size=(W, N, C)).astype(np.int32)
     swap = rng.uniform(size=(W, N, C)) < 0.3
     g1, g2 = np.where(swap, g2, g1).astype(np.int32), np.where(swap, g1, g2).astype(np.int32)
     f6 = rng.normal(0, 200, (W, N, C, 6))
     eng.grf_configure(gg, pairs)
-    o = eng.il_ground_forces(dev(ncon), dev(g1), dev(g2), dev(f6), want_steps=True)
-    e_step, e_mean = oracle.il_ground_forces(gg, pairs, ncon, g1, g2, f6)
+    o = eng.il_ground_forces(dev(ncon), dev(g1), dev(g2), dev(f6), want_steps=True, check=False)
+    e_step, e_mean, e_over = oracle.il_ground_forces(gg, pairs, ncon, g1, g2, f6, want_overflow=True)
     assert np.array_equal(host(o["steps"]), e_step)
     assert np.array_equal(host(o["mean"]), e_mean)
     assert (e_step != 0).any() or N == 1
+    # ncon > C: exact while every sensor pair has its first contact among the C staged slots (the reference scans
+    # all data.ncon contacts, UnitreeH1.py:113-123), flagged otherwise; bit-exact flags, and the default call raises
+    assert np.array_equal(host(o["overflow"]), e_over)
+    if N > 2:
+        assert e_over[1] == 1 and 0 < e_over.sum() < N, "the case must hold flagged and unflagged ncon > C environments"
+        assert ((ncon > C).any(0) & (e_over == 0)).any()
+        with pytest.raises(OlyError, match="staged slots"):
+            eng.il_ground_forces(dev(ncon), dev(g1), dev(g2), dev(f6))
+        keep = e_over == 0                                            # without the flagged environments: no error
+        o2 = eng.il_ground_forces(dev(ncon[:, keep]), dev(g1[:, keep]), dev(g2[:, keep]), dev(f6[:, keep]))
+        assert np.array_equal(host(o2["mean"]), e_mean[keep])
     # the dense form (rows already reduced per substep, as the packed host batcher stages them)
     assert np.array_equal(host(eng.il_grf_window(dev(e_step))), e_mean)
 
@@ -1316,7 +1330,7 @@ def test_error_paths_of_the_newer_entry_points():
     L = _ffi.lib()
     assert L.oly_mirror_loss(e.ctx.handle, 0, 12, None, None, None, None, None, None, None, None) == _abi.OLY_EINVAL
     assert b"oly_mirror_loss" in L.oly_last_error(e.ctx.handle)
-    assert L.oly_il_ground_forces(e.ctx.handle, 0, 4, 16, None, None, None, None, None, None, None) == _abi.OLY_EINVAL
+    assert L.oly_il_ground_forces(e.ctx.handle, 0, 4, 16, None, None, None, None, None, None, None, None) == _abi.OLY_EINVAL
 
 
 @pytest.mark.parametrize("N", [1, 63, 4096, 100001])

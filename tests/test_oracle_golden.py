@@ -529,6 +529,19 @@ def test_il_ground_forces_hand_cases(oracle):
     assert mean[0].tolist() == [22, 27.5, 33, 10, 15.5, 21]
     step0, mean0 = oracle.il_ground_forces(gg, pairs, np.zeros((2, 1), np.int32), g1, g2, f)
     assert not step0.any() and not mean0.any()
+    # raw ncon beyond the 4 staged slots (the reference scans every data.ncon contact, UnitreeH1.py:113-123):
+    #  env 0: both pairs have their first contact among the staged slots -> exact, no flag;
+    #  env 1: the foot_l pair has none among them (its contact may be the unseen 5th) -> flagged;
+    #  env 2: negative count -> flagged, reduced as no contact
+    g1b = np.array([[[0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 0, 0]]], np.int32)
+    g2b = np.array([[[2, 4, 1, 1], [2, 3, 1, 1], [2, 4, 2, 4]]], np.int32)
+    fb = np.arange(1 * 3 * 4 * 6, dtype=np.float64).reshape(1, 3, 4, 6)
+    stepb, meanb, over = oracle.il_ground_forces(gg, pairs, np.array([[6, 5, -2]], np.int32), g1b, g2b, fb, want_overflow=True)
+    assert over.tolist() == [0, 1, 1]
+    assert stepb[0, 0].tolist() == [0, 1, 2, 6, 7, 8] and stepb[0, 1].tolist() == [24, 25, 26, 0, 0, 0]
+    assert not stepb[0, 2].any() and np.array_equal(meanb, stepb[0])
+    _, _, over4 = oracle.il_ground_forces(gg, pairs, np.array([[4, 4, 0]], np.int32), g1b, g2b, fb, want_overflow=True)
+    assert over4.tolist() == [0, 0, 0]                                # ncon == C is not an overflow
 
 
 def test_robot_geom_tables():

@@ -88,7 +88,7 @@ def big(eng):
     W = 4
     rec("K3_il_ground_forces_[4,262144,16]",
         timeit(eng, lambda: eng.il_ground_forces(ncon[:Nc].view(W, -1), g1.view(W, Nc // W, C), g2.view(W, Nc // W, C),
-                                                 f6.view(W, Nc // W, C, 6)), reps=10), (4 + C * 8 + 2 * 24) * Nc)   # ncon + geom pairs + the two selected force rows
+                                                 f6.view(W, Nc // W, C, 6), check=False), reps=10), (4 + C * 8 + 2 * 24) * Nc)   # ncon + geom pairs + the two selected force rows
     del f6, pz, g1, g2
     Wd, Nd, Kd = 10, 1 << 20, 6          # dense per-substep rows as the packed host batcher stages them (H1: 2 pairs x 3)
     steps = rnd((Wd, Nd, Kd), torch.float64)
