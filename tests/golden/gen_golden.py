@@ -69,8 +69,21 @@ OT = stubs.ObservationType
 AlgorithmType = ns.enums.AlgorithmType
 
 
+# --out DIR (or GOLDEN_OUT=DIR): write the fixtures somewhere else, e.g. a temporary directory that
+# tests/test_oracle_golden.py::test_fixtures_regenerate_bit_identically compares with the committed files
+OUT_DIR = os.environ.get("GOLDEN_OUT", HERE)
+if "--out" in sys.argv:
+    _i = sys.argv.index("--out")
+    OUT_DIR = sys.argv[_i + 1]
+    del sys.argv[_i:_i + 2]
+os.makedirs(OUT_DIR, exist_ok=True)
+
+# fixed per-robot input seeds (hash(cls_name) is salted per process: such fixtures could not be regenerated)
+ROBOT_SEEDS = {"Atlas": 711, "Talos": 712}
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name)
+    path = os.path.join(OUT_DIR, name)
     np.savez_compressed(path, **arrays)
     print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KiB, keys={list(arrays)}")
 
@@ -963,7 +976,7 @@ def gen_il_robot(cls_name, mod, xml, defaults):
     import importlib
     m = importlib.import_module(f"olympic_mujoco.environments.real_humanoid_robots.{mod}")
     cls = getattr(m, cls_name)
-    rng = np.random.default_rng(abs(hash(cls_name)) % 1000)
+    rng = np.random.default_rng(ROBOT_SEEDS[cls_name])
     out = {}
     for tag, (arms, back) in (("default", defaults), ("all_joints", (False, False))):
         env = cls.__new__(cls)

@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/oly_oracle.c) to the golden vectors that were produced by
 executing the reference's own functions (tests/golden/gen_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -683,3 +685,28 @@ def test_rotation_restatement_against_scipy(golden, oracle):
     got = obs[:, :4].astype(np.float64)
     err = np.minimum(np.abs(got - flat).max(1), np.abs(got + flat).max(1))
     assert regular.sum() > 490 and err[regular].max() < 1e-6     # obs is float32
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_fixtures_regenerate_bit_identically(tmp_path):
+    """Every committed fixture is reproducible: tests/golden/gen_golden.py (which EXECUTES the reference's own
+    functions from /root/reference under inert stubs) is re-run into a temporary directory and each array of each
+    .npz must equal the committed one bit for bit (fixed seeds everywhere; no salted hash() seeds)."""
+    import glob
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    env = dict(os.environ, PYTHONHASHSEED="random")
+    for k in ("LD_PRELOAD", "OLY_ORACLE_ASAN", "ASAN_OPTIONS", "UBSAN_OPTIONS"):   # the generator never touches the oracle
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(here, "gen_golden.py"), "--out", str(tmp_path)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    committed = sorted(os.path.basename(f) for f in glob.glob(os.path.join(here, "*.npz")))
+    assert sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / "*.npz"))) == committed
+    for name in committed:
+        a, b = np.load(os.path.join(here, name), allow_pickle=False), np.load(str(tmp_path / name), allow_pickle=False)
+        assert sorted(a.files) == sorted(b.files), name
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (name, k)
+            assert a[k].tobytes() == b[k].tobytes(), f"{name}:{k} does not regenerate"
