@@ -19,7 +19,9 @@
 // no workgroup ever reads a counter another one has already advanced): the launch arguments are
 // the same for every step and the launch can be replayed from a HIP graph.
 #include "oly_common.h"
+#include "a3_vec_core.h"
 
+using namespace oly_a3v;
 namespace {
 #ifndef OLY_K10_THREADS
 #define OLY_K10_THREADS 256   // 128 (8 environments, two workgroups per CU) measured slower: 15.7 vs 14.1 us
@@ -27,8 +29,6 @@ namespace {
 constexpr int THREADS = OLY_K10_THREADS;
 constexpr int SLOTS = 16;               // lanes per environment
 constexpr int EPW = THREADS / SLOTS;    // environments per workgroup
-constexpr double PI = 3.141592653589793;
-constexpr double EPS = 2.220446049250313e-16;
 constexpr int MAX_NU = 16;
 constexpr int MAX_NOBS = 7 + 2 * MAX_NU + 10;
 
@@ -51,8 +51,6 @@ enum {
   L_ENV = 205
 };
 
-enum { F_NONE = 0, F_SINCOS = 1, F_TAN = 2, F_EXP = 3, F_ATAN2 = 4 };
-
 struct VecArgs {
   const A3Dev* md;
   ContactDev cd;
@@ -61,44 +59,6 @@ struct VecArgs {
   oly_a3_state st;
   oly_a3_rollout ro;
 };
-
-__device__ __forceinline__ void quat2mat(double w, double x, double y, double z, double R[3][3]) {
-  const double nq = w * w + x * x + y * y + z * z;
-  if (nq < EPS) {
-    R[0][0] = 1; R[0][1] = 0; R[0][2] = 0;
-    R[1][0] = 0; R[1][1] = 1; R[1][2] = 0;
-    R[2][0] = 0; R[2][1] = 0; R[2][2] = 1;
-    return;
-  }
-  const double s = 2.0 / nq;
-  const double X = x * s, Y = y * s, Z = z * s;
-  const double wX = w * X, wY = w * Y, wZ = w * Z;
-  const double xX = x * X, xY = x * Y, xZ = x * Z;
-  const double yY = y * Y, yZ = y * Z, zZ = z * Z;
-  R[0][0] = 1.0 - (yY + zZ); R[0][1] = xY - wZ;         R[0][2] = xZ + wY;
-  R[1][0] = xY + wZ;         R[1][1] = 1.0 - (xX + zZ); R[1][2] = yZ - wX;
-  R[2][0] = xZ - wY;         R[2][1] = yZ + wX;         R[2][2] = 1.0 - (xX + yY);
-}
-
-__device__ __forceinline__ double norm3d(double a0, double a1, double a2) {
-  return sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-}
-
-// one function on one argument per lane; lanes of different classes diverge, so a call costs one
-// evaluation per class present in the wave
-__device__ __forceinline__ void eval_task(int cls, double a, double b, double& r0, double& r1) {
-  r0 = 0.0;
-  r1 = 0.0;
-  if (cls == F_SINCOS) {
-    sincos(a, &r0, &r1);   // bit-identical to sin() / cos() on gfx950 (tools/hip/check_sincos.hip: 2^24 arguments)
-  } else if (cls == F_TAN) {
-    r0 = tan(a);
-  } else if (cls == F_EXP) {
-    r0 = exp(a);
-  } else if (cls == F_ATAN2) {
-    r0 = atan2(a, b);
-  }
-}
 
 __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   __shared__ double s_env[EPW][L_ENV];
@@ -307,8 +267,8 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   int phase = phase0 + 1;
   if (phase >= period) phase = 0;
   const double tx = se[L_SEQ + 4 * t1], ty = se[L_SEQ + 4 * t1 + 1], tz = se[L_SEQ + 4 * t1 + 2];
-  const double dl = norm3d(lf0 - tx, lf1 - ty, lf2 - tz);
-  const double dr = norm3d(rf0 - tx, rf1 - ty, rf2 - tz);
+  const double dl = vnorm3(lf0 - tx, lf1 - ty, lf2 - tz);
+  const double dr = vnorm3(rf0 - tx, rf1 - ty, rf2 - tz);
   int reached;
   if (dl < m->target_radius || dr < m->target_radius) {
     reached = 1;
@@ -358,14 +318,14 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   double nl = fmin(grf_l, max_frc) / max_frc;
   double nr = fmin(grf_r, max_frc) / max_frc;
   nl *= 2; nl -= 1; nr *= 2; nr -= 1;
-  double vl = fmin(norm3d(se[L_LV], se[L_LV + 1], se[L_LV + 2]), 0.2) / 0.2;
-  double vr = fmin(norm3d(se[L_RV], se[L_RV + 1], se[L_RV + 2]), 0.2) / 0.2;
+  double vl = fmin(vnorm3(se[L_LV], se[L_LV + 1], se[L_LV + 2]), 0.2) / 0.2;
+  double vr = fmin(vnorm3(se[L_RV], se[L_RV + 1], se[L_RV + 2]), 0.2) / 0.2;
   vl *= 2; vl -= 1; vr *= 2; vr -= 1;
   const double contact_point = (cnt_r > 0 || cnt_l > 0) ? min_z : 0.0;
   double err = fabs((rp2 - contact_point) - m->goal_height_ref);
   const double deadzone = 0.01 + 0.05 * m->goal_speed_ref;
   if (err < deadzone) err = 0;
-  const double fd = fmin(norm3d(lf0 - s1x, lf1 - s1y, lf2 - s1z), norm3d(rf0 - s1x, rf1 - s1y, rf2 - s1z));
+  const double fd = fmin(vnorm3(lf0 - s1x, lf1 - s1y, lf2 - s1z), vnorm3(rf0 - s1x, rf1 - s1y, rf2 - s1z));
   const double mpx = (s1x + s2x) / 2, mpy = (s1y + s2y) / 2;
   const double rx = rp0 - mpx, ry = rp1 - mpy;
   const double hx = se[L_HP] - rp0, hy = se[L_HP + 1] - rp1;

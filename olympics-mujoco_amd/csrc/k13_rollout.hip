@@ -1,0 +1,767 @@
+// K13: ONE launch per ROLLOUT of the PPO sampling loop for N StickFigureA3 environments whose physics readback is
+// staged on the device (rl/algos/ppo.py:169-196 with env.step = StickFigureA3.step, StickFigureA3.py:187-200).
+//
+// The two-kernel rollout (K11 forward + K10 vec step per step) pays two dependent launches per step: ~9 us of
+// launch ramp, first-touch loads and epilogues for ~4 us of work at N = 4096.  Environments are independent and the
+// weights are read-only during a rollout, so nothing in the loop needs a grid-wide synchronisation: here a
+// workgroup OWNS 32 environments for all T steps,
+//
+//     forward(obs_t)  ->  sample / store  ->  env step t (contacts, WalkingTask.step / reward / done / get_obs,
+//                                             cut rules, bootstrap row, env.reset() from the pre-drawn record)
+//                     ->  forward(obs_{t+1}) ...
+//
+// with the observation, the task state and the step sequence living in LDS / registers from the first step to the
+// last.  Geometry: grid (N / 32, 2).  blockIdx.y picks the NETWORK the workgroup evaluates (0: actor, 1: critic),
+// exactly K11's tile: 8 waves, 32 rows, one network, weights streamed from L2 in the packed B-operand layout.  BOTH
+// workgroups of a 32-environment tile run the (cheap, latency-bound) environment step themselves instead of
+// handing the observation across CUs: a cross-CU hand-off costs 1-3 us per step (MI355X_MICROARCH.md price list),
+// the replayed step costs nothing on the critical path, and it keeps all 256 CUs on the matrix pipes.  Only one
+// workgroup of a pair stores any given array: the actor one the actions, rewards, flags, bootstrap rows and the
+// final task state, the critic one the stored observations and the values.
+//
+// Per step the only global traffic on the critical path is the weight stream (L2 hits).  Readback rows and the
+// noise row of step t + 1 are requested right after step t's own rows were consumed, i.e. a whole libm phase and a
+// forward before they are needed; stores are fire-and-forget.
+//
+// Numerics: the forward is K11's (mlp_tiles.h: exact f32 fma chains, k ascending; the output layer's eight partial
+// chains added in wave order, bias last), the environment step K10's, expression for expression, on the same libm
+// entry points (a3_vec_core.h, -ffp-contract=off): buffers and final state are BIT-IDENTICAL to T rounds of
+// oly_mlp_forward2 + oly_a3_vec_step (tests/test_gpu_vecstep.py).
+#include "a3_vec_core.h"
+#include "mlp_tiles.h"
+#include "oly_common.h"
+
+using namespace oly_a3v;
+using namespace oly_mlp;
+
+namespace {
+constexpr int SLOTS = 16;               // lanes per environment
+constexpr int EPW = THREADS / SLOTS;    // environments per workgroup
+static_assert(EPW == RT, "a workgroup's environments are one 32-row MFMA tile");
+constexpr int MAX_NU = 16;
+constexpr int MAX_NOBS = 7 + 2 * MAX_NU + 10;
+constexpr int OBP = MAX_NOBS + 1;       // pitch of the observation rows in LDS
+constexpr int SEQW = OLY_MAX_SEQ * 4;   // doubles of one environment's step sequence
+constexpr int OBS_PT = (EPW * MAX_NOBS + THREADS - 1) / THREADS;
+
+// per-environment LDS scratch of the environment step (doubles); lives where the MLP activations live during
+// the forward (the two phases never overlap)
+enum {
+  L_RQ = 0,      // root quat 4
+  L_RP = 4,      // root pos 3
+  L_HP = 7,      // head pos 3
+  L_LF = 10,     // lf pos 3
+  L_RF = 13,     // rf pos 3
+  L_LV = 16,     // lf vel 3
+  L_RV = 19,     // rf vel 3
+  L_BQ = 22,     // body quat qpos[3:7]
+  L_AV = 26,     // qvel[3:6]
+  L_AL = 29,     // act_len 16
+  L_AVL = 45,    // act_vel 16
+  L_R1 = 61,     // round-1 results [16][2]
+  L_R2 = 93,     // round-2 results [16][2]
+  L_ENV = 125
+};
+
+struct RollArgs {
+  const A3Dev* md;
+  ContactDev cd;
+  int N, in_dim;
+  oly_a3_blocks b;
+  oly_a3_state st;
+  oly_a3_rollout ro;
+  const float* packed[2];
+  int out_dim[2], normalize[2];
+  float* mu_out;       // [N,nu] mean of the LAST forward (what ro.mu holds after the two-kernel loop), or NULL
+  float* value_out;    // [N]    value of the last forward, or NULL
+};
+
+constexpr size_t ROLL_LDS = sizeof(float) * (MAX_IN + 2 * HID) * LDP + sizeof(double) * EPW * SEQW +
+                            sizeof(float) * 2 * EPW * OBP;
+static_assert(sizeof(double) * (EPW * L_ENV + EPW * SLOTS * 2) + EPW * SLOTS <= sizeof(float) * 2 * HID * LDP,
+              "the environment scratch must fit in the activation images it aliases");
+static_assert((sizeof(float) * MAX_IN * LDP) % 8 == 0 && (sizeof(float) * (MAX_IN + 2 * HID) * LDP) % 8 == 0,
+              "fp64 regions must be 8-byte aligned");
+
+// the readback row of one step as the environment's 16 lanes hold it between the request and its use
+struct Readback {
+  int nc_raw, g1_0, g2_0;
+  double va, vb, v_len, v_vel, f0[6], pz0;
+};
+
+__global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xT = lds;                                              // [MAX_IN][LDP]  forward input, k-major
+  float* hA = xT + MAX_IN * LDP;                                // [HID][LDP]     layer-1 output / layer-3 partials
+  float* hB = hA + HID * LDP;                                   // [HID][LDP]     layer-2 output
+  double* s_env = reinterpret_cast<double*>(hA);                // [EPW][L_ENV]   (environment phase)
+  double* s_arg = s_env + EPW * L_ENV;                          // [EPW][SLOTS][2]
+  uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_arg + EPW * SLOTS * 2);   // [EPW][SLOTS]
+  double* seqs = reinterpret_cast<double*>(hB + HID * LDP);     // [EPW][SEQW]    step sequences, whole rollout
+  float* s_pre = reinterpret_cast<float*>(seqs + EPW * SEQW);   // [EPW][OBP]     observation before a reset
+  float* s_post = s_pre + EPW * OBP;                            // [EPW][OBP]     observation the policy sees next
+
+  const A3Dev* __restrict__ m = p.md;
+  const int nu = m->nu, n_obs = m->n_obs, period = m->period, nq = m->nq, nv = m->nv;
+  const int N = p.N, T = p.ro.T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, slot = lane & (SLOTS - 1);
+  const int el = wave * 4 + grp;
+  const int row0 = blockIdx.x * EPW;
+  const int n = row0 + el;
+  const bool env_ok = n < N;
+  const int rows = min(EPW, N - row0);
+  const int net = blockIdx.y;
+  const bool actor = net == 0;
+  const int out_dim = p.out_dim[net];
+  const bool det = p.ro.deterministic != 0;
+  const PackLayout L = pack_layout(p.in_dim, out_dim);
+  const float* __restrict__ Pbase = p.packed[net];
+  // K10 keeps one private (t, k) pair per 16-environment workgroup; this workgroup covers two of them
+  const int t0 = p.ro.ctr[4 * blockIdx.x];
+  const int k0 = p.ro.ctr[4 * blockIdx.x + 1];
+  const int C = p.b.C;
+  const int passes = (C + SLOTS - 1) / SLOTS;
+  double* se = s_env + el * L_ENV;
+  double* sq = seqs + el * SEQW;
+
+  // ---------------------------------------------------------------- task state: registers for the whole rollout
+  int phase0 = 0, t1 = 0, t2 = 0, frames = 0, mode = OLY_MODE_STANDING, seq_len = 1, tlen = 0, rc = 0, sc = 0;
+  int reached_last = 0;
+  double goal_last = 0.0;
+  if (env_ok) {
+    phase0 = p.st.phase[n];
+    t1 = p.st.t1[n];
+    t2 = p.st.t2[n];
+    frames = p.st.reached_frames[n];
+    reached_last = p.st.target_reached[n];
+    mode = p.st.mode[n];
+    seq_len = p.st.seq_len[n];
+    tlen = p.ro.traj_len[n];
+    rc = p.ro.pool_count[n];
+    sc = p.ro.side_count[n];
+    if (slot < 8) goal_last = p.st.goal[8 * (size_t)n + slot];
+#pragma unroll
+    for (int q = 0; q < SEQW / SLOTS; ++q) sq[slot + SLOTS * q] = p.st.sequence[(size_t)n * SEQW + slot + SLOTS * q];
+  }
+  t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
+  t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
+  for (int e = tid; e < rows * n_obs; e += THREADS) {
+    const int r = e / n_obs, c = e - r * n_obs;
+    s_post[r * OBP + c] = p.ro.state[(size_t)row0 * n_obs + e];
+  }
+
+  // per-thread constants of the dense sweeps (the element a thread owns does not change from step to step)
+  int ob_src[OBS_PT];                    // LDS offset of observation element tid + q THREADS of the tile
+#pragma unroll
+  for (int q = 0; q < OBS_PT; ++q) {
+    const int e = tid + q * THREADS, r = e / n_obs;
+    ob_src[q] = r * OBP + (e - r * n_obs);
+  }
+  const int xk = tid & (MAX_IN - 1);     // input column this thread stages (THREADS % MAX_IN == 0)
+  float x_mean = 0.f, x_std = 1.f;
+  if (p.normalize[net] && xk < p.in_dim) {
+    x_mean = Pbase[L.mean + xk];
+    x_std = Pbase[L.std + xk];
+  }
+  const int o_row = tid / out_dim, o_col = tid - o_row * out_dim;      // output element this thread finishes
+  const bool o_ok = tid < rows * out_dim;
+  const float o_bias = o_ok ? Pbase[L.b3 + o_col] : 0.f;
+  const float o_scale = (actor && o_ok && !det) ? p.ro.scale[o_col] : 0.f;
+
+  // readback row kk of the staged blocks, one piece per lane (K10's load plan)
+  int dst_b = -1;
+  if (slot < 3) dst_b = L_LV + slot;
+  else if (slot < 6) dst_b = L_RV + slot - 3;
+  else if (slot < 10) dst_b = L_BQ + slot - 6;
+  else if (slot < 13) dst_b = L_AV + slot - 10;
+  auto request = [&](int k, int n, int slot, Readback& rb) {
+    rb.nc_raw = 0; rb.g1_0 = -1; rb.g2_0 = -1;
+    rb.va = rb.vb = rb.v_len = rb.v_vel = rb.pz0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rb.f0[q] = 0.0;
+    if (!env_ok) return;
+    const size_t kN = (size_t)((unsigned)k % (unsigned)p.b.K) * N;
+    rb.nc_raw = p.b.ncon[kN + n];
+    const size_t r3 = (kN + n) * 3, r4 = (kN + n) * 4;
+    if (slot < 4) rb.va = p.b.root_quat[r4 + slot];
+    else if (slot < 7) rb.va = p.b.root_pos[r3 + slot - 4];
+    else if (slot < 10) rb.va = p.b.head_pos[r3 + slot - 7];
+    else if (slot < 13) rb.va = p.b.lf_pos[r3 + slot - 10];
+    else rb.va = p.b.rf_pos[r3 + slot - 13];
+    if (slot < 3) rb.vb = p.b.lf_vel[r3 + slot];
+    else if (slot < 6) rb.vb = p.b.rf_vel[r3 + slot - 3];
+    else if (slot < 10) rb.vb = p.b.qpos[(kN + n) * nq + 3 + slot - 6];
+    else if (slot < 13) rb.vb = p.b.qvel[(kN + n) * nv + 3 + slot - 10];
+    if (slot < nu) {
+      rb.v_len = p.b.act_len[(kN + n) * nu + slot];
+      rb.v_vel = p.b.act_vel[(kN + n) * nu + slot];
+    }
+    if (slot < C) {
+      const size_t e0 = (kN + n) * C + slot;
+      rb.g1_0 = p.b.geom1[e0];
+      rb.g2_0 = p.b.geom2[e0];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rb.f0[q] = p.b.force6[e0 * 6 + q];
+      rb.pz0 = p.b.cpos_z[e0];
+    }
+  };
+  Readback rb;
+  request(k0, n, slot, rb);
+  float eps_next = 0.f;                                      // the noise of the action element this thread samples
+  if (actor && o_ok && !det && t0 < T) eps_next = p.ro.eps[((size_t)t0 * N + row0) * nu + tid];
+  __syncthreads();
+
+  for (int t = t0; t < T; ++t) {
+    const size_t tN = (size_t)t * N;
+    const bool last_step = t == T - 1;
+    // the weight stream is the same every step: an opaque zero offset keeps the compiler from hoisting its
+    // (loop-invariant) loads out of the step loop and spilling them
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    const float* P = Pbase + opaque0;
+    const float4* P4 = reinterpret_cast<const float4*>(P);
+    // likewise the per-lane global addresses of some forty arrays: derived from opaque copies of the lane's
+    // environment / element index they are recomputed where used (a multiply-add) instead of being hoisted out
+    // of the loop as 64-bit registers and spilled
+    int n_t = n, tid_t = tid, slot_t = slot;
+    asm volatile("" : "+v"(n_t), "+v"(tid_t), "+v"(slot_t));
+
+    // ================================================================ forward of obs_t (K11's tile)
+    for (int e = tid; e < MAX_IN * RT; e += THREADS) {
+      const int mrow = e / MAX_IN;
+      float v = 0.f;
+      if (mrow < rows && xk < p.in_dim) {
+        v = s_post[mrow * OBP + xk];
+        if (p.normalize[net]) v = (v - x_mean) / x_std;
+      }
+      xT[xk * LDP + mrow] = v;
+    }
+    if (!actor) {       // memory.store(state, ...): the observation the policy saw (ppo.py:186)
+#pragma unroll
+      for (int q = 0; q < OBS_PT; ++q) {
+        const int e = tid + q * THREADS;
+        if (e < rows * n_obs) p.ro.buf_states[(tN + row0) * n_obs + tid_t + q * THREADS] = s_post[ob_src[q]];
+      }
+    }
+    const float eps_t = eps_next;
+    __syncthreads();
+    {  // ---- layer 1: [32, in <= 64] x [64, 256] (k zero-padded to 64)
+      f32x16 acc = {0};
+      layer_tile<G1>(xT, P4 + (L.w1 >> 2) + (size_t)wave * G1 * 64, lane, acc);
+      store_relu(acc, P + L.b1, 32 * wave, lane, hA);
+    }
+    __syncthreads();
+    {  // ---- layer 2: [32, 256] x [256, 256]
+      f32x16 acc = {0};
+      layer_tile<32>(hA, P4 + (L.w2 >> 2) + (size_t)wave * 32 * 64, lane, acc);
+      store_relu(acc, P + L.b2, 32 * wave, lane, hB);
+    }
+    __syncthreads();
+    {  // ---- layer 3: [32, 256] x [256, out <= 32]; wave w owns k in [32 w, 32 w + 32)
+      f32x16 acc = {0};
+      layer_tile<4>(hB + (size_t)(32 * wave) * LDP, P4 + (L.w3 >> 2) + (size_t)(4 * wave) * 64, lane, acc);
+      const int r = lane & 31, h = lane >> 5;
+      float* part = hA + (size_t)wave * RT * LDP;        // [row][col] partial of this wave
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        part[row * LDP + r] = acc[i];
+      }
+    }
+    __syncthreads();
+    if (o_ok) {
+      float s = hA[o_row * LDP + o_col];
+#pragma unroll
+      for (int w = 1; w < KSPLIT; ++w) s += hA[(w * RT + o_row) * LDP + o_col];
+      s += o_bias;
+      if (actor) {
+        // Normal(mu, std * anneal).sample() from the pre-drawn noise (ppo.py:181), memory.store's action and the
+        // PD target the physics would receive (robot.py:88-95)
+        float a = s;
+        if (!det) {
+          const float scl = o_scale * eps_t;
+          a = s + scl;
+        }
+        p.ro.buf_actions[(tN + row0) * nu + tid_t] = a;
+        if (last_step) {
+          p.ro.pd_target[(size_t)row0 * nu + tid_t] = (double)a + m->motor_offset[o_col];
+          if (p.mu_out) p.mu_out[(size_t)row0 * nu + tid_t] = s;
+        }
+      } else {
+        p.ro.buf_values[tN + row0 + tid_t] = s;
+        if (last_step && p.value_out) p.value_out[row0 + tid_t] = s;
+      }
+    }
+    __syncthreads();     // the activation images are dead: the environment scratch takes their place
+
+    // ================================================================ environment step t (K10's step)
+    if (env_ok) {
+      se[slot] = rb.va;
+      if (dst_b >= 0) se[dst_b] = rb.vb;
+      if (slot < nu) {
+        se[L_AL + slot] = rb.v_len;
+        se[L_AVL + slot] = rb.v_vel;
+      }
+    }
+    // ---- K3: foot contacts of the readback row
+    const int nc_raw = rb.nc_raw;
+    const int nc = min(max(nc_raw, 0), C);
+    int cnt_r = 0, cnt_l = 0;
+    double sum_r = 0.0, sum_l = 0.0, mz = 0.0;
+    bool have = false;
+    for (int ps = 0; ps < passes; ++ps) {
+      const int i = ps * SLOTS + slot;
+      bool is_r = false, is_l = false;
+      double nrm = 0.0, pz = 0.0;
+      if (env_ok && i < nc) {
+        int g1 = rb.g1_0, g2 = rb.g2_0;
+        double f[6] = {rb.f0[0], rb.f0[1], rb.f0[2], rb.f0[3], rb.f0[4], rb.f0[5]};
+        pz = rb.pz0;
+        if (ps > 0) {            // more than 16 contact slots: the later passes load on demand
+          const size_t kN = (size_t)((unsigned)(k0 + (t - t0)) % (unsigned)p.b.K) * N;
+          const size_t e = (kN + n_t) * C + i;
+          g1 = p.b.geom1[e];
+          g2 = p.b.geom2[e];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) f[q] = p.b.force6[e * 6 + q];
+          pz = p.b.cpos_z[e];
+        }
+        if (g1 >= 0 && g1 < p.cd.ngeom && g2 >= 0 && g2 < p.cd.ngeom) {
+          const int b1 = p.cd.geom_bodyid[g1], b2 = p.cd.geom_bodyid[g2];
+          is_r = (b1 == p.cd.floor_body) && (b2 == p.cd.rfoot_body);
+          is_l = (b1 == p.cd.floor_body) && (b2 == p.cd.lfoot_body);
+        }
+        if (is_r || is_l) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) s += f[q] * f[q];
+          nrm = sqrt(s);
+        } else {
+          pz = 0.0;
+        }
+      }
+      const unsigned long long br = __ballot(is_r), bl = __ballot(is_l);
+      const unsigned mr = (unsigned)((br >> (grp * SLOTS)) & 0xffffu);
+      const unsigned ml = (unsigned)((bl >> (grp * SLOTS)) & 0xffffu);
+      cnt_r += __popc(mr);
+      cnt_l += __popc(ml);
+      unsigned rem = mr | ml;   // in-order chain over the matching slots (contact order), as contact_kernel
+      while (__any(rem != 0u)) {
+        const int q = rem ? (__ffs((int)rem) - 1) : 0;
+        const double vk = __shfl(nrm, grp * SLOTS + q, 64);
+        const double zk = __shfl(pz, grp * SLOTS + q, 64);
+        if (rem) {
+          if ((mr >> q) & 1u) sum_r += vk;
+          if ((ml >> q) & 1u) sum_l += vk;
+          if (!have || zk < mz) mz = zk;
+          have = true;
+          rem &= rem - 1u;
+        }
+      }
+    }
+    const double grf_r = sum_r, grf_l = sum_l;
+    const double min_z = have ? mz : 0.0;
+    const bool bad = (cnt_r + cnt_l) != nc_raw;
+    // this step's readback registers are consumed: request step t + 1's rows and noise now, a whole libm phase
+    // and a forward ahead of their use
+    if (!last_step) {
+      request(k0 + (t + 1 - t0), n_t, slot_t, rb);
+      if (actor && o_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + tid_t];
+    }
+    __syncthreads();
+
+    // ---- level 1: everything without libm
+    const double rq0 = se[L_RQ], rq1 = se[L_RQ + 1], rq2 = se[L_RQ + 2], rq3 = se[L_RQ + 3];
+    const double rp0 = se[L_RP], rp1 = se[L_RP + 1], rp2 = se[L_RP + 2];
+    const double lf0 = se[L_LF], lf1 = se[L_LF + 1], lf2 = se[L_LF + 2];
+    const double rf0 = se[L_RF], rf1 = se[L_RF + 1], rf2 = se[L_RF + 2];
+
+    // WalkingTask.step (walking_task.py:246-293)
+    int phase = phase0 + 1;
+    if (phase >= period) phase = 0;
+    const double tx = sq[4 * t1], ty = sq[4 * t1 + 1], tz = sq[4 * t1 + 2];
+    const double dl = vnorm3(lf0 - tx, lf1 - ty, lf2 - tz);
+    const double dr = vnorm3(rf0 - tx, rf1 - ty, rf2 - tz);
+    int reached;
+    if (dl < m->target_radius || dr < m->target_radius) {
+      reached = 1;
+      frames += 1;
+    } else {
+      reached = 0;
+      frames = 0;
+    }
+    if (reached && frames >= m->delay_frames) {  // update_target_steps
+      t1 = t2;
+      t2 += 1;
+      if (t2 == seq_len) t2 = seq_len - 1;
+      t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
+      reached = 0;
+      frames = 0;
+    }
+    const int selA = 4 * t1, selB = 4 * t2;   // sequence[t1] / sequence[t2] after the update
+    const double s1x = sq[selA], s1y = sq[selA + 1], s1z = sq[selA + 2], s1w = sq[selA + 3];
+    const double s2x = sq[selB], s2y = sq[selB + 1], s2z = sq[selB + 2], s2w = sq[selB + 3];
+
+    double R[3][3];
+    quat2mat(rq0, rq1, rq2, rq3, R);
+    double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool walking = mode != OLY_MODE_STANDING;
+    if (walking) {
+      const double a0 = s1x - rp0, a1 = s1y - rp1, a2 = s1z - rp2;
+      const double b0 = s2x - rp0, b1 = s2y - rp1, b2 = s2z - rp2;
+      goal[0] = R[0][0] * a0 + R[1][0] * a1 + R[2][0] * a2;
+      goal[2] = R[0][1] * a0 + R[1][1] * a1 + R[2][1] * a2;
+      goal[4] = R[0][2] * a0 + R[1][2] * a1 + R[2][2] * a2;
+      goal[1] = R[0][0] * b0 + R[1][0] * b1 + R[2][0] * b2;
+      goal[3] = R[0][1] * b0 + R[1][1] * b1 + R[2][1] * b2;
+      goal[5] = R[0][2] * b0 + R[1][2] * b1 + R[2][2] * b2;
+    }
+
+    // calc_reward arguments (walking_task.py:74-110, tasks/rewards.py:27-40,65-102,121-126)
+    double c_rfrc, c_rvel, c_lfrc, c_lvel;
+    if (!walking) {
+      c_rfrc = 1.0; c_lfrc = 1.0; c_rvel = -1.0; c_lvel = -1.0;
+    } else {
+      c_rfrc = m->clock_lut[0 * period + phase];
+      c_rvel = m->clock_lut[1 * period + phase];
+      c_lfrc = m->clock_lut[2 * period + phase];
+      c_lvel = m->clock_lut[3 * period + phase];
+    }
+    const double max_frc = m->mass * 9.8 * 0.5;
+    double nl = fmin(grf_l, max_frc) / max_frc;
+    double nr = fmin(grf_r, max_frc) / max_frc;
+    nl *= 2; nl -= 1; nr *= 2; nr -= 1;
+    double vl = fmin(vnorm3(se[L_LV], se[L_LV + 1], se[L_LV + 2]), 0.2) / 0.2;
+    double vr = fmin(vnorm3(se[L_RV], se[L_RV + 1], se[L_RV + 2]), 0.2) / 0.2;
+    vl *= 2; vl -= 1; vr *= 2; vr -= 1;
+    const double contact_point = (cnt_r > 0 || cnt_l > 0) ? min_z : 0.0;
+    double err = fabs((rp2 - contact_point) - m->goal_height_ref);
+    const double deadzone = 0.01 + 0.05 * m->goal_speed_ref;
+    if (err < deadzone) err = 0;
+    const double fd = fmin(vnorm3(lf0 - s1x, lf1 - s1y, lf2 - s1z), vnorm3(rf0 - s1x, rf1 - s1y, rf2 - s1z));
+    const double mpx = (s1x + s2x) / 2, mpy = (s1y + s2y) / 2;
+    const double rx = rp0 - mpx, ry = rp1 - mpy;
+    const double hx = se[L_HP] - rp0, hy = se[L_HP + 1] - rp1;
+    const double hn = sqrt(hx * hx + hy * hy);
+
+    // done (walking_task.py:298-319) and the rollout's cut rule (ppo.py:178,189-196)
+    const double foot_z = fmin(lf2, rf2);
+    const bool done = ((rp2 - foot_z) < 0.6) || bad;
+    const int len = tlen + 1;
+    const bool cut = done || len >= p.ro.max_traj_len || last_step;
+    const bool need_reset = env_ok && cut && !last_step;
+
+    // get_obs: quat2euler(qpos[3:7]) (StickFigureA3.py:160)
+    double Rb[3][3];
+    quat2mat(se[L_BQ], se[L_BQ + 1], se[L_BQ + 2], se[L_BQ + 3], Rb);
+    const double cyb = sqrt(Rb[0][0] * Rb[0][0] + Rb[1][0] * Rb[1][0]);
+    const bool regular = cyb > 4.0 * EPS;
+    const double roll_y = regular ? Rb[2][1] : -Rb[1][2];
+    const double roll_x = regular ? Rb[2][2] : Rb[1][1];
+
+    // env.reset(): the next pool record (mode / phase / local sequence), drawn on the host.  K10 fetches the record
+    // with every step's first loads; a persistent workgroup sees a reset in about one step of ten, so the record is
+    // requested here, where the cut is known: the header is needed by round 1, the rows only after round 2.
+    int new_mode = mode, new_phase = 0, new_len = seq_len;
+    double rec_seq[(OLY_MAX_SEQ + SLOTS - 1) / SLOTS][4];
+#pragma unroll
+    for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q)
+      rec_seq[q][0] = rec_seq[q][1] = rec_seq[q][2] = rec_seq[q][3] = 0.0;
+    if (need_reset) {
+      const oly_a3_reset_record* rec = p.ro.pool + (size_t)n_t * p.ro.pool_depth + (unsigned)rc % (unsigned)p.ro.pool_depth;
+      new_mode = rec->mode;
+      new_phase = rec->phase;
+      new_len = min(max(rec->seq_len, 1), OLY_MAX_SEQ);
+#pragma unroll
+      for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
+        const int r = slot + SLOTS * q;
+        if (r < OLY_MAX_SEQ) {
+          rec_seq[q][0] = rec->seq[r][0]; rec_seq[q][1] = rec->seq[r][1];
+          rec_seq[q][2] = rec->seq[r][2]; rec_seq[q][3] = rec->seq[r][3];
+        }
+      }
+    }
+    // root yaw for transform_sequence: quat2euler(root xquat)[2] = mat2euler's ak
+    const double cyr = sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
+
+    // ---- round 1: one libm call per lane (arguments formed by the environment's lanes, evaluation regrouped by
+    // function over the waves: waves 0 / 4 sin-cos, 1 / 5 tan, 2 / 6 exp, 3 / 7 atan2, 16 environments each)
+    int cls = F_NONE;
+    double a = 0.0, b = 0.0;
+    switch (slot) {
+      case 0: if (walking) { cls = F_SINCOS; a = s1w; } break;                       // goal yaw 1: cos / sin(theta)
+      case 1: if (walking) { cls = F_SINCOS; a = s2w; } break;
+      case 2: cls = F_TAN; a = PI / 4 * c_lfrc * nl; break;                          // foot-force clock terms
+      case 3: cls = F_TAN; a = PI / 4 * c_rfrc * nr; break;
+      case 4: cls = F_TAN; a = PI / 4 * c_lvel * vl; break;                          // foot-velocity clock terms
+      case 5: cls = F_TAN; a = PI / 4 * c_rvel * vr; break;
+      case 6: cls = F_SINCOS; a = s1w / 2.0; break;                                  // euler2quat(0,0,yaw) of the target
+      case 7: cls = F_EXP; a = -40 * (err * err); break;                             // height
+      case 8: cls = F_EXP; a = -fd / 0.25; break;                                    // target hit
+      case 9: cls = F_EXP; a = -sqrt(rx * rx + ry * ry) / 2; break;                  // progress
+      case 10: cls = F_EXP; a = -10 * (hn * hn); break;                              // upper body
+      case 11: cls = F_ATAN2; a = roll_y; b = roll_x; break;                         // roll
+      case 12: cls = F_ATAN2; a = -Rb[2][0]; b = cyb; break;                         // pitch
+      case 13: cls = F_SINCOS; a = 2 * PI * phase / (double)period; break;           // clock
+      case 14: if (need_reset && cyr > 4.0 * EPS) { cls = F_ATAN2; a = R[1][0]; b = R[0][0]; } break;   // root yaw
+      default: if (need_reset) { cls = F_SINCOS; a = 2 * PI * new_phase / (double)period; } break;      // clock after reset
+    }
+    s_arg[(el * SLOTS + slot) * 2] = a;
+    s_arg[(el * SLOTS + slot) * 2 + 1] = b;
+    s_cls[el * SLOTS + slot] = (uint8_t)(env_ok ? cls : F_NONE);
+    __syncthreads();
+    double r0, r1;
+    const int ee = 16 * (wave >> 2) + (lane & 15);
+    {
+      constexpr int R1_TASK[4][4] = {{0, 1, 6, 13}, {2, 3, 4, 5}, {7, 8, 9, 10}, {11, 12, 14, -1}};
+      const int task = R1_TASK[wave & 3][lane >> 4];
+      if (task >= 0) {
+        eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
+        s_env[ee * L_ENV + L_R1 + 2 * task] = r0;
+        s_env[ee * L_ENV + L_R1 + 2 * task + 1] = r1;
+      }
+    }
+    __syncthreads();
+
+    // ---- round 2
+    const double root_yaw = se[L_R1 + 2 * 14];
+    cls = F_NONE;
+    a = 0.0;
+    b = 0.0;
+    switch (slot) {
+      case 0:
+      case 1:
+        if (walking) {   // theta = mat2euler(R^T Rz(yaw))[2] = atan2(M10, M00)
+          const double c = se[L_R1 + 2 * slot + 1], sn = se[L_R1 + 2 * slot];
+          cls = F_ATAN2;
+          a = R[0][1] * c + R[1][1] * sn;
+          b = R[0][0] * c + R[1][0] * sn;
+        }
+        break;
+      case 2: {          // body orientation: exp(-10 (1 - <q_ref, q>^2))
+        const double tq0 = se[L_R1 + 2 * 6 + 1], tq3 = se[L_R1 + 2 * 6];
+        const double ip = tq0 * rq0 + 0.0 * rq1 + 0.0 * rq2 + tq3 * rq3;
+        cls = F_EXP;
+        a = -(10 * (1 - ip * ip));
+      } break;
+      case 3: cls = F_SINCOS; a = se[L_R1 + 2 * 11] / 2.0; break;                    // roll / 2
+      case 4: cls = F_SINCOS; a = se[L_R1 + 2 * 12] / 2.0; break;                    // pitch / 2
+      case 5: if (need_reset) { cls = F_SINCOS; a = root_yaw; } break;               // transform_sequence rotation
+      default: break;
+    }
+    if (slot < 6) {
+      s_arg[(el * SLOTS + slot) * 2] = a;
+      s_arg[(el * SLOTS + slot) * 2 + 1] = b;
+      s_cls[el * SLOTS + slot] = (uint8_t)(env_ok ? cls : F_NONE);
+    }
+    __syncthreads();
+    {
+      // waves 0 / 4: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's clock-after-reset, slot 15, which only
+      // needed level-1 values); 1 / 5: atan2 (the two goal yaws); 2 / 6: exp (orientation); 3 / 7: idle
+      constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
+      const int task = R2_TASK[wave & 3][lane >> 4];
+      if (task >= 0) {
+        eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
+        const int dst = task == 15 ? L_R1 + 2 * 15 : L_R2 + 2 * task;
+        s_env[ee * L_ENV + dst] = r0;
+        s_env[ee * L_ENV + dst + 1] = r1;
+      }
+    }
+    __syncthreads();
+
+    // ---- combine, observation rows
+    float* op = s_pre + el * OBP;
+    float* oq = s_post + el * OBP;
+    if (env_ok) {
+      if (walking) {
+        goal[6] = se[L_R2 + 0];
+        goal[7] = se[L_R2 + 2];
+      }
+      const double ci = se[L_R2 + 2 * 3 + 1], si = se[L_R2 + 2 * 3], cj = se[L_R2 + 2 * 4 + 1], sj = se[L_R2 + 2 * 4];
+      if (slot == 0) op[0] = (float)(ci * cj);
+      if (slot == 1) op[1] = (float)(si * cj);
+      if (slot == 2) op[2] = (float)(ci * sj);
+      if (slot == 3) op[3] = (float)(-(si * sj));
+      if (slot >= 4 && slot < 7) op[slot] = (float)se[L_AV + slot - 4];
+      if (slot < nu) {
+        const double g = m->gear[slot];
+        op[7 + slot] = (float)(se[L_AL + slot] / g);
+        op[7 + nu + slot] = (float)(se[L_AVL + slot] / g);
+      }
+      if (slot == 7) op[7 + 2 * nu] = (float)se[L_R1 + 2 * 13];
+      if (slot == 8) op[8 + 2 * nu] = (float)se[L_R1 + 2 * 13 + 1];
+      if (slot >= 8) op[9 + 2 * nu + slot - 8] = (float)goal[slot - 8];
+    }
+    __syncthreads();
+    if (env_ok) {
+      for (int c = slot; c < n_obs; c += SLOTS) {
+        float v = op[c];
+        if (need_reset) {   // get_obs of the freshly reset task: goal steps zero, clock of the drawn phase
+          if (c == 7 + 2 * nu) v = (float)se[L_R1 + 2 * 15];
+          else if (c == 8 + 2 * nu) v = (float)se[L_R1 + 2 * 15 + 1];
+          else if (c >= 9 + 2 * nu) v = 0.0f;
+        }
+        oq[c] = v;
+      }
+
+      // ---- rewards, flags (stored by the actor workgroup only)
+      if (actor && slot == 0) {
+        const double frc = (se[L_R1 + 2 * 2] + se[L_R1 + 2 * 3]) / 2;
+        const double vel = (se[L_R1 + 2 * 4] + se[L_R1 + 2 * 5]) / 2;
+        const double orient = se[L_R2 + 2 * 2];
+        const double height = se[L_R1 + 2 * 7];
+        const double hit = reached ? se[L_R1 + 2 * 8] : 0.0;
+        const double progress = se[L_R1 + 2 * 9];
+        const double step_r = 0.8 * hit + 0.2 * progress;
+        const double upper = se[L_R1 + 2 * 10];
+        double rew[6];
+        rew[0] = 0.150 * frc;
+        rew[1] = 0.150 * vel;
+        rew[2] = 0.050 * orient;
+        rew[3] = 0.050 * height;
+        rew[4] = 0.450 * step_r;
+        rew[5] = 0.050 * upper;
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          tot += rew[i];
+          if (p.ro.buf_rew6) p.ro.buf_rew6[(tN + n_t) * 6 + i] = (float)rew[i];
+        }
+        p.ro.buf_rewards[tN + n_t] = tot;
+        p.ro.buf_flags[tN + n_t] = (uint8_t)((cut ? OLY_FLAG_LAST : 0) | (done ? OLY_FLAG_ABSORBING : 0));
+      }
+      // bootstrap row: finish_path's last_val = (not done) * V(state) needs V of THIS observation
+      if (cut && !done) {
+        if (actor && sc < p.ro.side_slots) {
+          const size_t srow = (size_t)n_t * p.ro.side_slots + sc;
+          for (int c = slot; c < n_obs; c += SLOTS) p.ro.side_obs[srow * n_obs + c] = op[c];
+          if (slot == 0) p.ro.side_t[srow] = t;
+        }
+        sc += 1;
+      }
+      tlen = cut ? 0 : len;
+      if (need_reset) {
+        // WalkingTask.reset (walking_task.py:321-397) + transform_sequence (:113-135)
+        const double cyw = se[L_R2 + 2 * 5 + 1], syw = se[L_R2 + 2 * 5];
+        const double mid0 = (lf0 + rf0) / 2, mid1 = (lf1 + rf1) / 2;
+#pragma unroll
+        for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
+          const int r = slot + SLOTS * q;
+          if (r >= OLY_MAX_SEQ) continue;
+          double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+          if (r < new_len) {
+            const double x = rec_seq[q][0], y = rec_seq[q][1], z = rec_seq[q][2], th = rec_seq[q][3];
+            o0 = mid0 + x * cyw - y * syw;
+            o1 = mid1 + x * syw + y * cyw;
+            o2 = z;
+            o3 = root_yaw + th;
+          }
+          sq[4 * r] = o0; sq[4 * r + 1] = o1; sq[4 * r + 2] = o2; sq[4 * r + 3] = o3;
+        }
+        phase0 = new_phase;
+        t1 = 0;
+        t2 = (new_len == 1) ? 0 : 1;        // t1 = t2 = 0, then update_target_steps
+        frames = 0;
+        reached_last = 0;
+        mode = new_mode;
+        seq_len = new_len;
+        rc += 1;
+        goal_last = 0.0;
+      } else {
+        phase0 = phase;
+        reached_last = reached;
+        if (slot < 8) goal_last = goal[slot];
+      }
+    }
+    __syncthreads();     // s_post is complete (the next forward stages it); the scratch may be overwritten
+  }
+
+  // ---------------------------------------------------------------- the rollout is over: leave the state K10 would
+  if (t0 >= T) return;
+  if (actor) {
+    if (env_ok) {
+      if (slot == 0) {
+        p.st.phase[n] = phase0;
+        p.st.t1[n] = t1;
+        p.st.t2[n] = t2;
+        p.st.reached_frames[n] = frames;
+        p.st.target_reached[n] = (uint8_t)reached_last;
+        const_cast<int32_t*>(p.st.mode)[n] = mode;
+        const_cast<int32_t*>(p.st.seq_len)[n] = seq_len;
+        p.ro.traj_len[n] = tlen;
+        p.ro.pool_count[n] = rc;
+        p.ro.side_count[n] = sc;
+      }
+      if (slot < 8) p.st.goal[8 * (size_t)n + slot] = goal_last;
+      double* seq_out = const_cast<double*>(p.st.sequence) + (size_t)n * SEQW;
+#pragma unroll
+      for (int q = 0; q < SEQW / SLOTS; ++q) seq_out[slot + SLOTS * q] = sq[slot + SLOTS * q];
+    }
+    for (int e = tid; e < rows * n_obs; e += THREADS) {
+      const int r = e / n_obs, c = e - r * n_obs;
+      p.ro.state[(size_t)row0 * n_obs + e] = s_post[r * OBP + c];
+    }
+    if (tid < 2 && 2 * blockIdx.x + tid < (unsigned)((N + 15) / 16)) {
+      p.ro.ctr[4 * blockIdx.x + 2 * tid] = T;
+      p.ro.ctr[4 * blockIdx.x + 2 * tid + 1] = k0 + (T - t0);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_blocks* blocks, const oly_a3_state* st,
+                                         const oly_a3_rollout* ro, int in_dim, const float* packed_actor,
+                                         int normalize_actor, const float* packed_critic, int normalize_critic,
+                                         float* mu_out, float* value_out, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_rollout_persistent before oly_a3_configure");
+  if (!ctx->contact_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_rollout_persistent before oly_contact_configure");
+  if (N < 0 || !blocks || !st || !ro) OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: bad argument");
+  if (N == 0) return OLY_OK;
+  if (blocks->K <= 0 || blocks->C <= 0 || ro->T <= 0 || ro->pool_depth <= 0 || ro->side_slots < 0)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: bad sizes (K=%d C=%d T=%d pool_depth=%d)", blocks->K,
+             blocks->C, ro->T, ro->pool_depth);
+  const void* req[] = {blocks->qpos, blocks->qvel, blocks->act_len, blocks->act_vel, blocks->lf_pos, blocks->rf_pos,
+                       blocks->lf_vel, blocks->rf_vel, blocks->root_pos, blocks->root_quat, blocks->head_pos,
+                       blocks->ncon, blocks->geom1, blocks->geom2, blocks->force6, blocks->cpos_z,
+                       st->phase, st->t1, st->t2, st->reached_frames, st->target_reached, st->mode, st->seq_len,
+                       st->sequence, st->goal, ro->state, ro->pool, ro->pool_count, ro->ctr, ro->traj_len,
+                       ro->pd_target, ro->buf_states, ro->buf_actions, ro->buf_rewards, ro->buf_values, ro->buf_flags,
+                       ro->side_obs, ro->side_t, ro->side_count, packed_actor, packed_critic};
+  for (const void* q : req)
+    if (!q) OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: NULL pointer in blocks / state / rollout / weights");
+  if (!ro->deterministic && (!ro->scale || !ro->eps))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: stochastic rollout without scale / eps");
+  if (ctx->a3_host.nu > MAX_NU || ctx->a3_host.nu > MAX_OUT)
+    OLY_FAIL(ctx, OLY_ERANGE, "oly_a3_rollout_persistent: nu > %d", MAX_NU);
+  if (in_dim != ctx->a3_host.n_obs || in_dim > MAX_IN || in_dim > MAX_NOBS)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: the networks read %d inputs, the observation has %d", in_dim,
+             ctx->a3_host.n_obs);
+  if (((reinterpret_cast<uintptr_t>(packed_actor) | reinterpret_cast<uintptr_t>(packed_critic)) & 15) != 0)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: packed weights must be 16-byte aligned");
+  if (!ctx->roll_attr_done) {
+    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROLL_LDS));
+    ctx->roll_attr_done = true;
+  }
+  RollArgs a;
+  a.md = ctx->a3_dev;
+  a.cd = ctx->contact;
+  a.N = N;
+  a.in_dim = in_dim;
+  a.b = *blocks;
+  a.st = *st;
+  a.ro = *ro;
+  a.packed[0] = packed_actor;
+  a.packed[1] = packed_critic;
+  a.out_dim[0] = ctx->a3_host.nu;
+  a.out_dim[1] = 1;
+  a.normalize[0] = normalize_actor;
+  a.normalize[1] = normalize_critic;
+  a.mu_out = mu_out;
+  a.value_out = value_out;
+  hipLaunchKernelGGL(a3_rollout_kernel, dim3((N + EPW - 1) / EPW, 2), dim3(THREADS), ROLL_LDS, oly_s(stream), a);
+  OLY_LAUNCH_CHECK(ctx, "a3_rollout_kernel");
+  return OLY_OK;
+}

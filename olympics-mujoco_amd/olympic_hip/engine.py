@@ -372,6 +372,23 @@ class Engine:
             if rc:
                 check(h, rc, "oly_a3_vec_step")
             return keep
+        pfn = lib().oly_a3_rollout_persistent
+
+        def persistent(packed_actor, norm_actor, packed_critic, norm_critic, mu_out=None, value_out=None):
+            """The remaining steps of the rollout (device counter t .. T - 1) in ONE launch (K13): per step the
+            actor + critic forward on the packed weights, then this same vec step; bit-identical buffers."""
+            for name, w, od in (("packed_actor", packed_actor, nu), ("packed_critic", packed_critic, 1)):
+                _req(w, name, (self._mlp_floats(nobs, od),), f32, dv)
+            if mu_out is not None:
+                _req(mu_out, "mu_out", (N, nu), f32, dv)
+            if value_out is not None:
+                _req(value_out, "value_out", (N,), f32, dv)
+            rc = pfn(h, N, C.byref(cb), C.byref(cst), C.byref(cr), nobs, ptr(packed_actor), int(bool(norm_actor)),
+                     ptr(packed_critic), int(bool(norm_critic)), ptr(mu_out), ptr(value_out), self._s())
+            if rc:
+                check(h, rc, "oly_a3_rollout_persistent")
+            return keep
+        launch.persistent = persistent
         return launch
 
     def a3_pd_target(self, action):

@@ -90,14 +90,21 @@ class FusedMLPForward:
         t = torch.as_tensor(sd, dtype=torch.float32, device=state.device).reshape(-1)
         return t.expand(act_dim).contiguous() if t.numel() == 1 else t.contiguous()
 
+    def outputs(self, N):
+        """(mu [N,A], value [N]) static output tensors: the same addresses every step (graph replay)."""
+        if N not in self._out:
+            dev = self.eng.device
+            self._out[N] = (torch.empty((N, self.act_dim), dtype=torch.float32, device=dev),
+                            torch.empty((N, 1), dtype=torch.float32, device=dev))
+        mu, v = self._out[N]
+        return mu, v.view(N)
+
     def __call__(self, state):
         N = int(state.shape[0])
-        if N not in self._out:          # static outputs: the same addresses every step (graph replay)
-            self._out[N] = (torch.empty((N, self.act_dim), dtype=torch.float32, device=state.device),
-                            torch.empty((N, 1), dtype=torch.float32, device=state.device))
-        mu, v = self._out[N]
-        self.eng.mlp_forward2(state, self.packed_a, self.act_dim, mu, self.packed_c, 1, v, self.norm_a, self.norm_c)
-        return mu, v.view(N)
+        mu, v = self.outputs(N)
+        self.eng.mlp_forward2(state, self.packed_a, self.act_dim, mu, self.packed_c, 1, v.view(N, 1), self.norm_a,
+                              self.norm_c)
+        return mu, v
 
     def value(self, x):
         """critic alone on [M, in] rows (the bootstrap side list)."""

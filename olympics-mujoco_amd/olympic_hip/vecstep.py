@@ -174,10 +174,12 @@ class A3DeviceRollout:
     # ------------------------------------------------------------------ the rollout
     @torch.no_grad()
     def rollout(self, policy, critic, T, max_traj_len, deterministic=False, anneal=1.0, graph=True, graph_steps=8,
-                forward=None):
+                forward=None, persistent=None):
         """Fills and returns the RolloutBuffer (states, actions, float64 rewards, values, next_values,
         flags), exactly what PPO.sample + finish_path's bootstrap need.  `forward(state) -> (mu, value)`
-        defaults to the modules' torch forward."""
+        defaults to the fused K11 forward (the modules' torch forward for other network shapes).
+        persistent (default: whenever the forward is the fused one): all T steps in ONE launch (K13,
+        oly_a3_rollout_persistent) instead of T x (K11 + K10); the buffers are bit-identical."""
         self._ensure(int(T), int(max_traj_len), deterministic)
         fw = forward if forward is not None else self._default_forward(policy, critic)
         if hasattr(fw, "refresh"):
@@ -193,6 +195,17 @@ class A3DeviceRollout:
             self.eps.normal_()
             self.scale.copy_(fw.std(self.state_obs, self.spec.nu) * float(anneal))
         self.launch(_abi.VSTEP_RESET_ALL)
+        from .mlp import FusedMLPForward
+        fused = isinstance(fw, FusedMLPForward)
+        if persistent is None:
+            persistent = fused
+        if persistent:
+            if not fused:
+                raise OlyError("persistent rollout needs the fused MLP forward (2 x 256 relu actor / critic)")
+            mu, v = fw.outputs(N)
+            self.launch.persistent(fw.packed_a, fw.norm_a, fw.packed_c, fw.norm_c, mu, v)
+            self._finalize(fw, critic)
+            return buf
 
         def one_step():
             mu, value = fw(self.state_obs)

@@ -234,7 +234,8 @@ def test_device_rollout_graph_replay_equals_eager_loop(deterministic):
     for graph in (False, True):
         env = _make_env(N, 7, seed=3)
         torch.manual_seed(11)                                     # the action noise block
-        buf = env.device_rollout(pi, vf, T, max_len, deterministic=deterministic, anneal=0.7, graph=graph)
+        buf = env.device_rollout(pi, vf, T, max_len, deterministic=deterministic, anneal=0.7, graph=graph,
+                                 persistent=False)
         out.append((buf, {k: v.clone() for k, v in env.state.items()}, dict(env._dev_rollout.last_info)))
     (a, sa, ia), (b, sb, ib) = out
     for name in ("states", "actions", "rewards", "values", "next_values", "flags"):
@@ -257,6 +258,62 @@ def test_device_rollout_graph_replay_equals_eager_loop(deterministic):
     else:
         z = (a.actions - mu) / (float(pi.fixed_std) * 0.7)
         assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+
+
+@pytest.mark.parametrize("N,T,max_len,det,K", [(512, 27, 10, False, 7), (500, 13, 4, True, 5), (37, 40, 100, False, 3),
+                                               (4096, 24, 8, False, 32), (1, 9, 3, False, 4)])
+def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K):
+    """K13 (oly_a3_rollout_persistent: ONE launch for the whole rollout, a workgroup owns 32 environments through all
+    T steps, observations / task state never leave the CU) against T rounds of K11 + K10 from the same start: every
+    buffer, the bootstrap side list, the final task state, the next observation, the PD targets, the pool cursors and
+    the device counters are BIT-identical (integer, float32 and float64 alike), for full and ragged tiles, with the
+    actor's input normalisation on, two rollouts in a row (the second continues the replay row and the pools)."""
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    torch.manual_seed(5)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    g = torch.Generator().manual_seed(1)
+    pi.obs_mean = (0.1 * torch.randn(41, generator=g)).cuda()
+    pi.obs_std = (1.0 + 0.2 * torch.rand(41, generator=g)).cuda()
+    out = []
+    for persistent in (False, True):
+        env = _make_env(N, K, seed=3, p_bad=0.03)
+        snaps = []
+        for it in range(2):
+            torch.manual_seed(11 + it)                            # the action noise block
+            env.device_rollout(pi, vf, T, max_len, deterministic=det, anneal=0.7, graph=False, persistent=persistent)
+            r = env._dev_rollout
+            named = dict(states=r.buf.states, actions=r.buf.actions, rewards=r.buf.rewards, values=r.buf.values,
+                         next_values=r.buf.next_values, flags=r.buf.flags, state_obs=r.state_obs, pd_target=r.pd_target,
+                         traj_len=r.traj_len, side_obs=r.side_obs, side_t=r.side_t, side_count=r.side_count,
+                         pool_count=r.pool_count, ctr=r.ctr, mu=r._fw.outputs(N)[0], value=r._fw.outputs(N)[1])
+            named.update({"st_" + k: v for k, v in env.state.items()})
+            snaps.append(({k: v.clone() for k, v in named.items()}, dict(r.last_info), env.physics.k))
+        out.append(snaps)
+    for (a, ia, ka), (b, ib, kb) in zip(*out):
+        for name in a:
+            assert a[name].dtype == b[name].dtype and torch.equal(a[name], b[name]), name
+        assert ia == ib and ka == kb
+    last = (out[1][0][0]["flags"] & _abi.FLAG_LAST).bool()
+    assert bool(last[-1].all()) and (N < 32 or int(last[:-1].sum()) > 0), "the case must exercise device-side resets"
+
+
+def test_persistent_rollout_keeps_the_reward_terms_and_rejects_other_forwards():
+    """buf_rew6 through K13, and the error when the forward is not the fused one."""
+    from olympic_hip._ffi import OlyError
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    from olympic_hip.vecstep import A3DeviceRollout, TorchForward
+    torch.manual_seed(2)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    res = []
+    for persistent in (False, True):
+        env = _make_env(96, 6, seed=8)
+        env._dev_rollout = A3DeviceRollout(env, env.physics.blocks, rs=np.random.RandomState(3), keep_rew6=True)
+        torch.manual_seed(4)
+        env.device_rollout(pi, vf, 12, 5, anneal=1.0, graph=False, persistent=persistent)
+        res.append(env._dev_rollout.rew6.clone())
+    assert torch.equal(res[0], res[1]) and float(res[1].abs().sum()) > 0
+    with pytest.raises(OlyError, match="fused MLP forward"):
+        env.device_rollout(pi, vf, 12, 5, graph=False, persistent=True, forward=TorchForward(pi, vf))
 
 
 def test_ppo_train_on_the_device_rollout(tmp_path):
