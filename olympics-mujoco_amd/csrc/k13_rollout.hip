@@ -27,6 +27,8 @@
 // chains added in wave order, bias last), the environment step K10's, expression for expression, on the same libm
 // entry points (a3_vec_core.h, -ffp-contract=off): buffers and final state are BIT-IDENTICAL to T rounds of
 // oly_mlp_forward2 + oly_a3_vec_step (tests/test_gpu_vecstep.py).
+#include <cstdlib>
+
 #include "a3_vec_core.h"
 #include "mlp_tiles.h"
 #include "oly_common.h"
@@ -74,6 +76,7 @@ struct RollArgs {
   int out_dim[2], normalize[2];
   float* mu_out;       // [N,nu] mean of the LAST forward (what ro.mu holds after the two-kernel loop), or NULL
   float* value_out;    // [N]    value of the last forward, or NULL
+  int skip;            // diagnostic (OLY_K13_SKIP, tools/time_k13.py): bit 0 no MFMA layers, bit 1 no environment step
 };
 
 constexpr size_t ROLL_LDS = sizeof(float) * (MAX_IN + 2 * HID) * LDP + sizeof(double) * EPW * SEQW +
@@ -246,19 +249,20 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     }
     const float eps_t = eps_next;
     __syncthreads();
-    {  // ---- layer 1: [32, in <= 64] x [64, 256] (k zero-padded to 64)
+    const bool run_mlp = !(p.skip & 1);
+    if (run_mlp) {  // ---- layer 1: [32, in <= 64] x [64, 256] (k zero-padded to 64)
       f32x16 acc = {0};
       layer_tile<G1>(xT, P4 + (L.w1 >> 2) + (size_t)wave * G1 * 64, lane, acc);
       store_relu(acc, P + L.b1, 32 * wave, lane, hA);
     }
     __syncthreads();
-    {  // ---- layer 2: [32, 256] x [256, 256]
+    if (run_mlp) {  // ---- layer 2: [32, 256] x [256, 256]
       f32x16 acc = {0};
       layer_tile<32>(hA, P4 + (L.w2 >> 2) + (size_t)wave * 32 * 64, lane, acc);
       store_relu(acc, P + L.b2, 32 * wave, lane, hB);
     }
     __syncthreads();
-    {  // ---- layer 3: [32, 256] x [256, out <= 32]; wave w owns k in [32 w, 32 w + 32)
+    if (run_mlp) {  // ---- layer 3: [32, 256] x [256, out <= 32]; wave w owns k in [32 w, 32 w + 32)
       f32x16 acc = {0};
       layer_tile<4>(hB + (size_t)(32 * wave) * LDP, P4 + (L.w3 >> 2) + (size_t)(4 * wave) * 64, lane, acc);
       const int r = lane & 31, h = lane >> 5;
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     __syncthreads();     // the activation images are dead: the environment scratch takes their place
 
     // ================================================================ environment step t (K10's step)
+    if (p.skip & 2) continue;
     if (env_ok) {
       se[slot] = rb.va;
       if (dst_b >= 0) se[dst_b] = rb.vb;
@@ -761,6 +766,8 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
   a.normalize[1] = normalize_critic;
   a.mu_out = mu_out;
   a.value_out = value_out;
+  static const int skip = [] { const char* e = getenv("OLY_K13_SKIP"); return e ? atoi(e) : 0; }();
+  a.skip = skip;
   hipLaunchKernelGGL(a3_rollout_kernel, dim3((N + EPW - 1) / EPW, 2), dim3(THREADS), ROLL_LDS, oly_s(stream), a);
   OLY_LAUNCH_CHECK(ctx, "a3_rollout_kernel");
   return OLY_OK;

@@ -33,14 +33,17 @@ REC = np.dtype([("mode", "<i4"), ("phase", "<i4"), ("seq_len", "<i4"), ("pad", "
 assert REC.itemsize == C.sizeof(_abi.A3ResetRecord) == 656
 
 
-def draw_reset_records(rs, count, spec, iter_count=0):
+def draw_reset_records(rs, count, spec, iter_count=0, out=None):
     """`count` draws of WalkingTask.reset's random part, vectorised (walking_task.py:353-392 with
     generate_step_sequence :137-182): phase in {0, period/2}, mode STANDING 0.2 / FORWARD 0.8, step
     height +-h(iteration), first-step offset U(0.095, 0.105), the step index c ~ randint(2,4) after
     which the height accumulates.  Sequences are LOCAL (before transform_sequence); x / z accumulate by
-    repeated addition exactly like the reference's loop."""
+    repeated addition exactly like the reference's loop.  `out`: a REC array of `count` entries to fill
+    (e.g. a view of pinned staging memory) instead of a new one."""
     period = int(np.floor(2 * spec.total_duration * (1 / spec.control_dt)))
-    rec = np.zeros(count, REC)
+    rec = np.zeros(count, REC) if out is None else out
+    if rec.shape != (count,) or rec.dtype != REC:
+        raise OlyError("draw_reset_records: `out` must be a REC array of `count` entries")
     phase = rs.choice([0, period / 2], size=count).astype(np.int64)
     mode = rs.choice([_abi.MODE_STANDING, _abi.MODE_BACKWARD, _abi.MODE_LATERAL, _abi.MODE_FORWARD], size=count,
                      p=[0.2, 0, 0, 0.8])
@@ -63,7 +66,7 @@ def draw_reset_records(rs, count, spec, iter_count=0):
         z = np.where(i > c, z + step_height, z)
         seq[:, i, 0], seq[:, i, 1], seq[:, i, 2] = x, y, z
     seq[~fwd, 1:] = 0.0
-    rec["mode"], rec["phase"], rec["seq_len"] = mode, phase, np.where(fwd, 20, 1)
+    rec["mode"], rec["phase"], rec["seq_len"], rec["pad"] = mode, phase, np.where(fwd, 20, 1), 0
     rec["seq"] = seq
     return rec
 
@@ -113,7 +116,6 @@ class A3DeviceRollout:
         self.depth = int(pool_depth)
         self.keep_rew6 = keep_rew6
         dev, N = self.eng.device, self.N
-        self.pool_host = np.zeros((N, self.depth), REC)
         self.pool = torch.zeros(N * self.depth * REC.itemsize, dtype=torch.uint8, device=dev)
         self.pool_count = torch.zeros(N, dtype=torch.int32, device=dev)
         self.ctr = torch.zeros(self.eng.a3_vec_ctr_len(N), dtype=torch.int32, device=dev)
@@ -121,23 +123,46 @@ class A3DeviceRollout:
         self.pd_target = torch.zeros((N, self.spec.nu), dtype=torch.float64, device=dev)
         self.traj_len = torch.zeros(N, dtype=torch.int32, device=dev)
         self.scale = torch.zeros(self.spec.nu, dtype=torch.float32, device=dev)
-        self._fresh = np.zeros(N, np.int64)          # records of each ring still unused
+        # two pinned stashes of pre-drawn records, used alternately: one is being uploaded (asynchronously) while the
+        # other is refilled on the host behind the next rollout's kernels
+        cap = N * self.depth
+        self._stash_t = [torch.empty(cap * REC.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self._stash = [t.numpy().view(REC) for t in self._stash_t]
+        self._stash_n, self._stash_i = 0, 0
+        self._last_total = N
+        self._env_ids = torch.arange(N, device=dev)
         self._shape = None
         self._graphs = {}
         self.last_info = {}
         self._refill(np.full(N, self.depth))
 
     # ------------------------------------------------------------------ reset-record pool
+    def _predraw(self, want):
+        """Top the current stash up to `want` records (host RNG: the random part of WalkingTask.reset)."""
+        want = min(int(want), len(self._stash[0]))
+        if self._stash_n < want:
+            draw_reset_records(self.rs, want - self._stash_n, self.spec, getattr(self.env, "iteration_count", 0),
+                               out=self._stash[self._stash_i][self._stash_n:want])
+            self._stash_n = want
+
     def _refill(self, consumed):
-        """Redraw the `consumed[n]` oldest records of every ring (host RNG), upload, rewind the cursors."""
-        consumed = np.minimum(consumed, self.depth)
+        """Replace the `consumed[n]` oldest records of every ring and rewind the cursors.  The records come from the
+        pinned stash (drawn while the rollout ran: rollout() calls _predraw right after its last launch), go up in ONE
+        asynchronous copy and are scattered into the rings on the device; records drawn but not needed are dropped."""
+        consumed = np.minimum(np.asarray(consumed), self.depth)
         total = int(consumed.sum())
         if total:
-            new = draw_reset_records(self.rs, total, self.spec, getattr(self.env, "iteration_count", 0))
-            rows = np.repeat(np.arange(self.N), consumed)
-            cols = np.arange(total) - np.repeat(np.cumsum(consumed) - consumed, consumed)
-            self.pool_host[rows, cols] = new
-            self.pool.copy_(torch.from_numpy(self.pool_host.view(np.uint8).reshape(-1)))
+            self._predraw(total)
+            isz, dev = REC.itemsize, self.eng.device
+            new = torch.empty(total * isz, dtype=torch.uint8, device=dev)
+            new.copy_(self._stash_t[self._stash_i][:total * isz], non_blocking=True)
+            cons = torch.as_tensor(consumed, dtype=torch.int64).to(dev, non_blocking=True)
+            rows = torch.repeat_interleave(self._env_ids, cons, output_size=total)
+            cols = torch.arange(total, device=dev) - (torch.cumsum(cons, 0) - cons)[rows]
+            self.pool.view(torch.int64).view(self.N, self.depth, isz // 8)[rows, cols] = new.view(torch.int64).view(total, isz // 8)
+            self._last_total = total
+        self._stash_i ^= 1          # the other stash is free: its upload finished a whole rollout ago
+        self._stash_n = 0
         self.pool_count.zero_()
 
     # ------------------------------------------------------------------ buffers for one (T, max_traj_len)
@@ -204,6 +229,7 @@ class A3DeviceRollout:
                 raise OlyError("persistent rollout needs the fused MLP forward (2 x 256 relu actor / critic)")
             mu, v = fw.outputs(N)
             self.launch.persistent(fw.packed_a, fw.norm_a, fw.packed_c, fw.norm_c, mu, v)
+            self._predraw(1.15 * self._last_total + 64)       # host work behind the kernel
             self._finalize(fw, critic)
             return buf
 
@@ -220,6 +246,7 @@ class A3DeviceRollout:
         while t < T:
             one_step()
             t += 1
+        self._predraw(1.15 * self._last_total + 64)           # host work behind the queued launches
         self._finalize(fw, critic)
         return buf
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Config 3 sampling, per vec step: the device-resident rollout (one fused K10 launch per step + the
-policy / critic forward), eager and replayed from HIP graphs.  Prints one JSON object; run under
-`rocprofv3 --kernel-trace --stats` for the kernel durations."""
+"""Config 3 sampling, per vec step: the device-resident rollout as (a) one K11 + one K10 launch per step, eager and
+replayed from HIP graphs, and (b) ONE persistent launch per rollout (K13).  The persistent launch is also timed alone
+with HIP events (kernel time of the T steps, without the reset launch / bootstrap pass / pool refill around it).
+Prints one JSON object; run under `rocprofv3 --kernel-trace --stats` for the kernel durations."""
 import argparse
 import json
 import os
@@ -40,18 +41,44 @@ def main():
         from olympic_hip.vecstep import TorchForward
         kw["forward"] = TorchForward(pi, vf)
     res = {}
-    for label, graph in (("eager", False), ("graph", True)):
+    variants = [("eager", False, False), ("graph", True, False)]
+    if args.forward == "hip":
+        variants.append(("persistent", False, True))
+    for label, graph, persistent in variants:
         for _ in range(2):
-            env.device_rollout(pi, vf, T, T, graph=graph, graph_steps=args.graph_steps, **kw)
+            env.device_rollout(pi, vf, T, T, graph=graph, graph_steps=args.graph_steps, persistent=persistent, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.reps):
-            env.device_rollout(pi, vf, T, T, graph=graph, graph_steps=args.graph_steps, **kw)
+            env.device_rollout(pi, vf, T, T, graph=graph, graph_steps=args.graph_steps, persistent=persistent, **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.reps
         res[label] = {"rollout_s": dt, "us_per_vec_step": 1e6 * dt / T, "env_steps_per_s": N * T / dt,
                       "info": env._dev_rollout.last_info}
+    if args.forward == "hip":
+        res["persistent"]["kernel_us_per_vec_step"] = persistent_kernel_us(env, T) / T
     print(json.dumps({"N": N, "T": T, "forward": args.forward, "graph_steps": args.graph_steps, **res}))
+
+
+def persistent_kernel_us(env, T, reps=5):
+    """HIP-event time of the K13 launch alone: rewind the step counters, launch, repeat."""
+    r = env._dev_rollout
+    fw = r._fw
+    mu, v = fw.outputs(r.N)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tot = 0.0
+    for _ in range(reps):
+        r.traj_len.zero_()
+        r.side_count.zero_()
+        r.side_t.fill_(-1)
+        r.pool_count.zero_()
+        r.ctr[0::2] = 0
+        a.record()
+        r.launch.persistent(fw.packed_a, fw.norm_a, fw.packed_c, fw.norm_c, mu, v)
+        b.record()
+        torch.cuda.synchronize()
+        tot += a.elapsed_time(b) * 1e3
+    return tot / reps
 
 
 if __name__ == "__main__":

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Where a step of the persistent rollout kernel (K13) spends its time: HIP-event time of the launch at
+N = 4096, T = 400 with phases switched off (OLY_K13_SKIP: bit 0 = no MFMA layers, bit 1 = no environment step;
+diagnostic builds of the SAME kernel, outputs are garbage).  One process per variant (the knob is read once)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import json, os, sys
+sys.path.insert(0, os.path.join(%r, "olympics-mujoco_amd")); sys.path.insert(0, os.path.join(%r, "tools"))
+import numpy as np, torch
+from bench_vecstep import persistent_kernel_us
+from olympic_hip import specs
+from olympic_hip.a3 import ReplayA3Physics, VecA3Env
+from olympic_hip.engine import Engine
+from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+from olympic_hip.synthetic import A3_FLOOR_BODY, A3_GEOM_BODYID, A3_LFOOT_BODY, A3_RFOOT_BODY, a3_synthetic_blocks
+N, T = int(sys.argv[1]), int(sys.argv[2])
+blocks = {k: torch.as_tensor(v).cuda() for k, v in a3_synthetic_blocks(N, 32, seed=1).items()}
+env = VecA3Env(specs.A3Spec(mass=41.5), N, Engine(0), ReplayA3Physics(blocks), A3_GEOM_BODYID, A3_FLOOR_BODY,
+               A3_RFOOT_BODY, A3_LFOOT_BODY, rs=np.random.RandomState(0))
+torch.manual_seed(0)
+pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+skip = int(os.environ.get("OLY_K13_SKIP", "0"))
+env._dev_rollout = None
+try:
+    env.device_rollout(pi, vf, T, T, graph=False, persistent=True)
+except Exception as e:
+    print(json.dumps({"skip": skip, "error": repr(e)[:200]})); sys.exit(0)
+print(json.dumps({"skip": skip, "us_per_step": persistent_kernel_us(env, T, reps=8) / T}))
+''' % (ROOT, ROOT)
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    out = {}
+    for skip, label in ((0, "everything"), (1, "no_mfma_layers"), (2, "no_environment_step"), (3, "neither")):
+        env = dict(os.environ, OLY_K13_SKIP=str(skip))
+        r = subprocess.run([sys.executable, "-c", CHILD, str(N), str(T)], env=env, capture_output=True, text=True)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out[label] = json.loads(line[-1]) if line else {"error": r.stderr[-300:]}
+    print(json.dumps({"N": N, "T": T, **out}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
