@@ -16,6 +16,14 @@ environments per GPU (BASELINE.json configs[1]).
     all-gather of (count, sum, sumsq) = 24 B per rank (RCCL over xGMI) -> K7 normalisation that adds
     the rank triples on the device (rl/algos/ppo.py:200-230 merge + :335-336).
 
+The default (config 2) line also carries, measured OUTSIDE the headline's timed region and each wrapped so that
+it can never cost the headline:
+  world 1:  `configs` = BASELINE configs 3, 4 and 5 on one GPU, each with its own roofline and an oracle
+            `cpu_baseline` (config 3: the rollout's kernels K13 / K11 / K10; config 4: the fused VAIL reward K12;
+            config 5: the iteration tail at world 1);
+  world > 1: `config5_tail` = the iteration tail run in these same rank processes, so that a `--gpus 8` run
+            records that the process group saw 8 ranks and what the one collective of the design costs.
+
 With --gpus N > 1 and no WORLD_SIZE in the environment this script starts the N rank processes
 itself (the parent never touches a GPU), relays rank 0's JSON line and fails if any rank fails.
 Prints ONE JSON line on rank 0.
@@ -46,6 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--N", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true", help="skip the single-vec-step block of config 2")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 3 / 4 / 5 block of the default line")
     ap.add_argument("--fall-code", action="store_true", help="also write the fall-code byte")
     ap.add_argument("--robot", default="h1", choices=["h1", "atlas", "talos", "h1_arms", "h1_ff"],
                     help="h1 is the BASELINE config; the others exercise the same kernel on other tables")
@@ -68,19 +77,44 @@ def spawn_ranks(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, errs = [], []
+    import tempfile
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(tempfile.TemporaryFile(mode="w+"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1], text=True))
+    # poll every child: a rank that dies before or at the rendezvous would otherwise leave rank 0 blocked in
+    # init_process_group / a collective and this launcher in communicate() forever
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.05)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    rcs = [p.returncode for p in procs]
     sys.stdout.write(out0 or "")
     sys.stdout.flush()
-    if any(rcs):
-        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    errs[0].seek(0)
+    sys.stderr.write(errs[0].read())          # rank 0's warnings, as before
+    if failed is not None:
+        errs[failed].seek(0)
+        print(f"bench.py: rank {failed} failed first; rank exit codes {rcs}; its stderr tail:\n"
+              + errs[failed].read()[-2000:], file=sys.stderr)
         return 1
     return 0
 
@@ -102,10 +136,12 @@ class Ranks:
         if self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            import datetime
+            tmo = datetime.timedelta(seconds=300)          # a missing peer fails the rank instead of hanging it
             if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
+                dist.init_process_group("nccl", device_id=self.dev, timeout=tmo)
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=tmo)
             self.dist = dist
         if self.world != args.gpus and self.rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={self.world}", file=sys.stderr)
@@ -256,7 +292,6 @@ def per_step_block(rk, eng, spec, N):
     us10 = wall_us(g.replay) / 10
     out["h1_graph_of_10_steps"] = {"us_per_vec_step": us10, "env_steps_per_s": N / (us10 * 1e-6),
                                    "launches_per_step": 1, "note": "ten consecutive vec steps per graph replay"}
-    out["config3_a3_ppo_sampling"] = config3_sampling(N, rk.dev)
     try:
         out["h1_through_the_host_batcher"] = h1_host_batcher(eng, spec, N, qpos_h, qvel_h, act)
     except Exception as e:                                   # never take the headline line down
@@ -287,11 +322,10 @@ def h1_host_batcher(eng, spec, N, qpos_h, qvel_h, act, reps=300):
             "note": "host memory in the loop: PCIe- and sync-bound by construction; physics is a kinematic stand-in"}
 
 
-def config3_sampling(N, dev, T=400, reps=3):
-    """BASELINE.json configs[2], the sampling half: N StickFigureA3 environments x T steps with the
-    synthetic physics readback resident on the device, policy 41->256->256->12 + critic -> 1 (random
-    normc-like init), Gaussian sampling, episode cuts and device-side resets: per vec step ONE K11
-    launch (both MLPs) and ONE K10 launch (everything else), replayed from HIP graphs of 8 steps."""
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def _a3_rollout_env(N, dev):
     import numpy as np
     import torch
     from olympic_hip import specs
@@ -303,24 +337,268 @@ def config3_sampling(N, dev, T=400, reps=3):
     env = VecA3Env(specs.A3Spec(mass=41.5), N, Engine(dev.index or 0), ReplayA3Physics(blocks), A3_GEOM_BODYID,
                    A3_FLOOR_BODY, A3_RFOOT_BODY, A3_LFOOT_BODY, rs=np.random.RandomState(0))
     torch.manual_seed(0)
-    pi, vf = MLPGaussianActor(41, 12).to(dev), MLPCritic(41).to(dev)
+    return env, MLPGaussianActor(41, 12).to(dev), MLPCritic(41).to(dev)
+
+
+def config3_sampling(N, dev, T=400, reps=3):
+    """BASELINE.json configs[2], the sampling half: N StickFigureA3 environments x T steps with the
+    synthetic physics readback resident on the device, policy 41->256->256->12 + critic -> 1 (random
+    normc-like init), Gaussian sampling, episode cuts and device-side resets, three ways:
+      persistent      ONE launch per rollout (K13: a workgroup owns 32 environments through all T steps)
+      graph_replay    per vec step one K11 launch (both MLPs) + one K10 launch, replayed from HIP graphs of 8 steps
+      eager_launches  the same two launches per step, issued op by op
+    Wall clock of whole rollouts (reset launch, bootstrap pass, reset-pool refill included) / T.  Also returns the
+    environment and networks for the kernel-level timings."""
+    import torch
+    env, pi, vf = _a3_rollout_env(N, dev)
     res = {}
-    for label, graph in (("eager_launches", False), ("graph_replay", True)):
+    for label, graph, persistent in (("eager_launches", False, False), ("graph_replay", True, False),
+                                     ("persistent", False, True)):
         for _ in range(2):
-            env.device_rollout(pi, vf, T, T, graph=graph)
+            env.device_rollout(pi, vf, T, T, graph=graph, persistent=persistent)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(reps):
-            env.device_rollout(pi, vf, T, T, graph=graph)
+            env.device_rollout(pi, vf, T, T, graph=graph, persistent=persistent)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / reps
         res[label] = {"us_per_vec_step": 1e6 * dt / T, "env_steps_per_s": N * T / dt}
+    res["eager_launches"]["launches_per_step"] = res["graph_replay"]["launches_per_step"] = 2
+    res["persistent"]["launches_per_rollout"] = 1
     info = env._dev_rollout.last_info
-    res.update({"N": N, "T": T, "launches_per_step": 2, "kernels": "mlp_forward_kernel (K11) + a3_vec_kernel (K10)",
-                "timing": "wall clock of whole rollouts (reset-pool refill and bootstrap pass included) / T",
+    res.update({"N": N, "T": T, "kernels": "a3_rollout_kernel (K13) | mlp_forward_kernel (K11) + a3_vec_kernel (K10)",
+                "timing": "wall clock of whole rollouts (reset launch, bootstrap pass, reset-pool refill included) / T",
                 "resets_per_rollout": info.get("resets"), "bootstrap_rows": info.get("side_rows"),
-                "round1_host_loop_us_per_vec_step": 360.0})
-    return res
+                "round1_host_loop_us_per_vec_step": 360.0, "round2_graph_replay_us_per_vec_step": 33.9})
+    return res, (env, pi, vf)
+
+
+def _mlp_flop_per_row(n_in, n_act):
+    """Algorithmic multiply-adds x 2 of the actor (n_in -> 256 -> 256 -> n_act) + critic (-> 1) forward."""
+    return 2 * ((n_in * 256 + 256 * 256 + 256 * n_act) + (n_in * 256 + 256 * 256 + 256 * 1))
+
+
+def _k10_bytes_per_env_step(spec, C):
+    """Algorithmic HBM bytes of one K10 vec step per environment, each array once: the readback row (root / head /
+    foot poses and velocities, base quaternion and angular velocity, actuator rows, ncon + C contact slots), mu /
+    noise / the stored observation and value in; observation (buffer + next), action, PD target, float64 reward,
+    value, flag, task state (ints + goal steps) out.  The 640-B step sequence is read every step (counted) and
+    rewritten only on resets (not counted)."""
+    nu, nobs = spec.nu, spec.n_obs
+    rd = 8 * (4 + 3 * 6 + 4 + 3 + 2 * nu) + 4 + C * (4 + 4 + 48 + 8) + 4 * (2 * nu + nobs + 1) + 8 * 80 + 4 * 7
+    wr = 4 * (2 * nobs + nu + 1) + 8 * nu + 8 + 1 + 4 * 5 + 1 + 8 * 8
+    return rd + wr
+
+
+def cpu_baseline_config3(seconds=8.0):
+    """The oracle's restatement of one sampling step (oly_mlp_forward_cpu for actor and critic, then
+    oly_a3_vec_step_cpu) on a bounded sample: 256 environments, repeated for ~`seconds`, one thread."""
+    import numpy as np
+    from oracle import oracle as orc
+    from olympic_hip import _abi, specs
+    from olympic_hip.a3 import clock_lut
+    from olympic_hip.synthetic import A3_FLOOR_BODY, A3_GEOM_BODYID, A3_LFOOT_BODY, A3_RFOOT_BODY, a3_synthetic_blocks
+    from olympic_hip.vecstep import draw_reset_records
+    spec = specs.A3Spec(mass=41.5)
+    lut = clock_lut(spec.swing_duration, spec.stance_duration, 0.1, "grounded", 1 / spec.control_dt, spec.period)
+    contact = (A3_GEOM_BODYID, A3_FLOOR_BODY, A3_RFOOT_BODY, A3_LFOOT_BODY)
+    N, K, T, nobs, nu, depth = 256, 8, 1 << 20, spec.n_obs, spec.nu, 4
+    rng = np.random.default_rng(0)
+    blocks = a3_synthetic_blocks(N, K, seed=1)
+    z = lambda dt, *sh: np.zeros((N,) + sh, dt)
+    state = dict(phase=z(np.int32), t1=z(np.int32), t2=z(np.int32), reached_frames=z(np.int32), target_reached=z(np.uint8),
+                 mode=np.full(N, _abi.MODE_STANDING, np.int32), seq_len=np.ones(N, np.int32),
+                 sequence=z(np.float64, _abi.OLY_MAX_SEQ, 4), goal=z(np.float64, 8))
+    Tb = 64                     # buffer rows; the step counter is rewound before it reaches them
+    ro = dict(T=T, max_traj_len=400, deterministic=False, side_slots=4, pool_depth=depth, mu=z(np.float32, nu),
+              value=z(np.float32), scale=np.full(nu, 0.2, np.float32), eps=rng.normal(0, 1, (Tb, N, nu)).astype(np.float32),
+              state=z(np.float32, nobs), pd_target=z(np.float64, nu), buf_states=np.zeros((Tb, N, nobs), np.float32),
+              buf_actions=np.zeros((Tb, N, nu), np.float32), buf_rewards=np.zeros((Tb, N)),
+              buf_values=np.zeros((Tb, N), np.float32), buf_flags=np.zeros((Tb, N), np.uint8), buf_rew6=None,
+              traj_len=z(np.int32), side_obs=np.zeros((N * 4, nobs), np.float32), side_t=np.full(N * 4, -1, np.int32),
+              side_count=z(np.int32), pool=draw_reset_records(np.random.RandomState(0), N * depth, spec, 5000)
+              .view(np.uint8).reshape(-1).copy(), pool_count=z(np.int32), ctr=np.zeros(2, np.int32))
+    wa = [rng.normal(0, 0.1, sh).astype(np.float32) for sh in ((256, nobs), (256,), (256, 256), (256,), (nu, 256), (nu,))]
+    wc = [rng.normal(0, 0.1, sh).astype(np.float32) for sh in ((256, nobs), (256,), (256, 256), (256,), (1, 256), (1,))]
+    orc.a3_vec_step(spec, lut, contact, blocks, state, ro, _abi.VSTEP_RESET_ALL)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds:
+        ro["mu"][:] = orc.mlp_forward(ro["state"], *wa)
+        ro["value"][:] = orc.mlp_forward(ro["state"], *wc)[:, 0]
+        orc.a3_vec_step(spec, lut, contact, blocks, state, ro, 0)
+        steps += 1
+        if ro["ctr"][0] >= Tb:
+            ro["ctr"][0] = 0
+            ro["side_count"][:] = 0
+    dt = time.perf_counter() - t0
+    return {"value": steps * N / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle actor + critic forward (oly_mlp_forward_cpu) + oly_a3_vec_step_cpu on {N} environments, "
+                      f"{steps} vec steps in {dt:.1f} s, 1 thread"}
+
+
+def config3_block(rk, args):
+    """BASELINE config 3 on one GPU: the sampling loop's wall clock per vec step, and its kernels against their
+    rooflines, HIP-event timed on the launch stream: K13 (the whole rollout in one launch; f32 MFMA), K11 (actor +
+    critic forward; f32 MFMA) and K10 (the vec step; HBM bytes), the last two as the two-launch path runs them."""
+    import torch
+    from olympic_hip import specs
+    N, dev = args.N, rk.dev
+    res, (env, pi, vf) = config3_sampling(N, dev)
+    r = env._dev_rollout
+    fw, T, spec = r._fw, r.buf.T, specs.A3Spec(mass=41.5)
+    stream = env.eng.ctx.stream
+    mu, v = fw.outputs(N)
+    flop = _mlp_flop_per_row(spec.n_obs, spec.nu) * N
+
+    def rewind():
+        r.traj_len.zero_()
+        r.side_count.zero_()
+        r.side_t.fill_(-1)
+        r.pool_count.zero_()
+        r.ctr[0::2] = 0
+    k13 = []
+    for _ in range(4):
+        rewind()
+        k13.append(_one_event_ms(stream, lambda: r.launch.persistent(fw.packed_a, fw.norm_a, fw.packed_c, fw.norm_c, mu, v)))
+    k13_us = 1e3 * min(k13) / T
+    rewind()
+    k11_us = 1e3 * event_ms(stream, 100, lambda: fw(r.state_obs))
+    rewind()
+    k10_us = 1e3 * event_ms(stream, 100, lambda: r.launch(0, mu, v))        # 103 steps < T rows: stays inside the buffer
+    rewind()
+    b10 = _k10_bytes_per_env_step(spec, int(r.blocks["geom1"].shape[2])) * N
+    out = {"workload": f"A3 walk PPO sampling, {N} envs x {T} steps, synthetic readback resident on the device "
+                       "(BASELINE configs[2]); update phase = PyTorch-ROCm, not timed here",
+           "sampling": res, "value": res["persistent"]["env_steps_per_s"], "unit": "env-steps/s",
+           "kernels": {
+               "a3_rollout_kernel(K13)": {
+                   "us_per_vec_step": k13_us, "launches_per_rollout": 1,
+                   "roofline": {"bound": "mfma", "achieved": flop / (k13_us * 1e-6) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": flop / (k13_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                "alg_flop_per_env_step": flop // N,
+                                "note": "a step = forward (matrix cores) THEN the latency-bound environment step on the "
+                                        "same workgroup; phase times in profiles/r03"}},
+               "mlp_forward_kernel(K11)": {
+                   "us_per_launch": k11_us,
+                   "roofline": {"bound": "mfma", "achieved": flop / (k11_us * 1e-6) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": flop / (k11_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                "alg_flop_per_env_step": flop // N}},
+               "a3_vec_kernel(K10)": {
+                   "us_per_launch": k10_us,
+                   "roofline": {"bound": "hbm", "achieved": b10 / (k10_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": b10 / (k10_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                "alg_bytes_per_env_step": b10 // N,
+                                "note": "10 MB per launch = 1.2 us of HBM time: launch- and dependent-latency-bound"}}},
+           "timing": "HIP events on the launch stream, back-to-back launches (K11 / K10: 100 each; K13: best of 4 whole "
+                     "rollouts / T)"}
+    env._dev_rollout.close()
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_config3()
+    return out
+
+
+def _one_event_ms(stream, fn):
+    from olympic_hip._ffi import HipTimer
+    t = HipTimer()
+    t.start(stream())
+    fn()
+    t.stop(stream())
+    return t.elapsed_ms()
+
+
+# ------------------------------------------------------------------------------------ config 4
+def disc_flop_per_sample(D=32):
+    """Algorithmic multiply-adds x 2 of the variational discriminator D -> 256 -> 128 -> (128, 128) -> 1."""
+    return 2 * (D * 256 + 256 * 128 + 2 * 128 * 128 + 128)
+
+
+def cpu_baseline_config4(weights, seconds=8.0):
+    import numpy as np
+    from oracle import oracle as orc
+    rng = np.random.default_rng(4)
+    B = 1024
+    x = rng.normal(0, 1, (B, 32)).astype(np.float32)
+    eps = rng.normal(0, 1, (B, 128)).astype(np.float32)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        cs = orc.col_stats(x)
+        orc.disc_forward(x, weights, colstats=cs, eps=eps)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": reps * B / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"oracle column statistics + oly_disc_forward_cpu on {B} samples, {reps} passes in {dt:.1f} s, 1 thread"}
+
+
+def config4_block(rk, args):
+    """BASELINE config 4: the VAIL discriminator reward (imitation_lib/imitation/gail_TRPO.py:320-327 ->
+    VariationalNet.forward, utils/networks.py:258-284) for B = 4096 samples and for a [400,4096] block:
+    oly_col_stats (the Standardizer's running update) + oly_disc_forward (K12, one launch on the f32 matrix cores)."""
+    import numpy as np
+    import torch
+    from olympic_hip.engine import Engine
+    from olympic_hip.gail import DiscriminatorReward, VariationalDiscriminator
+    dev = rk.dev
+    eng = Engine(dev.index or 0)
+    torch.manual_seed(0)
+    net = VariationalDiscriminator().to(dev)
+    stream = eng.ctx.stream
+    out = {"workload": "UnitreeH1 VAIL reward, variational discriminator 32 -> 256 -> 128 -> (128, 128) -> 1, "
+                       "eps supplied (BASELINE configs[3])", "unit": "samples/s", "shapes": {}}
+    for label, B, reps in (("B4096", args.N, 200), ("T400xN4096", 400 * args.N, 10)):
+        g = torch.Generator(device=dev).manual_seed(7)
+        x = torch.randn((B, 32), device=dev, generator=g)
+        eps = torch.randn((B, 128), device=dev, generator=g)
+        dr = DiscriminatorReward(eng, net, state_mask=np.arange(32))
+        packed = dr.packed()
+        cs = eng.col_stats(x)
+        bufs = dict(reward=torch.empty(B, device=dev))
+        ms_k12 = event_ms(stream, reps, lambda: eng.disc_forward(x, packed, colstats=cs, eps=eps, out=bufs))
+        ms_all = event_ms(stream, reps, lambda: dr.forward(x, eps, out=bufs))
+        fl = disc_flop_per_sample() * B
+        out["shapes"][label] = {
+            "samples": B, "disc_forward_us": 1e3 * ms_k12, "col_stats_plus_disc_forward_us": 1e3 * ms_all,
+            "samples_per_s": B / (ms_all * 1e-3),
+            "roofline": {"bound": "mfma", "achieved": fl / (ms_k12 * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": fl / (ms_k12 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "disc_forward_kernel<4>", "alg_flop_per_sample": disc_flop_per_sample(),
+                         "hbm_bytes_per_sample": 4 * (32 + 128 + 1)}}
+        del x, eps, bufs
+    out["value"] = out["shapes"]["T400xN4096"]["samples_per_s"]
+    out["round1_layer_by_layer_us_at_B4096"] = 249.0
+    if not args.no_cpu_baseline:
+        n = net
+        w = {k: t.detach().cpu().numpy() for k, t in dict(
+            enc_w0=n.encoder[0].weight, enc_b0=n.encoder[0].bias, enc_w1=n.encoder[1].weight, enc_b1=n.encoder[1].bias,
+            mu_w=n.mu_out.weight, mu_b=n.mu_out.bias, lv_w=n.logvar_out.weight, lv_b=n.logvar_out.bias,
+            dec_w=n.decoder.weight, dec_b=n.decoder.bias).items()}
+        out["cpu_baseline"] = cpu_baseline_config4(w)
+    return out
+
+
+def config5_world1_block(rk, args):
+    """BASELINE config 5's iteration tail on ONE GPU (its 8-GPU form is `bench.py --config 5 --gpus 8`; under a
+    multi-rank default run the same tail is measured as `config5_tail`)."""
+    from olympic_hip.engine import Engine
+    m = measure_config5_tail(rk, Engine(rk.local_rank), 400, args.N, 100, 10)
+    out = {"workload": "PPO iteration tail on one [400,4096] shard: K6 scan (statistics fused, f64 rewards) -> "
+                       "(world 1: the all-gather is a view) -> K7 normalise", "value": m["value"], "unit": m["unit"],
+           "ms_per_step": m["ms_per_step"], "stages_ms": m["stages_ms"], "roofline": m["roofline"]}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_config5(400, args.N, seconds=6.0)
+    return out
+
+
+def configs_block(rk, args):
+    out = {}
+    for name, fn in (("config3_a3_ppo_sampling", config3_block), ("config4_vail_reward", config4_block),
+                     ("config5_tail_world1", config5_world1_block)):
+        try:                       # a secondary block must never cost the headline line
+            out[name] = fn(rk, args)
+        except Exception as e:     # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def bench_config2(args, rk):
@@ -356,6 +634,15 @@ def bench_config2(args, rk):
     wall, kern_ms = timed_region(rk, eng.ctx.stream, args.warmup, args.steps, step)
     rows = T * N
     fallen = float(out["absorbing"].float().mean().item())
+    # N > 1: the design's ONE exchange step (rl/algos/ppo.py:200-230,335-336) measured in these same rank processes,
+    # so that a driver --gpus N run of the default command records that the process group saw N ranks and what the
+    # all-gather costs (config 2 itself has no data-path collective).  Every rank takes part.
+    tail = None
+    if world > 1 and not args.no_configs:
+        try:
+            tail = measure_config5_tail(rk, eng, 400, N, 50, 5)
+        except Exception as e:     # noqa: BLE001  (never costs the headline line)
+            tail = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank != 0:
         return None
     copy_gbps = copy_bandwidth(rk, eng.ctx.stream)
@@ -389,15 +676,29 @@ def bench_config2(args, rk):
                    "parallelism": f"env-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": ("profiles/traffic_k1.json (rocprofv3 PMC passes of round 2, FETCH_SIZE x 2 + "
+                                        "WRITE_SIZE; read from the file, not measured in this run)" if traffic else None),
                      "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
+                     "measured_copy_note": "torch's device-to-device copy_ of 404 MB timed the same way; it is slower than "
+                                           "the guide's float4 copy (6.29 TB/s), so a ratio above 1 only says that",
                      "kernel": "il_tile_kernel<128,%s>" % args.robot, "kernel_ms": kern_ms,
                      "alg_bytes_per_env_step": bpr, "env_steps_per_launch": rows},
     }
+    if tail is not None:
+        tail.pop("wall_s", None)
+        tail["workload"] = ("config-5 iteration tail per rank on its own [400,N] shard: K6 scan (statistics fused) -> ONE "
+                            "all-gather of 24 B per rank -> K7 normalise; measured after the headline's timed region")
+        line["config5_tail"] = tail
     if world == 1 and not args.no_per_step and args.robot == "h1":
         try:                       # a secondary block must never cost the headline line
             line["per_step"] = per_step_block(rk, eng, spec, N)
         except Exception as e:     # noqa: BLE001
             line["per_step"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_configs and args.robot == "h1":
+        line["configs"] = configs_block(rk, args)
+        c3 = line["configs"].get("config3_a3_ppo_sampling", {})
+        if "per_step" in line and "sampling" in c3:
+            line["per_step"]["config3_a3_ppo_sampling"] = c3["sampling"]
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_config2(spec)
     return line
@@ -423,15 +724,13 @@ def cpu_baseline_config5(T, N, seconds=10.0):
                       f"1 thread, repeated for ~{seconds:.0f} s"}
 
 
-def bench_config5(args, rk):
+def measure_config5_tail(rk, eng, T, N, steps, warmup):
     """K6 (+ fused statistics) -> all-gather of 3 doubles per rank -> K7 normalise, per rank on its own
-    [T,N] shard of the N*world environments (rl/algos/ppo.py:200-230,335-336)."""
+    [T,N] shard of the N*world environments (rl/algos/ppo.py:200-230,335-336).  Returns a dict with the timed
+    region's wall time, the per-stage times and the roofline of scan + normalise; every rank must call it."""
     import torch
     from olympic_hip import _abi, dist as odist
-    from olympic_hip.engine import Engine
     dev, rank, world = rk.dev, rk.rank, rk.world
-    eng = Engine(rk.local_rank)
-    T, N = args.T, args.N
     g = torch.Generator(device=dev).manual_seed(500 + rank)
     rew = torch.empty((T, N), dtype=torch.float64, device=dev).uniform_(-0.3, 1.0, generator=g)
     val = torch.empty((T, N), dtype=torch.float32, device=dev).normal_(0, 1, generator=g)
@@ -453,9 +752,9 @@ def bench_config5(args, rk):
         scan()
         eng.adv_normalize(adv, gather(), 1, 1e-5)
 
-    wall, ms_step = timed_region(rk, eng.ctx.stream, args.warmup, args.steps, step)
+    wall, ms_step = timed_region(rk, eng.ctx.stream, warmup, steps, step)
     # stage breakdown, outside the timed region: each stage alone, back to back, HIP events
-    reps = max(20, min(args.steps, 200))
+    reps = max(20, min(steps, 200))
     ms_scan = event_ms(eng.ctx.stream, reps, scan)
     parts = gather()
     ms_norm = event_ms(eng.ctx.stream, reps, lambda: eng.adv_normalize(adv, parts, 1, 1e-5))
@@ -469,29 +768,13 @@ def bench_config5(args, rk):
     # the all-gathered triples are identical on every rank, their tree sum is the global statistic
     tot = odist.tree_sum(parts)
     assert float(tot[0]) == float(T * N * world), (float(tot[0]), T * N * world)
-    if rank != 0:
-        return None
     elems = T * N
     b_scan, b_norm = 21, 8         # f64 reward 8 + value 4 + next value 4 + flag 1 in, ret 4 + adv 4 out | adv in + out
-    line = {
-        "metric": "env-steps/sec through the PPO iteration tail (return scan + advantage statistics + "
-                  "all-gather + normalisation), 4096 envs x 400 steps per GPU",
-        "value": world * elems * args.steps / wall,
-        "unit": "env-steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * wall / max(args.steps, 1),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": "config-5: K6 scan (statistics fused) -> all-gather 24 B/rank -> K7 normalise, "
-                               "one [T,N] shard per rank",
-                   "T": T, "envs_per_gpu": N, "envs_total": N * world, "backend": rk.backend if world > 1 else None,
-                   "rewards": "f64 (un-narrowed, as env.step returns them)",
-                   "parallelism": f"env-sharded x{world}, one all-gather of 3 doubles per rank per step"},
+    ranks_seen = rk.dist.get_world_size() if rk.dist is not None else 1
+    return {
+        "wall_s": wall, "steps": steps, "value": world * elems * steps / wall, "unit": "env-steps/s",
+        "ms_per_step": 1e3 * wall / max(steps, 1), "ranks_seen": ranks_seen, "gathered_rows": int(parts.shape[0]),
+        "backend": rk.backend if rk.dist is not None else None, "T": T, "envs_per_gpu": N,
         "stages_ms": {"scan_with_fused_stats": ms_scan, "all_gather_host_wall": ms_gather, "normalise": ms_norm,
                       "whole_step_hip_events": ms_step},
         "roofline": {"bound": "hbm", "achieved": (b_scan + b_norm) * elems / ((ms_scan + ms_norm) * 1e-3) / 1e9,
@@ -503,7 +786,42 @@ def bench_config5(args, rk):
                                                        "separate statistics pass, 4 B, which the fused scan no longer makes)"},
                      "scan_GBps": b_scan * elems / (ms_scan * 1e-3) / 1e9,
                      "normalise_GBps": b_norm * elems / (ms_norm * 1e-3) / 1e9,
-                     "elements_per_launch": elems},
+                     "elements_per_launch": elems,
+                     "note": "the [400,4096] tail is bound by the 400-step dependent fp64 chain and launch latency, "
+                             "not by its 48 MB (DESIGN 4, K6)"},
+    }
+
+
+def bench_config5(args, rk):
+    from olympic_hip.engine import Engine
+    world = rk.world
+    eng = Engine(rk.local_rank)
+    T, N = args.T, args.N
+    m = measure_config5_tail(rk, eng, T, N, args.steps, args.warmup)
+    if rk.rank != 0:
+        return None
+    line = {
+        "metric": "env-steps/sec through the PPO iteration tail (return scan + advantage statistics + "
+                  "all-gather + normalisation), 4096 envs x 400 steps per GPU",
+        "value": m["value"],
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "config-5: K6 scan (statistics fused) -> all-gather 24 B/rank -> K7 normalise, "
+                               "one [T,N] shard per rank",
+                   "T": T, "envs_per_gpu": N, "envs_total": N * world, "backend": m["backend"],
+                   "ranks_seen": m["ranks_seen"],
+                   "rewards": "f64 (un-narrowed, as env.step returns them)",
+                   "parallelism": f"env-sharded x{world}, one all-gather of 3 doubles per rank per step"},
+        "stages_ms": m["stages_ms"],
+        "roofline": m["roofline"],
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_config5(T, N)
@@ -514,6 +832,8 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    if os.environ.get("OLY_BENCH_TEST_DIE_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(3)            # test hook (tests/test_gpu_multirank.py): a rank that dies before the rendezvous
     rk = Ranks(args)
     line = (bench_config5 if args.config == 5 else bench_config2)(args, rk)
     if rk.rank == 0 and line is not None:

@@ -62,6 +62,53 @@ def test_bench_starts_its_own_ranks(config):
     assert line["value"] > 0 and line["roofline"]["bound"] == "hbm"
     if config == 5:
         assert set(line["stages_ms"]) >= {"scan_with_fused_stats", "all_gather_host_wall", "normalise"}
+        assert line["config"]["ranks_seen"] == 2
+    else:
+        # the default (config 2) line of a multi-rank run also measures the design's ONE exchange step in the same
+        # processes: the process group saw both ranks, the all-gather returned one triple per rank
+        tail = line["config5_tail"]
+        assert "error" not in tail, tail
+        assert tail["ranks_seen"] == 2 and tail["gathered_rows"] == 2 and tail["backend"] == "gloo"
+        assert set(tail["stages_ms"]) >= {"scan_with_fused_stats", "all_gather_host_wall", "normalise"}
+        assert tail["value"] > 0 and 0 < tail["roofline"]["frac"] < 1
+        assert "configs" not in line and "per_step" not in line
+
+
+def test_bench_launcher_ends_when_a_rank_dies_before_the_rendezvous():
+    """Rank 1 exits before init_process_group; rank 0 is then blocked in the rendezvous.  The launcher polls all its
+    children, ends the survivors and fails, instead of waiting on rank 0 forever."""
+    import time
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+               OLY_BENCH_TEST_DIE_RANK="1")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--share-device", "--steps", "2", "--warmup", "1", "--T", "50", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode != 0 and "rank 1 failed first" in out.stderr, out.stderr[-2000:]
+    assert time.time() - t0 < 120
+
+
+def test_bench_default_line_carries_every_baseline_config():
+    """One GPU, the driver's command shape: the config-2 headline plus `configs` = BASELINE configs 3 / 4 / 5, each
+    with its own roofline (and, without --no-cpu-baseline, an oracle cpu_baseline), none of them an error."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["roofline"]["traffic_source"].startswith("profiles/traffic_k1.json")
+    c = line["configs"]
+    assert set(c) == {"config3_a3_ppo_sampling", "config4_vail_reward", "config5_tail_world1"}
+    assert not any("error" in v for v in c.values()), c
+    c3 = c["config3_a3_ppo_sampling"]
+    assert c3["sampling"]["persistent"]["us_per_vec_step"] < c3["sampling"]["graph_replay"]["us_per_vec_step"]
+    for k, bound in (("a3_rollout_kernel(K13)", "mfma"), ("mlp_forward_kernel(K11)", "mfma"), ("a3_vec_kernel(K10)", "hbm")):
+        r = c3["kernels"][k]["roofline"]
+        assert r["bound"] == bound and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c4 = c["config4_vail_reward"]
+    assert c4["shapes"]["T400xN4096"]["roofline"]["frac"] > 0.3 and c4["shapes"]["B4096"]["disc_forward_us"] < 40
+    assert set(c["config5_tail_world1"]["stages_ms"]) >= {"scan_with_fused_stats", "normalise"}
+    assert line["per_step"]["config3_a3_ppo_sampling"] == c3["sampling"]
 
 
 def test_bench_fails_loudly_when_a_rank_fails():
@@ -95,7 +142,7 @@ def test_bench_under_torchrun_uses_rccl(config):
     """The driver's launch line with one rank: bench.py forms an "nccl" group (barrier with device_ids,
     MAX over ranks, config 5's all-gather) and prints the contract's JSON line."""
     out = _torchrun_one_rank([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", str(config), "--steps", "5",
-                              "--warmup", "2", "--T", "100", "--no-cpu-baseline", "--no-per-step"])
+                              "--warmup", "2", "--T", "100", "--no-cpu-baseline", "--no-per-step", "--no-configs"])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"].startswith("env-sharded x1")
