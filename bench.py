@@ -175,6 +175,7 @@ def timed_region(rk, stream, warmup, steps, step):
     billed to the K steps.  Returns (wall seconds, HIP-event ms per step on the kernels' stream)."""
     from olympic_hip._ffi import HipTimer
     torch = rk.torch
+    prewarm(rk, step)
     for i in range(warmup):
         step(i)
     timer = HipTimer()
@@ -190,11 +191,40 @@ def timed_region(rk, stream, warmup, steps, step):
     return rk.max_over_ranks(wall), timer.elapsed_ms() / max(steps, 1)
 
 
-def event_ms(stream, reps, fn):
-    """Average HIP-event time of `fn()` over `reps` back-to-back calls on `stream()`."""
+PREWARM = {}
+
+
+def prewarm(rk, step, seconds=0.25):
+    """Not a benchmark step: wakes the device.  On this pool an idle MI355X sits at sclk ~600 MHz (`rocm-smi
+    --showclocks`) and takes tens of milliseconds of work to reach its running clocks: with the contract's W = 5
+    warm-up launches (0.7 ms of work) the K timed launches measured 2.1 ms each instead of 0.13 ms, with W = 50
+    0.132 ms (profiles/r03/clock_ramp.json).  So the same launch is repeated for `seconds` of wall time BEFORE the W
+    warm-up steps and the K timed steps; nothing here is timed or counted, and the line reports it."""
+    import torch
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            step(n)
+            n += 1
+        torch.cuda.synchronize(rk.dev)
+    PREWARM.update({"launches": n, "seconds": time.perf_counter() - t0,
+                    "why": "device clocks ramp from idle over tens of ms on this pool; untimed, before the W warm-up steps"})
+
+
+def event_ms(stream, reps, fn, wake_s=0.08):
+    """Average HIP-event time of `fn()` over `reps` back-to-back calls on `stream()`, after `wake_s` seconds of the
+    same call untimed (the sections of this script alternate with CPU-only baselines during which the device idles
+    and drops its clocks, see prewarm)."""
+    import torch
     from olympic_hip._ffi import HipTimer
-    for _ in range(3):
-        fn()
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 >= wake_s:
+            break
     t = HipTimer()
     t.start(stream())
     for _ in range(reps):
@@ -465,7 +495,7 @@ def config3_block(rk, args):
     rewind()
     k11_us = 1e3 * event_ms(stream, 100, lambda: fw(r.state_obs))
     rewind()
-    k10_us = 1e3 * event_ms(stream, 100, lambda: r.launch(0, mu, v))        # 103 steps < T rows: stays inside the buffer
+    k10_us = 1e3 * event_ms(stream, 100, lambda: r.launch(0, mu, v), wake_s=0.0)   # 104 steps < T rows (K11 just woke the device)
     rewind()
     b10 = _k10_bytes_per_env_step(spec, int(r.blocks["geom1"].shape[2])) * N
     out = {"workload": f"A3 walk PPO sampling, {N} envs x {T} steps, synthetic readback resident on the device "
@@ -668,6 +698,7 @@ def bench_config2(args, rk):
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        "prewarm": dict(PREWARM),
         "config": {"workload": ("UnitreeH1.walk config-2" if args.robot == "h1" else args.robot + ".walk") +
                                ": fused K1+K5 over one [T,N] block per step",
                    "T": T, "envs_per_gpu": N, "env_steps_per_step": rows * world,
@@ -814,6 +845,7 @@ def bench_config5(args, rk):
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        "prewarm": dict(PREWARM),
         "config": {"workload": "config-5: K6 scan (statistics fused) -> all-gather 24 B/rank -> K7 normalise, "
                                "one [T,N] shard per rank",
                    "T": T, "envs_per_gpu": N, "envs_total": N * world, "backend": m["backend"],

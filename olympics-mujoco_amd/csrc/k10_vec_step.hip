@@ -80,6 +80,13 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   const int k = p.ro.ctr[2 * blockIdx.x + 1];
   const int kk = (int)((unsigned)k % (unsigned)p.b.K);
   const int T = p.ro.T;
+  // t lives on the device, so the host cannot check it: a replay past the rollout's T rows (or a caller that forgot
+  // to rewind the counters) must not write beyond the buffers.  Touch nothing, advance nothing, leave a sticky mark
+  // in the word behind the per-workgroup counters (vecstep._finalize turns it into an error).
+  if (!reset_all && (unsigned)t >= (unsigned)T) {
+    if (tid == 0) p.ro.ctr[2 * gridDim.x] = 1;
+    return;
+  }
   const size_t tN = (size_t)t * N;
   const size_t kN = (size_t)kk * N;
   double* se = s_env[el];
@@ -600,7 +607,8 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
 }
 }  // namespace
 
-extern "C" int oly_a3_vec_ctr_len(int N) { return N <= 0 ? 0 : 2 * ((N + EPW - 1) / EPW); }
+// (t, k) per 16-environment workgroup, then the sticky overrun word (+ one pad word)
+extern "C" int oly_a3_vec_ctr_len(int N) { return N <= 0 ? 0 : 2 * ((N + EPW - 1) / EPW) + 2; }
 
 extern "C" int oly_a3_vec_step(oly_ctx* ctx, int N, const oly_a3_blocks* blocks, const oly_a3_state* st,
                                const oly_a3_rollout* ro, int flags, oly_stream stream) {

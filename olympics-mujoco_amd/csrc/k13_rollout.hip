@@ -123,6 +123,10 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
   // K10 keeps one private (t, k) pair per 16-environment workgroup; this workgroup covers two of them
   const int t0 = p.ro.ctr[4 * blockIdx.x];
   const int k0 = p.ro.ctr[4 * blockIdx.x + 1];
+  if (t0 < 0 || t0 > T) {     // counters the caller never rewound: K10's rule (no write, sticky mark behind the counters)
+    if (threadIdx.x == 0) p.ro.ctr[2 * ((N + 15) / 16)] = 1;
+    return;
+  }
   const int C = p.b.C;
   const int passes = (C + SLOTS - 1) / SLOTS;
   double* se = s_env + el * L_ENV;

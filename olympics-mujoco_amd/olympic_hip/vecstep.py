@@ -309,8 +309,12 @@ class A3DeviceRollout:
         # one host round trip per rollout: pool cursors (to refill the consumed records), the readback
         # cursor, and the side-list high-water mark
         host = torch.cat([self.pool_count, self.side_count.max().reshape(1), self.ctr[1:2],
-                          valid.sum().to(torch.int32).reshape(1)]).cpu().numpy()
+                          valid.sum().to(torch.int32).reshape(1), self.ctr[-2:-1]]).cpu().numpy()
         consumed, hw, k, side_rows = host[:N], int(host[N]), int(host[N + 1]), int(host[N + 2])
+        if int(host[N + 3]):
+            self.ctr[-2:] = 0
+            raise OlyError("a vec step was launched with its device step counter outside [0, T): nothing was written "
+                           "by that launch; rewind ctr[0::2] before a rollout")
         if hw > self.slots:
             raise OlyError(f"bootstrap side list overflow: {hw} cuts in one environment, {self.slots} slots")
         self.last_info = dict(resets=int(consumed.sum()), reused_records=int(np.maximum(consumed - self.depth, 0).sum()),

@@ -512,6 +512,7 @@ int oly_a3_vec_step_cpu(const oly_a3_model* m, int ngeom, const int32_t* geom_bo
   const int nu = m->nu, n_obs = 7 + 2 * nu + 10, C = b->C;
   const int reset_all = (flags & OLY_VSTEP_RESET_ALL) != 0;
   const int t = ro->ctr[0], k = ro->ctr[1];
+  if (!reset_all && (t < 0 || t >= ro->T)) return OLY_ERANGE;   /* the device kernel: no write, sticky mark */
   const int kk = (int)((unsigned)k % (unsigned)b->K);
   const size_t tN = (size_t)t * N, kN = (size_t)kk * N;
   for (int n = 0; n < N; ++n) {

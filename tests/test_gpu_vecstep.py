@@ -59,7 +59,7 @@ def _to_device(eng, blocks, state, ro):
     d_state = {k: dev(v) for k, v in state.items()}
     d_ro = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in ro.items()}
     ctr = torch.zeros(eng.a3_vec_ctr_len(N), dtype=torch.int32, device="cuda")
-    ctr[0::2], ctr[1::2] = int(ro["ctr"][0]), int(ro["ctr"][1])
+    ctr[0:-2:2], ctr[1:-2:2] = int(ro["ctr"][0]), int(ro["ctr"][1])      # the last pair is (overrun mark, pad)
     d_ro["ctr"] = ctr
     return d_blocks, d_state, d_ro
 
@@ -93,7 +93,7 @@ def test_vec_step_vs_oracle(eng, golden, oracle, N, T, max_len, det):
             a, b = h(d_ro[k]), ro[k]
             assert np.abs(a - b).max() <= np.spacing(np.float32(1.0)) * max(1.0, np.abs(b).max()), (step, k)
         c = h(d_ro["ctr"]).reshape(-1, 2)
-        assert (c[:, 0] == ro["ctr"][0]).all() and (c[:, 1] == ro["ctr"][1]).all()
+        assert (c[:-1, 0] == ro["ctr"][0]).all() and (c[:-1, 1] == ro["ctr"][1]).all() and c[-1, 0] == 0
 
     launch(_abi.VSTEP_RESET_ALL)
     oracle.a3_vec_step(spec, lut, CONTACT, blocks, state, ro, _abi.VSTEP_RESET_ALL)
@@ -295,6 +295,54 @@ def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K):
         assert ia == ib and ka == kb
     last = (out[1][0][0]["flags"] & _abi.FLAG_LAST).bool()
     assert bool(last[-1].all()) and (N < 32 or int(last[:-1].sum()) > 0), "the case must exercise device-side resets"
+
+
+def test_a_step_past_the_last_row_writes_nothing_and_is_reported(eng, golden, oracle):
+    """The step index lives on the device: a launch with t outside [0, T) (one replay too many, counters never
+    rewound) must not write beyond the rollout buffers.  K10 and K13 touch nothing, advance nothing and leave a sticky
+    mark behind the counters; the oracle refuses the same call; A3DeviceRollout turns the mark into an error."""
+    from olympic_hip._ffi import OlyError
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    h = lambda t_: t_.cpu().numpy()
+    g = golden("a3_task.npz")
+    spec = specs.A3Spec(mass=41.5)
+    eng.a3_configure(spec, g["clock_lut"])
+    eng.contact_configure(*CONTACT)
+    N, T = 40, 3
+    blocks, state, ro, _ = _host_rollout(spec, N, 4, T, 2, 2, seed=9)
+    d_blocks, d_state, d_ro = _to_device(eng, blocks, state, ro)
+    launch = eng.a3_vec_prepare(d_blocks, d_state, d_ro)
+    launch(_abi.VSTEP_RESET_ALL)
+    for _ in range(T):
+        launch(0)
+    torch.cuda.synchronize()
+    snap = {k: v.clone() for k, v in list(d_ro.items()) + list(d_state.items()) if isinstance(v, torch.Tensor)}
+    launch(0)                                                        # t == T
+    torch.cuda.synchronize()
+    c = h(d_ro["ctr"]).reshape(-1, 2)
+    assert c[-1, 0] == 1 and (c[:-1, 0] == T).all()
+    d_ro["ctr"][-2] = 0
+    for k, v in snap.items():
+        cur = d_ro[k] if k in d_ro else d_state[k]
+        assert torch.equal(cur, v), k
+    orc_ro = dict(ro, ctr=np.array([T, 0], np.int32))
+    with pytest.raises(Exception):
+        oracle.a3_vec_step(spec, g["clock_lut"], CONTACT, blocks, state, orc_ro, 0)
+    d_ro["ctr"][0:-2:2] = -1                                          # K13 with a negative counter
+    pa = torch.zeros(eng._mlp_floats(41, 12), device="cuda")
+    pc = torch.zeros(eng._mlp_floats(41, 1), device="cuda")
+    launch.persistent(pa, True, pc, False)
+    torch.cuda.synchronize()
+    assert int(d_ro["ctr"][-2]) == 1
+    # the facade: a rollout whose counters were tampered with raises instead of returning a corrupt buffer
+    env = _make_env(64, 4, seed=1)
+    torch.manual_seed(0)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    env.device_rollout(pi, vf, 6, 3, graph=False, persistent=False)
+    r = env._dev_rollout
+    r.launch(0, *r._fw.outputs(64))                                   # a seventh step into a six-row buffer
+    with pytest.raises(OlyError, match="outside"):
+        r._finalize(r._fw, vf)
 
 
 def test_persistent_rollout_keeps_the_reward_terms_and_rejects_other_forwards():
@@ -508,7 +556,7 @@ def test_vec_step_random_configurations(eng, golden, oracle, seed):
             a, b = h(d_ro[k]), ro[k]
             assert np.abs(a - b).max() <= np.spacing(np.float32(1.0)) * max(1.0, np.abs(b).max()), (k, what)
     c = h(d_ro["ctr"]).reshape(-1, 2)
-    assert (c[:, 0] == ro["ctr"][0]).all() and (c[:, 1] == ro["ctr"][1]).all()
+    assert (c[:-1, 0] == ro["ctr"][0]).all() and (c[:-1, 1] == ro["ctr"][1]).all() and c[-1, 0] == 0
 
 
 @pytest.mark.parametrize("in_dim,out_a,out_b,N", [(1, 1, 1, 5), (7, 32, 1, 33), (40, 5, 32, 64), (64, 12, 1, 97),
