@@ -63,6 +63,11 @@ def mean_std_from_stats(stats3, ddof):
     return mean, torch.sqrt(var)
 
 
+def _via_host(t):
+    """gloo is the rehearsal backend (CPU collectives): device tensors bounce through the host."""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
 def broadcast_parameters(modules, src=0):
     """One learner replicated on every rank: copy rank `src`'s parameters and buffers to all ranks
     (the reference has ONE policy / critic that every ray worker receives, rl/algos/ppo.py:200-207)."""
@@ -70,21 +75,57 @@ def broadcast_parameters(modules, src=0):
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
-            dist.broadcast(t.data, src=src)
+            if _via_host(t.data):
+                h = t.data.cpu()
+                dist.broadcast(h, src=src)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src=src)
 
 
-def allreduce_gradients(params):
-    """Mean of the gradients over ranks in ONE fused all-reduce (policy + critic ~ 160 k floats = 0.6 MB:
-    latency-bound on xGMI, so a single flat buffer).  With equal shard sizes the mean of the per-rank
-    minibatch means is the gradient of the global minibatch the reference's single learner would see."""
+def allreduce_sum(values):
+    """Element-wise sum over ranks of a short list of python numbers (float64), identical on every rank."""
+    if not is_dist():
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    if dist.get_backend() != "gloo":
+        t = t.cuda()
+    dist.all_reduce(t)
+    return t.cpu().tolist()
+
+
+def allreduce_min(value):
+    if not is_dist():
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64)
+    if dist.get_backend() != "gloo":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def allreduce_gradients(params, weight=None, total_weight=None):
+    """Weighted mean of the gradients over ranks in ONE fused all-reduce (policy + critic ~ 160 k floats =
+    0.6 MB: latency-bound on xGMI, so a single flat buffer).  weight = this rank's minibatch rows, total_weight =
+    their sum over ranks: sum_r (rows_r / rows) grad_r is the gradient of the global minibatch the reference's
+    single learner would see, whatever the shard sizes.  Without weights: the plain mean (equal shards).
+    Every rank ends with bit-identical gradients (the collective's result is the same everywhere)."""
     if not is_dist():
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
-        return
+    for p in params:           # a parameter no loss term reached on THIS rank still takes part (zeros): the flat
+        if p.grad is None:     # buffers of all ranks must have the same layout
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat)
-    flat /= dist.get_world_size()
+    if weight is not None:
+        flat *= float(weight)
+    if _via_host(flat):
+        h = flat.cpu()
+        dist.all_reduce(h)
+        flat.copy_(h)
+    else:
+        dist.all_reduce(flat)
+    flat /= float(total_weight) if weight is not None else dist.get_world_size()
     off = 0
     for g in grads:
         n = g.numel()

@@ -277,6 +277,16 @@ class GraphedActorCritic:
         return self.mu + (self.scale * self.anneal) * torch.randn_like(self.mu), self.value
 
 
+def _global_episode_means(ep_ret, ep_len, multi_rank):
+    """(mean return, mean length) over the episodes of every rank (this rank's alone without a process group)."""
+    tot = [float(np.sum(ep_ret)) if len(ep_ret) else 0.0, float(np.sum(ep_len)) if len(ep_len) else 0.0,
+           float(len(ep_ret))]
+    if multi_rank:
+        from . import dist as odist
+        tot = odist.allreduce_sum(tot)
+    return (tot[0] / tot[2], tot[1] / tot[2]) if tot[2] else (0.0, 0.0)
+
+
 class PPO:
     def __init__(self, args, save_path):
         self.gamma, self.lam = args["gamma"], args["lam"]
@@ -448,6 +458,7 @@ class PPO:
             # collective, so multi-rank training takes the eager update path.
             odist.broadcast_parameters([policy, critic, self.old_policy])
             use_graph = False
+        is_writer = (not multi_rank) or torch.distributed.get_rank() == 0     # ONE set of logs / checkpoints
         post = PPORollout(env.eng, gamma=self.gamma, lam=self.lam, eps=self.eps)
         obs_mirr = getattr(env, "mirror_clock_observation", None) if hasattr(env, "mirror_observation") else None
         act_mirr = getattr(env, "mirror_action", None)
@@ -478,6 +489,13 @@ class PPO:
             self.total_steps += n
             self.old_policy.load_state_dict(policy.state_dict())
             minibatch = self.minibatch_size or n
+            n_batches = n // minibatch
+            rows_all = float(minibatch)
+            if multi_rank:
+                # shards may differ in size (shard_range hands out near-equal ranges): every rank must enter the same
+                # number of gradient all-reduces, and a rank's gradient counts with its minibatch's rows
+                n_batches = odist.allreduce_min(n_batches)
+                rows_all = odist.allreduce_sum([minibatch])[0]
             t1 = time.time()
             stats = []
             graphed = None
@@ -497,7 +515,7 @@ class PPO:
                 # torch.randperm(n) from the default CPU generator and cuts it into consecutive
                 # batches; the same permutation is cut on the device here (no per-index Python loop)
                 perm = torch.randperm(n).to(observations.device)
-                for b in range(n // minibatch):
+                for b in range(n_batches):
                     idx = perm[b * minibatch:(b + 1) * minibatch]
                     if graphed is not None:
                         every = getattr(self, "graph_recapture_every", None)     # test hook: fresh graph every k replays
@@ -524,7 +542,8 @@ class PPO:
                         (a_l + self.mirror_coeff * m_l + self.ent_coeff * ent).sum().backward()
                         c_l.backward()
                     if multi_rank:
-                        odist.allreduce_gradients(list(policy.parameters()) + list(critic.parameters()))
+                        odist.allreduce_gradients(list(policy.parameters()) + list(critic.parameters()),
+                                                  weight=minibatch, total_weight=rows_all)
                     torch.nn.utils.clip_grad_norm_(policy.parameters(), self.grad_clip)
                     self.actor_optimizer.step()
                     torch.nn.utils.clip_grad_norm_(critic.parameters(), self.grad_clip)
@@ -538,25 +557,30 @@ class PPO:
                 graphed.close()
             del graphed
             ep_ret, ep_len = buf.episode_stats()
-            mean_ret = float(np.mean(ep_ret)) if ep_ret else 0.0
-            with open(self.train_fn, "a") as out:
-                out.write("{},{}\n".format(mean_ret, float(np.mean(ep_len)) if ep_len else 0.0))
+            mean_ret, mean_len = _global_episode_means(ep_ret, ep_len, multi_rank)
+            if is_writer:
+                with open(self.train_fn, "a") as out:
+                    out.write("{},{}\n".format(mean_ret, mean_len))
             eval_rec = {}
             if (itr + 1) % self.eval_freq == 0:               # deterministic evaluation + checkpoints (:443-477)
                 t2 = time.time()
                 test = self.sample_vec(env, self.policy, self.critic, T, self.max_traj_len, deterministic=True)
                 t_ret, t_len = test.episode_stats()
-                avg_eval_reward = float(np.mean(t_ret)) if t_ret else 0.0
-                with open(self.eval_fn, "a") as out:
-                    out.write("{},{}\n".format(avg_eval_reward, float(np.mean(t_len)) if t_len else 0.0))
-                self.save(policy, critic, "_" + repr(itr))
+                # the evaluation return over ALL ranks' episodes: highest_reward drives the exploration anneal above,
+                # which must not diverge between the replicas of the one learner
+                avg_eval_reward, avg_eval_len = _global_episode_means(t_ret, t_len, multi_rank)
+                if is_writer:
+                    with open(self.eval_fn, "a") as out:
+                        out.write("{},{}\n".format(avg_eval_reward, avg_eval_len))
+                    self.save(policy, critic, "_" + repr(itr))
                 if self.highest_reward < avg_eval_reward:
                     self.highest_reward = avg_eval_reward
-                    self.save(policy, critic)
+                    if is_writer:
+                        self.save(policy, critic)
                 eval_rec = dict(eval_return=avg_eval_reward, eval_s=time.time() - t2)
                 if verbose:
                     print("====EVALUATE EPISODE====  (Return = {})".format(avg_eval_reward))
-            rec = dict(itr=itr, ep_return=mean_ret, ep_len=float(np.mean(ep_len)) if ep_len else 0.0,
+            rec = dict(itr=itr, ep_return=mean_ret, ep_len=mean_len,
                        sample_s=sample_s, optim_s=time.time() - t1,
                        fps=self.total_steps / (time.time() - start), losses=np.mean(stats, axis=0).tolist(), **eval_rec)
             history.append(rec)

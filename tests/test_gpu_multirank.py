@@ -47,6 +47,31 @@ def test_config5_two_ranks_share_one_gpu(tmp_path):
     np.testing.assert_allclose(want, (a - a.mean()) / (a.std(ddof=1) + 1e-5), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("n0,n1", [(64, 64), (64, 48)])
+def test_ppo_train_two_ranks_share_one_gpu(tmp_path, n0, n1):
+    """PPO.train with world 2: the replicas of the ONE learner stay bit-identical through two iterations
+    (parameter broadcast from rank 0, row-weighted gradient all-reduce per minibatch, globally reduced evaluation
+    return driving highest_reward / the anneal), also when the shards differ in size (every rank enters the same
+    number of collectives: no hang), and only rank 0 writes logs and checkpoints."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "tests", "_dist_train_worker.py"), str(tmp_path), str(n0), str(n1)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert not np.array_equal(r0["first"], r1["first"])                  # they started from different weights ...
+    assert np.array_equal(r0["params"], r1["params"])                    # ... and end bit-identical
+    assert np.isfinite(r0["params"]).all() and np.isfinite(r0["losses"]).all()
+    assert float(r0["highest"]) == float(r1["highest"]) > -1e9
+    assert np.array_equal(r0["eval_returns"], r1["eval_returns"]) and np.array_equal(r0["ep_returns"], r1["ep_returns"])
+    assert int(r0["total_steps"]) == 2 * 8 * n0 and int(r1["total_steps"]) == 2 * 8 * n1
+    # header + ONE line per iteration in each log (not one per rank); checkpoints exist (rank 0 wrote them)
+    for f in ("train.txt", "eval.txt"):
+        assert len(open(tmp_path / f).read().splitlines()) == 3, f
+    assert os.path.exists(tmp_path / "actor.pt") and os.path.exists(tmp_path / "critic_1.pt")
+
+
 @pytest.mark.parametrize("config", [5, 2])
 def test_bench_starts_its_own_ranks(config):
     """`python bench.py --gpus 2` with no WORLD_SIZE starts two rank processes itself and reports
