@@ -675,7 +675,8 @@ extern "C" int oly_a3_batcher_step(oly_a3_batcher* b, const float* action, const
     OLY_HIP(ctx, hipMemcpyAsync(d, b->hc_slab, b->c_fixed_bytes + sizeof(oly_contact_record) * (size_t)total,
                                 hipMemcpyHostToDevice, s));
     int rc = oly_contact_reduce_csr(ctx, b->N, b->C, c_ptr<int32_t>(b, d, C_NCON), c_ptr<int32_t>(b, d, C_COFF),
-                                    c_ptr<oly_contact_record>(b, d, C_REC), b->d_nr, b->d_nl, b->d_grf_r, b->d_grf_l,
+                                    c_ptr<oly_contact_record>(b, d, C_REC), (int64_t)total, b->d_nr, b->d_nl, b->d_grf_r,
+                                    b->d_grf_l,
                                     b->d_minz, b->d_bad, stream);
     if (rc) return rc;
     oly_a3_inputs in;

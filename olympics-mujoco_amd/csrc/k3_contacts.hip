@@ -22,8 +22,10 @@ constexpr int SLOTS = 16;
 // CSR = false: padded slots, contact i of env n at [n, i] of geom1 / geom2 / force6 / pos_z.
 // CSR = true:  compact records (oly_contact_record, 64 B), contact i of env n at rec[coff[n] + i]: what the
 //              host batcher ships when only the used slots cross PCIe; geom1 = coff, force6 = the records.
+// nrec (CSR only): number of records behind `force6`; an offset + slot at or beyond it is never dereferenced and
+// marks the environment bad.
 template <bool CSR>
-__global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, int C,
+__global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, int C, long nrec,
                                                           const int* __restrict__ ncon,
                                                           const int* __restrict__ geom1,
                                                           const int* __restrict__ geom2,
@@ -48,12 +50,17 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
     const int nc = min(max(nc_raw, 0), C);
     int cnt_r = 0, cnt_l = 0;
     double sum_r = 0.0, sum_l = 0.0, mz = 0.0;
-    bool have = false;
+    bool have = false, oob = false;
     for (int ps = 0; ps < passes; ++ps) {
       const int i = ps * SLOTS + slot;
       bool is_r = false, is_l = false;
       double nrm = 0.0, pz = 0.0;
-      if (env_ok && i < nc) {
+      bool in_range = env_ok && i < nc;
+      if (CSR && in_range) {
+        const long e = (long)geom1[n] + i;
+        if (e < 0 || e >= nrec) { in_range = false; oob = true; }
+      }
+      if (in_range) {
         const size_t e = CSR ? (size_t)geom1[n] + i : (size_t)n * C + i;
         const oly_contact_record* rec = reinterpret_cast<const oly_contact_record*>(force6) + e;
         const int g1 = CSR ? rec->geom1 : geom1[e], g2 = CSR ? rec->geom2 : geom2[e];
@@ -97,6 +104,8 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
         }
       }
     }
+    // a record index outside the record array (CSR): the environment cannot be reduced, report it as bad
+    const bool any_oob = ((__ballot(oob) >> (grp * SLOTS)) & 0xffffull) != 0ull;
     if (env_ok) {
       // -1 padding of the index lists
       for (int i = slot; i < C; i += SLOTS) {
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(THREADS) void contact_kernel(ContactDev cd, int N, 
         // against the RAW count: an environment with more contacts than the C staged slots (or a
         // negative count) cannot be reduced faithfully, so it is reported as a bad collision
         // instead of silently dropping the surplus (check_bad_collisions iterates all data.ncon)
-        bad[n] = (uint8_t)((cnt_r + cnt_l) != nc_raw);
+        bad[n] = (uint8_t)(((cnt_r + cnt_l) != nc_raw) || any_oob);
       }
     }
   }
@@ -250,19 +259,19 @@ extern "C" int oly_contact_reduce(oly_ctx* ctx, int N, int C, const int32_t* nco
   long blocks = (waves * 64 + THREADS - 1) / THREADS;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(contact_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->contact,
-                     N, C, ncon, geom1, geom2, force6, pos_z, n_r, n_l, idx_r, idx_l, grf_r, grf_l, min_z,
+                     N, C, 0L, ncon, geom1, geom2, force6, pos_z, n_r, n_l, idx_r, idx_l, grf_r, grf_l, min_z,
                      bad);
   OLY_LAUNCH_CHECK(ctx, "contact_kernel");
   return OLY_OK;
 }
 
 extern "C" int oly_contact_reduce_csr(oly_ctx* ctx, int N, int C, const int32_t* ncon, const int32_t* coff,
-                                      const oly_contact_record* records, int32_t* n_r, int32_t* n_l,
+                                      const oly_contact_record* records, int64_t n_records, int32_t* n_r, int32_t* n_l,
                                       double* grf_r, double* grf_l, double* min_z, uint8_t* bad,
                                       oly_stream stream) {
   if (!ctx) return OLY_EINVAL;
   if (!ctx->contact_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_contact_reduce_csr before oly_contact_configure");
-  if (N < 0 || C <= 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_contact_reduce_csr: bad N or C");
+  if (N < 0 || C <= 0 || n_records < 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_contact_reduce_csr: bad N, C or n_records");
   if (N == 0) return OLY_OK;
   if (!ncon || !coff || !records || !n_r || !n_l || !grf_r || !grf_l || !min_z || !bad)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_contact_reduce_csr: NULL pointer");
@@ -270,7 +279,7 @@ extern "C" int oly_contact_reduce_csr(oly_ctx* ctx, int N, int C, const int32_t*
   long blocks = (waves * 64 + THREADS - 1) / THREADS;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(contact_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, oly_s(stream), ctx->contact,
-                     N, C, ncon, coff, nullptr, reinterpret_cast<const double*>(records), nullptr, n_r, n_l,
+                     N, C, (long)n_records, ncon, coff, nullptr, reinterpret_cast<const double*>(records), nullptr, n_r, n_l,
                      nullptr, nullptr, grf_r, grf_l, min_z, bad);
   OLY_LAUNCH_CHECK(ctx, "contact_kernel<csr>");
   return OLY_OK;

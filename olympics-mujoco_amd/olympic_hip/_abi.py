@@ -157,7 +157,7 @@ SIGNATURES = {
     "oly_expert_dataset": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "oly_contact_configure": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
     "oly_contact_reduce": (C.c_int, [vp, C.c_int, C.c_int] + [vp] * 13 + [vp]),
-    "oly_contact_reduce_csr": (C.c_int, [vp, C.c_int, C.c_int] + [vp] * 10),
+    "oly_contact_reduce_csr": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64] + [vp] * 7),
     "oly_a3_configure": (C.c_int, [vp, C.POINTER(A3Model)]),
     "oly_a3_step": (C.c_int, [vp, C.c_int, C.POINTER(A3Inputs), C.POINTER(A3State), vp, vp, vp, vp,
                               C.c_int, vp]),

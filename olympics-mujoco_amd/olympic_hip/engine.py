@@ -254,7 +254,8 @@ class Engine:
         o = dict(n_r=self._new((N,), torch.int32), n_l=self._new((N,), torch.int32),
                  grf_r=self._new((N,), torch.float64), grf_l=self._new((N,), torch.float64),
                  min_z=self._new((N,), torch.float64), bad=self._new((N,), torch.uint8))
-        self.ctx.call("oly_contact_reduce_csr", N, int(max_contacts), ptr(ncon), ptr(coff), ptr(records), ptr(o["n_r"]),
+        self.ctx.call("oly_contact_reduce_csr", N, int(max_contacts), ptr(ncon), ptr(coff), ptr(records),
+                      records.numel() // C.sizeof(_abi.ContactRecord), ptr(o["n_r"]),
                       ptr(o["n_l"]), ptr(o["grf_r"]), ptr(o["grf_l"]), ptr(o["min_z"]), ptr(o["bad"]), self._s())
         return o
 

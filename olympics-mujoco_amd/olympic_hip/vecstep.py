@@ -248,6 +248,13 @@ class A3DeviceRollout:
             t += 1
         self._predraw(1.15 * self._last_total + 64)           # host work behind the queued launches
         self._finalize(fw, critic)
+        if U and not fused:
+            # A graph that holds torch GEMM / elementwise nodes lives for ONE rollout.  profiles/r02/graph_drift: a
+            # captured torch graph replays bit-exactly until [synchronize -> kernel write into a newly allocated
+            # block >= 1 MB] happens between two replays, which is exactly what an update phase does; the cause
+            # sits inside the runtime / the captured temporaries.  Graphs of this library's own two kernels (the
+            # fused forward) use no torch temporaries and stay cached.
+            self.close()
         return buf
 
     def _default_forward(self, policy, critic):

@@ -721,6 +721,19 @@ def test_contact_reduce_csr_equals_the_padded_form(eng, N, C):
     for k in ("n_r", "n_l", "grf_r", "grf_l", "min_z", "bad"):
         assert torch.equal(got[k], ref[k]), k
     assert int(ref["bad"].sum()) > 0 or N == 1
+    # offsets are device data: one that points past the records (or before them) is never dereferenced, the
+    # environment comes back bad; the other environments are unaffected
+    if N > 2:
+        coff2 = coff.copy()
+        victims = [i for i in (1, N - 1) if ncon[i] > 0][:2]
+        for i, off in zip(victims, (len(rec), -5)):                   # first record index == n_records; negative
+            coff2[i] = off
+        got2 = eng.contact_reduce_csr(dev(ncon), dev(coff2), dev(rec.view(np.uint8).reshape(-1)), C)
+        ok = np.ones(N, bool)
+        ok[victims] = False
+        for k in ("n_r", "n_l", "grf_r", "grf_l", "min_z", "bad"):
+            assert torch.equal(got2[k][torch.as_tensor(ok)], ref[k][torch.as_tensor(ok)]), k
+        assert all(int(got2["bad"][i]) == 1 for i in victims)
 
 
 def test_contacts_more_than_the_staged_slots(eng):

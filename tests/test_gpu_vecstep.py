@@ -345,6 +345,42 @@ def test_a_step_past_the_last_row_writes_nothing_and_is_reported(eng, golden, or
         r._finalize(r._fw, vf)
 
 
+def test_torch_forward_graphs_do_not_outlive_their_rollout():
+    """with the modules' own torch forward (any policy that is not 2 x 256 relu) the captured rollout graph
+    holds torch GEMM nodes; an update phase between two rollouts (synchronize, fresh allocations >= 1 MB, kernel
+    writes) is the sequence after which such graphs were seen to replay wrongly (profiles/r02/graph_drift).  The
+    graphs are therefore released with their rollout: a second, re-captured rollout after an update-like phase equals
+    the eager loop bit for bit, and no graph stays cached."""
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    from olympic_hip.vecstep import TorchForward
+    N, T, max_len = 256, 19, 7
+    torch.manual_seed(0)
+    pi, vf = MLPGaussianActor(41, 12, layers=(128, 96)).cuda(), MLPCritic(41, layers=(128, 96)).cuda()
+    out = []
+    for graph in (False, True):
+        env = _make_env(N, 5, seed=6)
+        fw = TorchForward(pi, vf)
+        for it in range(2):
+            torch.manual_seed(21 + it)
+            buf = env.device_rollout(pi, vf, T, max_len, anneal=0.9, graph=graph, forward=fw)
+            assert not env._dev_rollout._graphs, "torch-forward graphs must be released with their rollout"
+            snap = {k: getattr(buf, k).clone() for k in ("states", "actions", "rewards", "values", "next_values", "flags")}
+            # an update-like phase: synchronize, new >= 1 MB blocks written by kernels
+            torch.cuda.synchronize()
+            junk = [torch.empty(1 << 20, device="cuda").normal_() for _ in range(3)]
+            (junk[0] @ junk[1][:1 << 20]).item()
+            del junk
+            torch.cuda.empty_cache()
+        out.append(snap)
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
+    # the default policy shape keeps its graphs (they replay only K10 + K11)
+    pi2, vf2 = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    env = _make_env(N, 5, seed=6)
+    env.device_rollout(pi2, vf2, T, max_len, graph=True, persistent=False)
+    assert len(env._dev_rollout._graphs) == 1
+
+
 def test_persistent_rollout_keeps_the_reward_terms_and_rejects_other_forwards():
     """buf_rew6 through K13, and the error when the forward is not the fused one."""
     from olympic_hip._ffi import OlyError
