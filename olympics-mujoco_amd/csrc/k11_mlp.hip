@@ -59,9 +59,20 @@ __global__ void mlp_pack_kernel(PackLayout L, const float* __restrict__ W1, cons
     } else if (e < L.std) {
       const int k = (int)(e - L.mean);
       v = (mean && k < L.in_dim) ? mean[k] : 0.f;
-    } else {
+    } else if (e < L.w1n) {
       const int k = (int)(e - L.std);
       v = (std && k < L.in_dim) ? std[k] : 1.f;
+    } else {
+      // the 16-column-tile streams: P16[tile][group][lane][q] = W[16 tile + (lane & 15)][16 group + 4 q + (lane >> 4)]
+      const bool l1 = e < L.w2n, l2 = !l1 && e < L.w3n;
+      const size_t r = e - (l1 ? L.w1n : l2 ? L.w2n : L.w3n);
+      const int groups = l1 ? G1N : HID / 16;
+      const int q = r & 3, lane = (r >> 2) & 63;
+      const int g = (int)((r >> 8) % groups), tile = (int)((r >> 8) / groups);
+      const int k = 16 * g + 4 * q + (lane >> 4), n = 16 * tile + (lane & 15);
+      if (l1) v = k < L.in_dim ? W1[(size_t)n * L.in_dim + k] : 0.f;
+      else if (l2) v = W2[(size_t)n * HID + k];
+      else v = n < L.out_dim ? W3[(size_t)n * HID + k] : 0.f;
     }
     out[e] = v;
   }

@@ -4,29 +4,34 @@
 // The two-kernel rollout (K11 forward + K10 vec step per step) pays two dependent launches per step: ~9 us of
 // launch ramp, first-touch loads and epilogues for ~4 us of work at N = 4096.  Environments are independent and the
 // weights are read-only during a rollout, so nothing in the loop needs a grid-wide synchronisation: here a
-// workgroup OWNS 32 environments for all T steps,
+// workgroup OWNS 16 environments for all T steps,
 //
 //     forward(obs_t)  ->  sample / store  ->  env step t (contacts, WalkingTask.step / reward / done / get_obs,
 //                                             cut rules, bootstrap row, env.reset() from the pre-drawn record)
 //                     ->  forward(obs_{t+1}) ...
 //
 // with the observation, the task state and the step sequence living in LDS / registers from the first step to the
-// last.  Geometry: grid (N / 32, 2).  blockIdx.y picks the NETWORK the workgroup evaluates (0: actor, 1: critic),
-// exactly K11's tile: 8 waves, 32 rows, one network, weights streamed from L2 in the packed B-operand layout.  BOTH
-// workgroups of a 32-environment tile run the (cheap, latency-bound) environment step themselves instead of
-// handing the observation across CUs: a cross-CU hand-off costs 1-3 us per step (MI355X_MICROARCH.md price list),
-// the replayed step costs nothing on the critical path, and it keeps all 256 CUs on the matrix pipes.  Only one
-// workgroup of a pair stores any given array: the actor one the actions, rewards, flags, bootstrap rows and the
-// final task state, the critic one the stored observations and the values.
+// last.  The order of the reference's loop is kept (the environment step of t follows the forward that produces
+// action t, as it must when the action feeds a physics engine), so a workgroup alternates between a matrix phase and
+// a latency-bound libm phase that leaves the matrix pipes idle.  Geometry therefore: grid (N / 16, 2) = 512
+// workgroups of 4 waves at N = 4096, TWO resident per CU, each on its own environments: while one is in its
+// environment step the other's forward has the matrix cores (v1 of this kernel, one 32-environment / 8-wave
+// workgroup per CU, ran the two phases back to back: 12.8 + 9.9 us per step, profiles/r03/k13_phase_times_first.json).
+// blockIdx.y picks the NETWORK the workgroup evaluates (0: actor, 1: critic) as 16-row tiles on
+// v_mfma_f32_16x16x4_f32, weights streamed from L2 in the packed B-operand layout (mlp_tiles.h).  BOTH workgroups
+// of a 16-environment tile run the (cheap) environment step themselves instead of handing the observation across CUs:
+// a cross-CU hand-off costs 1-3 us per step (MI355X_MICROARCH.md price list), the replayed step needs no
+// synchronisation at all.  Only one workgroup of a pair stores any given array: the actor one the actions, rewards,
+// flags, bootstrap rows and the final task state, the critic one the stored observations and the values.
 //
 // Per step the only global traffic on the critical path is the weight stream (L2 hits).  Readback rows and the
 // noise row of step t + 1 are requested right after step t's own rows were consumed, i.e. a whole libm phase and a
 // forward before they are needed; stores are fire-and-forget.
 //
-// Numerics: the forward is K11's (mlp_tiles.h: exact f32 fma chains, k ascending; the output layer's eight partial
-// chains added in wave order, bias last), the environment step K10's, expression for expression, on the same libm
-// entry points (a3_vec_core.h, -ffp-contract=off): buffers and final state are BIT-IDENTICAL to T rounds of
-// oly_mlp_forward2 + oly_a3_vec_step (tests/test_gpu_vecstep.py).
+// Numerics: the forward is K11's arithmetic (exact f32 fma chains, k ascending; the output layer's eight partial
+// chains over k in [32 j, 32 j + 32) added in order j, bias last) on the 16-row instruction, the environment step
+// K10's, expression for expression, on the same libm entry points (a3_vec_core.h, -ffp-contract=off): buffers and
+// final state are BIT-IDENTICAL to T rounds of oly_mlp_forward2 + oly_a3_vec_step (tests/test_gpu_vecstep.py).
 #include <cstdlib>
 
 #include "a3_vec_core.h"
@@ -34,12 +39,23 @@
 #include "oly_common.h"
 
 using namespace oly_a3v;
-using namespace oly_mlp;
+using oly_mlp::act16_index;
+using oly_mlp::f32x4;
+using oly_mlp::G1N;
+using oly_mlp::HID;
+using oly_mlp::layer_tiles16;
+using oly_mlp::MAX_IN;
+using oly_mlp::pack_layout;
+using oly_mlp::PackLayout;
+using oly_mlp::store_relu16;
 
 namespace {
+constexpr int THREADS = 256;            // 4 waves; two workgroups per CU
 constexpr int SLOTS = 16;               // lanes per environment
-constexpr int EPW = THREADS / SLOTS;    // environments per workgroup
-static_assert(EPW == RT, "a workgroup's environments are one 32-row MFMA tile");
+constexpr int EPW = THREADS / SLOTS;    // environments per workgroup = rows of the MFMA tile
+static_assert(EPW == 16, "a workgroup's environments are one 16-row MFMA tile");
+constexpr int KSPLIT = 8;               // output layer: partial chains over k in [32 j, 32 j + 32), as K11's eight waves
+constexpr int PPITCH = 17;              // pitch of the output layer's partial tiles [chain][row][col]
 constexpr int MAX_NU = 16;
 constexpr int MAX_NOBS = 7 + 2 * MAX_NU + 10;
 constexpr int OBP = MAX_NOBS + 1;       // pitch of the observation rows in LDS
@@ -76,15 +92,21 @@ struct RollArgs {
   int out_dim[2], normalize[2];
   float* mu_out;       // [N,nu] mean of the LAST forward (what ro.mu holds after the two-kernel loop), or NULL
   float* value_out;    // [N]    value of the last forward, or NULL
-  int skip;            // diagnostic (OLY_K13_SKIP, tools/time_k13.py): bit 0 no MFMA layers, bit 1 no environment step
+  int skip;            // diagnostic (OLY_K13_SKIP, tools/time_k13.py): bit 0 no MFMA layers, bit 1 no environment step;
+                       // bits 4..7 leave the environment step early: after the contacts / level 1 / round 1 / round 2
 };
 
-constexpr size_t ROLL_LDS = sizeof(float) * (MAX_IN + 2 * HID) * LDP + sizeof(double) * EPW * SEQW +
-                            sizeof(float) * 2 * EPW * OBP;
-static_assert(sizeof(double) * (EPW * L_ENV + EPW * SLOTS * 2) + EPW * SLOTS <= sizeof(float) * 2 * HID * LDP,
+// LDS: input image | layer-1 image | layer-2 image (the environment scratch and the output layer's partial tiles
+// alias the two hidden images) | step sequences | observation rows before / after a reset
+constexpr int GEOM_LDS = 1024;          // geom -> body table kept in LDS up to this many geoms
+constexpr size_t ROLL_LDS = sizeof(float) * (MAX_IN + 2 * HID) * EPW + sizeof(double) * EPW * SEQW +
+                            sizeof(float) * 2 * EPW * OBP + sizeof(double) * 4 * OLY_MAX_PERIOD + sizeof(int) * GEOM_LDS;
+static_assert((sizeof(float) * 2 * EPW * OBP) % 8 == 0, "the clock table must stay 8-byte aligned");
+static_assert(sizeof(double) * (EPW * L_ENV + EPW * SLOTS * 2) + EPW * SLOTS <= sizeof(float) * 2 * HID * EPW,
               "the environment scratch must fit in the activation images it aliases");
-static_assert((sizeof(float) * MAX_IN * LDP) % 8 == 0 && (sizeof(float) * (MAX_IN + 2 * HID) * LDP) % 8 == 0,
-              "fp64 regions must be 8-byte aligned");
+static_assert(sizeof(float) * KSPLIT * EPW * PPITCH <= sizeof(float) * HID * EPW, "partial tiles alias the layer-1 image");
+static_assert((sizeof(float) * MAX_IN * EPW) % 16 == 0 && (sizeof(float) * (MAX_IN + 2 * HID) * EPW) % 8 == 0,
+              "image / fp64 regions must stay aligned");
 
 // the readback row of one step as the environment's 16 lanes hold it between the request and its use
 struct Readback {
@@ -92,17 +114,23 @@ struct Readback {
   double va, vb, v_len, v_vel, f0[6], pz0;
 };
 
-__global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
+template <int G1>      // groups of layer 1: 3 (inputs <= 48) or 4
+__global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xT = lds;                                              // [MAX_IN][LDP]  forward input, k-major
-  float* hA = xT + MAX_IN * LDP;                                // [HID][LDP]     layer-1 output / layer-3 partials
-  float* hB = hA + HID * LDP;                                   // [HID][LDP]     layer-2 output
-  double* s_env = reinterpret_cast<double*>(hA);                // [EPW][L_ENV]   (environment phase)
+  float* xT = lds;                                              // [MAX_IN x EPW]  forward input image
+  float* hA = xT + MAX_IN * EPW;                                // [HID x EPW]     layer-1 image / output-layer partials
+  float* hB = hA + HID * EPW;                                   // [HID x EPW]     layer-2 image
+  double* s_env = reinterpret_cast<double*>(hA);                // [EPW][L_ENV]    (environment phase)
   double* s_arg = s_env + EPW * L_ENV;                          // [EPW][SLOTS][2]
   uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_arg + EPW * SLOTS * 2);   // [EPW][SLOTS]
-  double* seqs = reinterpret_cast<double*>(hB + HID * LDP);     // [EPW][SEQW]    step sequences, whole rollout
-  float* s_pre = reinterpret_cast<float*>(seqs + EPW * SEQW);   // [EPW][OBP]     observation before a reset
-  float* s_post = s_pre + EPW * OBP;                            // [EPW][OBP]     observation the policy sees next
+  double* seqs = reinterpret_cast<double*>(hB + HID * EPW);     // [EPW][SEQW]     step sequences, whole rollout
+  float* s_pre = reinterpret_cast<float*>(seqs + EPW * SEQW);   // [EPW][OBP]      observation before a reset
+  float* s_post = s_pre + EPW * OBP;                            // [EPW][OBP]      observation the policy sees next
+  // Model tables the environment step indexes per lane.  From global memory they would be VECTOR loads, and vector
+  // memory operations complete in order: a clock-table load issued behind the request for step t + 1's readback rows
+  // (or behind the forward's stores) waits for all of those first - 3 us per step in the first version of this kernel.
+  double* s_lut = reinterpret_cast<double*>(s_post + EPW * OBP);   // [4][period]  clock LUT
+  int* s_gb = reinterpret_cast<int*>(s_lut + 4 * OLY_MAX_PERIOD);  // [ngeom]      geom -> body
 
   const A3Dev* __restrict__ m = p.md;
   const int nu = m->nu, n_obs = m->n_obs, period = m->period, nq = m->nq, nv = m->nv;
@@ -120,9 +148,9 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
   const bool det = p.ro.deterministic != 0;
   const PackLayout L = pack_layout(p.in_dim, out_dim);
   const float* __restrict__ Pbase = p.packed[net];
-  // K10 keeps one private (t, k) pair per 16-environment workgroup; this workgroup covers two of them
-  const int t0 = p.ro.ctr[4 * blockIdx.x];
-  const int k0 = p.ro.ctr[4 * blockIdx.x + 1];
+  // K10's private (t, k) pair of this 16-environment group
+  const int t0 = p.ro.ctr[2 * blockIdx.x];
+  const int k0 = p.ro.ctr[2 * blockIdx.x + 1];
   if (t0 < 0 || t0 > T) {     // counters the caller never rewound: K10's rule (no write, sticky mark behind the counters)
     if (threadIdx.x == 0) p.ro.ctr[2 * ((N + 15) / 16)] = 1;
     return;
@@ -153,6 +181,11 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
   }
   t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
   t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
+  for (int i = tid; i < 4 * period; i += THREADS) s_lut[i] = m->clock_lut[i];
+  const bool gb_lds = p.cd.ngeom <= GEOM_LDS;
+  if (gb_lds)
+    for (int i = tid; i < p.cd.ngeom; i += THREADS) s_gb[i] = p.cd.geom_bodyid[i];
+  const double gear_s = slot < nu ? m->gear[slot] : 1.0;
   for (int e = tid; e < rows * n_obs; e += THREADS) {
     const int r = e / n_obs, c = e - r * n_obs;
     s_post[r * OBP + c] = p.ro.state[(size_t)row0 * n_obs + e];
@@ -219,6 +252,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
   if (actor && o_ok && !det && t0 < T) eps_next = p.ro.eps[((size_t)t0 * N + row0) * nu + tid];
   __syncthreads();
 
+  const int skip = p.skip;
   for (int t = t0; t < T; ++t) {
     const size_t tN = (size_t)t * N;
     const bool last_step = t == T - 1;
@@ -234,15 +268,15 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     int n_t = n, tid_t = tid, slot_t = slot;
     asm volatile("" : "+v"(n_t), "+v"(tid_t), "+v"(slot_t));
 
-    // ================================================================ forward of obs_t (K11's tile)
-    for (int e = tid; e < MAX_IN * RT; e += THREADS) {
+    // ================================================================ forward of obs_t (K11's arithmetic, 16-row tiles)
+    for (int e = tid; e < MAX_IN * EPW; e += THREADS) {
       const int mrow = e / MAX_IN;
       float v = 0.f;
       if (mrow < rows && xk < p.in_dim) {
         v = s_post[mrow * OBP + xk];
         if (p.normalize[net]) v = (v - x_mean) / x_std;
       }
-      xT[xk * LDP + mrow] = v;
+      xT[act16_index(xk, mrow)] = v;
     }
     if (!actor) {       // memory.store(state, ...): the observation the policy saw (ppo.py:186)
 #pragma unroll
@@ -253,35 +287,43 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     }
     const float eps_t = eps_next;
     __syncthreads();
-    const bool run_mlp = !(p.skip & 1);
-    if (run_mlp) {  // ---- layer 1: [32, in <= 64] x [64, 256] (k zero-padded to 64)
-      f32x16 acc = {0};
-      layer_tile<G1>(xT, P4 + (L.w1 >> 2) + (size_t)wave * G1 * 64, lane, acc);
-      store_relu(acc, P + L.b1, 32 * wave, lane, hA);
-    }
-    __syncthreads();
-    if (run_mlp) {  // ---- layer 2: [32, 256] x [256, 256]
-      f32x16 acc = {0};
-      layer_tile<32>(hA, P4 + (L.w2 >> 2) + (size_t)wave * 32 * 64, lane, acc);
-      store_relu(acc, P + L.b2, 32 * wave, lane, hB);
-    }
-    __syncthreads();
-    if (run_mlp) {  // ---- layer 3: [32, 256] x [256, out <= 32]; wave w owns k in [32 w, 32 w + 32)
-      f32x16 acc = {0};
-      layer_tile<4>(hB + (size_t)(32 * wave) * LDP, P4 + (L.w3 >> 2) + (size_t)(4 * wave) * 64, lane, acc);
-      const int r = lane & 31, h = lane >> 5;
-      float* part = hA + (size_t)wave * RT * LDP;        // [row][col] partial of this wave
+    const bool run_mlp = !(skip & 1);
+    if (run_mlp) {  // ---- layer 1: [16, in <= 64] x [64, 256]; wave w owns columns [64 w, 64 w + 64) = 4 tiles
+      f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+      const float4* base = P4 + (L.w1n >> 2) + (size_t)(4 * wave) * G1N * 64;
+      const float4* const w[4] = {base, base + G1N * 64, base + 2 * G1N * 64, base + 3 * G1N * 64};
+      layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xT), w, lane, acc);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        part[row * LDP + r] = acc[i];
+      for (int t = 0; t < 4; ++t) store_relu16(acc[t], P + L.b1, 4 * wave + t, lane, hA);
+    }
+    __syncthreads();
+    if (run_mlp) {  // ---- layer 2: [16, 256] x [256, 256]
+      f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+      const float4* base = P4 + (L.w2n >> 2) + (size_t)(4 * wave) * (HID / 16) * 64;
+      const float4* const w[4] = {base, base + (HID / 16) * 64, base + 2 * (HID / 16) * 64, base + 3 * (HID / 16) * 64};
+      layer_tiles16<HID / 16, 4>(reinterpret_cast<const float4*>(hA), w, lane, acc);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store_relu16(acc[t], P + L.b2, 4 * wave + t, lane, hB);
+    }
+    __syncthreads();
+    if (run_mlp) {  // ---- layer 3: [16, 256] x [256, out <= 16] as eight partial chains; wave w runs chains 2 w, 2 w + 1
+      const int c = lane & 15, h2 = lane >> 4;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * wave + jj;
+        f32x4 acc[1] = {{0}};
+        const float4* const w[1] = {P4 + (L.w3n >> 2) + (size_t)(2 * j) * 64};
+        layer_tiles16<2, 1>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * j) * 64, w, lane, acc);
+        float* part = hA + (size_t)j * EPW * PPITCH;       // [row][col] partial of chain j
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + c] = acc[0][i];
       }
     }
     __syncthreads();
     if (o_ok) {
-      float s = hA[o_row * LDP + o_col];
+      float s = hA[o_row * PPITCH + o_col];
 #pragma unroll
-      for (int w = 1; w < KSPLIT; ++w) s += hA[(w * RT + o_row) * LDP + o_col];
+      for (int w = 1; w < KSPLIT; ++w) s += hA[(w * EPW + o_row) * PPITCH + o_col];
       s += o_bias;
       if (actor) {
         // Normal(mu, std * anneal).sample() from the pre-drawn noise (ppo.py:181), memory.store's action and the
@@ -304,7 +346,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     __syncthreads();     // the activation images are dead: the environment scratch takes their place
 
     // ================================================================ environment step t (K10's step)
-    if (p.skip & 2) continue;
+    if (skip & 2) continue;
     if (env_ok) {
       se[slot] = rb.va;
       if (dst_b >= 0) se[dst_b] = rb.vb;
@@ -337,7 +379,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
           pz = p.b.cpos_z[e];
         }
         if (g1 >= 0 && g1 < p.cd.ngeom && g2 >= 0 && g2 < p.cd.ngeom) {
-          const int b1 = p.cd.geom_bodyid[g1], b2 = p.cd.geom_bodyid[g2];
+          const int b1 = gb_lds ? s_gb[g1] : p.cd.geom_bodyid[g1], b2 = gb_lds ? s_gb[g2] : p.cd.geom_bodyid[g2];
           is_r = (b1 == p.cd.floor_body) && (b2 == p.cd.rfoot_body);
           is_l = (b1 == p.cd.floor_body) && (b2 == p.cd.lfoot_body);
         }
@@ -379,6 +421,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
       if (actor && o_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + tid_t];
     }
     __syncthreads();
+    if (skip & 16) continue;
 
     // ---- level 1: everything without libm
     const double rq0 = se[L_RQ], rq1 = se[L_RQ + 1], rq2 = se[L_RQ + 2], rq3 = se[L_RQ + 3];
@@ -432,10 +475,10 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     if (!walking) {
       c_rfrc = 1.0; c_lfrc = 1.0; c_rvel = -1.0; c_lvel = -1.0;
     } else {
-      c_rfrc = m->clock_lut[0 * period + phase];
-      c_rvel = m->clock_lut[1 * period + phase];
-      c_lfrc = m->clock_lut[2 * period + phase];
-      c_lvel = m->clock_lut[3 * period + phase];
+      c_rfrc = s_lut[0 * period + phase];
+      c_rvel = s_lut[1 * period + phase];
+      c_lfrc = s_lut[2 * period + phase];
+      c_lvel = s_lut[3 * period + phase];
     }
     const double max_frc = m->mass * 9.8 * 0.5;
     double nl = fmin(grf_l, max_frc) / max_frc;
@@ -495,7 +538,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     const double cyr = sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
 
     // ---- round 1: one libm call per lane (arguments formed by the environment's lanes, evaluation regrouped by
-    // function over the waves: waves 0 / 4 sin-cos, 1 / 5 tan, 2 / 6 exp, 3 / 7 atan2, 16 environments each)
+    // function over the waves: wave 0 sin-cos, 1 tan, 2 exp, 3 atan2 of the workgroup's 16 environments)
     int cls = F_NONE;
     double a = 0.0, b = 0.0;
     switch (slot) {
@@ -520,11 +563,12 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     s_arg[(el * SLOTS + slot) * 2 + 1] = b;
     s_cls[el * SLOTS + slot] = (uint8_t)(env_ok ? cls : F_NONE);
     __syncthreads();
+    if (skip & 32) continue;
     double r0, r1;
-    const int ee = 16 * (wave >> 2) + (lane & 15);
+    const int ee = lane & 15;
     {
       constexpr int R1_TASK[4][4] = {{0, 1, 6, 13}, {2, 3, 4, 5}, {7, 8, 9, 10}, {11, 12, 14, -1}};
-      const int task = R1_TASK[wave & 3][lane >> 4];
+      const int task = R1_TASK[wave][lane >> 4];
       if (task >= 0) {
         eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
         s_env[ee * L_ENV + L_R1 + 2 * task] = r0;
@@ -532,6 +576,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
       }
     }
     __syncthreads();
+    if (skip & 64) continue;
 
     // ---- round 2
     const double root_yaw = se[L_R1 + 2 * 14];
@@ -566,10 +611,10 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
     }
     __syncthreads();
     {
-      // waves 0 / 4: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's clock-after-reset, slot 15, which only
-      // needed level-1 values); 1 / 5: atan2 (the two goal yaws); 2 / 6: exp (orientation); 3 / 7: idle
+      // wave 0: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's clock-after-reset, slot 15, which only
+      // needed level-1 values); wave 1: atan2 (the two goal yaws); wave 2: exp (orientation); wave 3: idle
       constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
-      const int task = R2_TASK[wave & 3][lane >> 4];
+      const int task = R2_TASK[wave][lane >> 4];
       if (task >= 0) {
         eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
         const int dst = task == 15 ? L_R1 + 2 * 15 : L_R2 + 2 * task;
@@ -578,6 +623,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
       }
     }
     __syncthreads();
+    if (skip & 128) continue;
 
     // ---- combine, observation rows
     float* op = s_pre + el * OBP;
@@ -594,7 +640,7 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
       if (slot == 3) op[3] = (float)(-(si * sj));
       if (slot >= 4 && slot < 7) op[slot] = (float)se[L_AV + slot - 4];
       if (slot < nu) {
-        const double g = m->gear[slot];
+        const double g = gear_s;
         op[7 + slot] = (float)(se[L_AL + slot] / g);
         op[7 + nu + slot] = (float)(se[L_AVL + slot] / g);
       }
@@ -711,9 +757,9 @@ __global__ __launch_bounds__(THREADS) void a3_rollout_kernel(RollArgs p) {
       const int r = e / n_obs, c = e - r * n_obs;
       p.ro.state[(size_t)row0 * n_obs + e] = s_post[r * OBP + c];
     }
-    if (tid < 2 && 2 * blockIdx.x + tid < (unsigned)((N + 15) / 16)) {
-      p.ro.ctr[4 * blockIdx.x + 2 * tid] = T;
-      p.ro.ctr[4 * blockIdx.x + 2 * tid + 1] = k0 + (T - t0);
+    if (tid == 0) {
+      p.ro.ctr[2 * blockIdx.x] = T;
+      p.ro.ctr[2 * blockIdx.x + 1] = k0 + (T - t0);
     }
   }
 }
@@ -742,15 +788,16 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
     if (!q) OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: NULL pointer in blocks / state / rollout / weights");
   if (!ro->deterministic && (!ro->scale || !ro->eps))
     OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: stochastic rollout without scale / eps");
-  if (ctx->a3_host.nu > MAX_NU || ctx->a3_host.nu > MAX_OUT)
-    OLY_FAIL(ctx, OLY_ERANGE, "oly_a3_rollout_persistent: nu > %d", MAX_NU);
+  if (ctx->a3_host.nu > MAX_NU) OLY_FAIL(ctx, OLY_ERANGE, "oly_a3_rollout_persistent: nu > %d", MAX_NU);
   if (in_dim != ctx->a3_host.n_obs || in_dim > MAX_IN || in_dim > MAX_NOBS)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: the networks read %d inputs, the observation has %d", in_dim,
              ctx->a3_host.n_obs);
   if (((reinterpret_cast<uintptr_t>(packed_actor) | reinterpret_cast<uintptr_t>(packed_critic)) & 15) != 0)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: packed weights must be 16-byte aligned");
   if (!ctx->roll_attr_done) {
-    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel),
+    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel<3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROLL_LDS));
+    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel<4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROLL_LDS));
     ctx->roll_attr_done = true;
   }
@@ -772,7 +819,9 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
   a.value_out = value_out;
   static const int skip = [] { const char* e = getenv("OLY_K13_SKIP"); return e ? atoi(e) : 0; }();
   a.skip = skip;
-  hipLaunchKernelGGL(a3_rollout_kernel, dim3((N + EPW - 1) / EPW, 2), dim3(THREADS), ROLL_LDS, oly_s(stream), a);
+  const dim3 grid((N + EPW - 1) / EPW, 2);
+  if (in_dim <= 48) hipLaunchKernelGGL(a3_rollout_kernel<3>, grid, dim3(THREADS), ROLL_LDS, oly_s(stream), a);
+  else hipLaunchKernelGGL(a3_rollout_kernel<4>, grid, dim3(THREADS), ROLL_LDS, oly_s(stream), a);
   OLY_LAUNCH_CHECK(ctx, "a3_rollout_kernel");
   return OLY_OK;
 }

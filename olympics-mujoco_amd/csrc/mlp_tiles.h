@@ -15,9 +15,17 @@ constexpr int THREADS = 512;     // 8 waves
 constexpr int KSPLIT = 8;        // output layer: k split over the waves
 constexpr int G1 = 8;            // layer 1: k zero-padded to MAX_IN = 8 groups of four k-steps
 
+// The packed stream of one network holds every weight matrix TWICE: as the B-operand stream of
+// v_mfma_f32_32x32x2_f32 (32-row tiles: K11) and as that of v_mfma_f32_16x16x4_f32 (16-row tiles: K13, which needs
+// twice as many workgroups); biases and the input normalisation once.
+constexpr int G1N = 4;           // 16-wide layout, layer 1: k zero-padded to MAX_IN = 4 groups of four k-steps (16 k each)
+constexpr int T3N = MAX_OUT / 16;   // 16-wide layout, output layer: column tiles
+
 struct PackLayout {
   int in_dim, out_dim, g1;      // g1: groups of four k-steps in layer 1
-  size_t w1, b1, w2, b2, w3, b3, mean, std, total;
+  size_t w1, b1, w2, b2, w3, b3, mean, std;
+  size_t w1n, w2n, w3n;         // the 16-column-tile streams
+  size_t total;
 };
 
 __host__ __device__ inline PackLayout pack_layout(int in_dim, int out_dim) {
@@ -33,8 +41,76 @@ __host__ __device__ inline PackLayout pack_layout(int in_dim, int out_dim) {
   L.b3 = L.w3 + (size_t)32 * 256;
   L.mean = L.b3 + MAX_OUT;
   L.std = L.mean + MAX_IN;
-  L.total = L.std + MAX_IN;
+  L.w1n = L.std + MAX_IN;
+  L.w2n = L.w1n + (size_t)(HID / 16) * G1N * 256;
+  L.w3n = L.w2n + (size_t)(HID / 16) * (HID / 16) * 256;
+  L.total = L.w3n + (size_t)T3N * (HID / 16) * 256;
   return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16-row tiles on v_mfma_f32_16x16x4_f32 (lane l: A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15]; C/D: col =
+// l & 15, row = 4 (l >> 4) + register).  Same numerics as the 32-row form: every output is the f32 fma chain over k
+// ascending (k = 16 g + 4 q + (l >> 4) for group g, k-step q).
+//
+// Packed weights:  P16[tile][group g][lane][q] = W[n = 16 tile + (lane & 15)][k = 16 g + 4 q + (lane >> 4)]
+//                  (one 16-byte load per lane feeds four k-steps of one 16-column tile)
+// Activations in LDS, as float4:  image[g * 64 + lane] = { act[k = 16 g + 4 q + (lane >> 4)][row = lane & 15] : q = 0..3 }
+//                  i.e. element (k, row) lives at float index act16_index(k, row): the A fragments of a group are ONE
+//                  conflict-free 16-byte read per lane.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int act16_index(int k, int row) {
+  return (((k >> 4) * 4 + (k & 3)) * 16 + row) * 4 + ((k >> 2) & 3);
+}
+
+// NT 16-column tiles of  A W  that share the A operand, G groups (k = 0 .. 16 G - 1 in order): weights two groups
+// ahead, activations one group ahead, fully unrolled; NT >= 2 independent accumulators cover the 40-cycle dependent
+// latency of the 32-cycle instruction.
+template <int G, int NT>
+__device__ __forceinline__ void layer_tiles16(const float4* __restrict__ a4, const float4* const (&w)[NT], int lane,
+                                              f32x4 (&acc)[NT]) {
+  float4 b[3][NT];
+  float4 a[2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    b[0][t] = w[t][lane];
+    if (G > 1) b[1][t] = w[t][64 + lane];
+  }
+  a[0] = a4[lane];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (g + 2 < G) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[(g + 2) % 3][t] = w[t][(size_t)(g + 2) * 64 + lane];
+    }
+    if (g + 1 < G) a[(g + 1) & 1] = a4[(g + 1) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads above ahead of this group's MFMAs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float aq = q == 0 ? a[g & 1].x : q == 1 ? a[g & 1].y : q == 2 ? a[g & 1].z : a[g & 1].w;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bq = q == 0 ? b[g % 3][t].x : q == 1 ? b[g % 3][t].y : q == 2 ? b[g % 3][t].z : b[g % 3][t].w;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// bias + ReLU of a 16 x 16 accumulator tile (columns 16 tile ..) into the activation image of the next layer
+__device__ __forceinline__ void store_relu16(const f32x4& acc, const float* __restrict__ bias, int tile, int lane,
+                                             float* __restrict__ img) {
+  const int c = lane & 15, h2 = lane >> 4;
+  const float bv = bias[16 * tile + c];
+  // k = 16 tile + c of the next layer: group = tile, k-step q = c >> 2, lane group c & 3
+  float* dst = img + ((tile * 4 + (c & 3)) * 16 + 4 * h2) * 4 + (c >> 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = acc[i] + bv;
+    dst[4 * i] = (v > 0.f || v != v) ? v : 0.f;     // relu, NaN kept like torch
+  }
 }
 
 // one 32-row x 32-column tile of  A W  (k = 0 .. 8 G - 1 in order): A fragments from the [k][row] LDS
