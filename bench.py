@@ -198,17 +198,30 @@ def prewarm(rk, step, seconds=0.25):
     """Not a benchmark step: wakes the device.  On this pool an idle MI355X sits at sclk ~600 MHz (`rocm-smi
     --showclocks`) and takes tens of milliseconds of work to reach its running clocks: with the contract's W = 5
     warm-up launches (0.7 ms of work) the K timed launches measured 2.1 ms each instead of 0.13 ms, with W = 50
-    0.132 ms (profiles/r03/clock_ramp.json).  So the same launch is repeated for `seconds` of wall time BEFORE the W
-    warm-up steps and the K timed steps; nothing here is timed or counted, and the line reports it."""
+    0.132 ms (profiles/r03/clock_ramp.json).  So the same launch is repeated for about `seconds` BEFORE the W
+    warm-up steps and the K timed steps; nothing here is timed or counted, and the line reports it.
+    A step may hold a collective (config 5): every rank must run the SAME number of steps, so the counts are
+    derived from per-step times that were MAX-reduced over the ranks, never from a rank's own clock."""
     import torch
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < seconds:
+    n, elapsed = 0, 0.0
+    while True:
+        torch.cuda.synchronize(rk.dev)
+        t0 = time.perf_counter()
         for _ in range(8):
             step(n)
             n += 1
         torch.cuda.synchronize(rk.dev)
-    PREWARM.update({"launches": n, "seconds": time.perf_counter() - t0,
+        dt = max(rk.max_over_ranks((time.perf_counter() - t0) / 8), 1e-7)     # identical on every rank
+        elapsed += 8 * dt
+        if elapsed >= seconds:
+            break
+        count = int(min((seconds - elapsed) / dt, 4096))
+        for _ in range(count):
+            step(n)
+            n += 1
+        elapsed += count * dt
+    torch.cuda.synchronize(rk.dev)
+    PREWARM.update({"launches": n, "seconds_estimated": elapsed,
                     "why": "device clocks ramp from idle over tens of ms on this pool; untimed, before the W warm-up steps"})
 
 
