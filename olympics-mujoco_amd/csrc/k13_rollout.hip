@@ -397,17 +397,26 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
       const unsigned ml = (unsigned)((bl >> (grp * SLOTS)) & 0xffffu);
       cnt_r += __popc(mr);
       cnt_l += __popc(ml);
-      unsigned rem = mr | ml;   // in-order chain over the matching slots (contact order), as contact_kernel
-      while (__any(rem != 0u)) {
-        const int q = rem ? (__ffs((int)rem) - 1) : 0;
-        const double vk = __shfl(nrm, grp * SLOTS + q, 64);
-        const double zk = __shfl(pz, grp * SLOTS + q, 64);
-        if (rem) {
+      // In-order chain over the matching slots (contact order), as contact_kernel / K10: ((0 + n_a) + n_b) + ...
+      // K10 walks the set bits with two 64-bit shuffles per contact (~400 cycles each round); here every lane parks its
+      // norm / height in the environment's scratch row (same wave: LDS operations of a wave complete in order, no
+      // barrier needed) and each lane runs the chain over the 16 slots from LDS broadcasts.
+      double* cn = se + L_R1;            // [16] norms, [16] heights: the libm result rows, unused until round 1
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (a later pass overwrites what this one read)
+      cn[slot] = nrm;
+      cn[SLOTS + slot] = pz;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned any = mr | ml;
+#pragma unroll
+      for (int q = 0; q < SLOTS; ++q) {     // (measured: this form 2.3 us, branch-free selects 2.7, a loop to the highest
+        const double vk = cn[q], zk = cn[SLOTS + q];    // matching slot 2.9, K10's shuffle walk 3.2)
+        if ((any >> q) & 1u) {
           if ((mr >> q) & 1u) sum_r += vk;
           if ((ml >> q) & 1u) sum_l += vk;
           if (!have || zk < mz) mz = zk;
           have = true;
-          rem &= rem - 1u;
         }
       }
     }
