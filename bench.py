@@ -600,12 +600,20 @@ def config4_block(rk, args):
         ms_k12 = event_ms(stream, reps, lambda: eng.disc_forward(x, packed, colstats=cs, eps=eps, out=bufs))
         ms_all = event_ms(stream, reps, lambda: dr.forward(x, eps, out=bufs))
         fl = disc_flop_per_sample() * B
+        traffic = src = None
+        tpath = os.path.join(ROOT, "profiles", "r03", "traffic_k12.json")
+        if label == "T400xN4096" and B == 1638400 and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                src = "profiles/r03/traffic_k12.json (rocprofv3 PMC passes of round 3; read from the file, not measured in this run)"
+            except Exception:
+                traffic = None
         out["shapes"][label] = {
             "samples": B, "disc_forward_us": 1e3 * ms_k12, "col_stats_plus_disc_forward_us": 1e3 * ms_all,
             "samples_per_s": B / (ms_all * 1e-3),
             "roofline": {"bound": "mfma", "achieved": fl / (ms_k12 * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": fl / (ms_k12 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "disc_forward_kernel<4>", "alg_flop_per_sample": disc_flop_per_sample(),
+                         "unit": "TFLOP/s", "frac": fl / (ms_k12 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": src, "kernel": "disc_forward_kernel<4>", "alg_flop_per_sample": disc_flop_per_sample(),
                          "hbm_bytes_per_sample": 4 * (32 + 128 + 1)}}
         del x, eps, bufs
     out["value"] = out["shapes"]["T400xN4096"]["samples_per_s"]
@@ -691,11 +699,12 @@ def bench_config2(args, rk):
     copy_gbps = copy_bandwidth(rk, eng.ctx.stream)
     bpr = alg_bytes_per_row(spec, args.fall_code)
     achieved = bpr * rows / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_round = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_k1.json")
     if os.path.exists(tpath) and (T, N) == (400, 4096) and not args.fall_code and args.robot == "h1":
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic, traffic_round = tj.get("hbm_bytes_per_launch"), tj.get("round")
         except Exception:
             traffic = None
     line = {
@@ -720,8 +729,8 @@ def bench_config2(args, rk):
                    "parallelism": f"env-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": ("profiles/traffic_k1.json (rocprofv3 PMC passes of round 2, FETCH_SIZE x 2 + "
-                                        "WRITE_SIZE; read from the file, not measured in this run)" if traffic else None),
+                     "traffic_source": (f"profiles/traffic_k1.json (rocprofv3 PMC passes of round {traffic_round}, FETCH_SIZE x 2 "
+                                        "+ WRITE_SIZE; read from the file, not measured in this run)" if traffic else None),
                      "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
                      "measured_copy_note": "torch's device-to-device copy_ of 404 MB timed the same way; it is slower than "
                                            "the guide's float4 copy (6.29 TB/s), so a ratio above 1 only says that",
