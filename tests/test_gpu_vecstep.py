@@ -212,10 +212,13 @@ def test_vec_step_equals_the_separate_kernels(eng, golden):
         traj_len = d_ro["traj_len"].clone()
 
 
-def _make_env(N, K, seed, p_bad=0.02):
+def _make_env(N, K, seed, p_bad=0.02, C=16):
     from olympic_hip.a3 import ReplayA3Physics, VecA3Env
     from olympic_hip.engine import Engine
-    blocks = {k: dev(v) for k, v in a3_synthetic_blocks(N, K, seed=seed, p_bad=p_bad, p_low=0.01).items()}
+    host = a3_synthetic_blocks(N, K, seed=seed, C=C, p_bad=p_bad, p_low=0.01)
+    if C != 16:            # use every slot count up to C (the default Poisson(4) rarely passes 10)
+        host["ncon"] = np.random.default_rng(seed).integers(0, C + 1, host["ncon"].shape).astype(np.int32)
+    blocks = {k: dev(v) for k, v in host.items()}
     env = VecA3Env(specs.A3Spec(mass=41.5), N, Engine(0), ReplayA3Physics(blocks), *CONTACT, rs=np.random.RandomState(seed))
     env.device = env.eng.device
     return env
@@ -260,14 +263,17 @@ def test_device_rollout_graph_replay_equals_eager_loop(deterministic):
         assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
 
 
-@pytest.mark.parametrize("N,T,max_len,det,K", [(512, 27, 10, False, 7), (500, 13, 4, True, 5), (37, 40, 100, False, 3),
-                                               (4096, 24, 8, False, 32), (1, 9, 3, False, 4)])
-def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K):
+@pytest.mark.parametrize("N,T,max_len,det,K,C", [(512, 27, 10, False, 7, 16), (500, 13, 4, True, 5, 16),
+                                                 (37, 40, 100, False, 3, 16), (4096, 24, 8, False, 32, 16),
+                                                 (1, 9, 3, False, 4, 16), (300, 11, 5, False, 4, 20),
+                                                 (100, 9, 4, False, 3, 5)])
+def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K, C):
     """K13 (oly_a3_rollout_persistent: ONE launch for the whole rollout, a workgroup owns 32 environments through all
     T steps, observations / task state never leave the CU) against T rounds of K11 + K10 from the same start: every
     buffer, the bootstrap side list, the final task state, the next observation, the PD targets, the pool cursors and
     the device counters are BIT-identical (integer, float32 and float64 alike), for full and ragged tiles, with the
-    actor's input normalisation on, two rollouts in a row (the second continues the replay row and the pools)."""
+    actor's input normalisation on, two rollouts in a row (the second continues the replay row and the pools), and for
+    20 contact slots (a second, on-demand pass over the slots) and 5 (fewer slots than lanes)."""
     from olympic_hip.ppo import MLPCritic, MLPGaussianActor
     torch.manual_seed(5)
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
@@ -276,7 +282,7 @@ def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K):
     pi.obs_std = (1.0 + 0.2 * torch.rand(41, generator=g)).cuda()
     out = []
     for persistent in (False, True):
-        env = _make_env(N, K, seed=3, p_bad=0.03)
+        env = _make_env(N, K, seed=3, p_bad=0.03, C=C)
         snaps = []
         for it in range(2):
             torch.manual_seed(11 + it)                            # the action noise block
