@@ -67,16 +67,21 @@ __global__ __launch_bounds__(64) void stats_finish_kernel(int nblocks, long n,
 // st: [parts][3] (count, sum, sumsq) triples, one per rank; combined by a balanced pairwise tree
 // in rank order ((r0 + r1) + (r2 + r3)) + ... : the same on every rank, and equal to what one rank
 // holding all shards as aligned sub-trees would form.
+// Lane i of a wave holds part i (zero beyond `parts`): `v += shfl_down(v, h)` for h = 1, 2, 4, ... leaves exactly that
+// tree in lane 0 (the zero padding adds exact zeros); every wave computes it for itself.  (An indexed local array of
+// OLY_MAX_STAT_PARTS doubles went to scratch memory: 528 B per lane for a kernel of 28 registers.)
+static_assert(OLY_MAX_STAT_PARTS <= 64, "one wave holds all parts");
 __device__ __forceinline__ void combine_parts(const double* __restrict__ st, int parts, double out[3]) {
-  double a[OLY_MAX_STAT_PARTS];
-#pragma unroll 1
+  const int lane = threadIdx.x & 63;
+#pragma unroll
   for (int k = 0; k < 3; ++k) {
-    int m = 1;
-    while (m < parts) m <<= 1;
-    for (int i = 0; i < m; ++i) a[i] = (i < parts) ? st[3 * i + k] : 0.0;
-    for (int h = 1; h < m; h <<= 1)
-      for (int i = 0; i + h < m; i += 2 * h) a[i] += a[i + h];
-    out[k] = a[0];
+    double v = lane < parts ? st[3 * lane + k] : 0.0;
+#pragma unroll
+    for (int h = 1; h < 64; h <<= 1) {
+      const double o = __shfl_down(v, h, 64);
+      if ((lane & (2 * h - 1)) == 0) v += o;
+    }
+    out[k] = __shfl(v, 0, 64);
   }
 }
 
