@@ -28,7 +28,15 @@
 //   d    = (chain_{k<64}(z_k wd_k) + chain_{64<=k<128}(z_k wd_k)) + bd
 //   r    = -f32(log(f64(1 - 1/(1 + f32(exp(f64(-d)))) + 1e-8)))     float32 steps as numpy takes them, each
 //          transcendental correctly rounded through fp64 (one per sample: free next to 148 kFLOP)
+#include <cstdlib>
+
+#include "mlp_tiles.h"
 #include "oly_common.h"
+
+using oly_mlp::act16_index;
+using oly_mlp::f32x4;
+using oly_mlp::layer_tiles16;
+using oly_mlp::store_relu16;
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,8 +50,13 @@ constexpr int THREADS = 256;     // 4 waves: one per SIMD; two workgroups per CU
 
 struct DiscLayout {
   int in_dim, g1;                // g1: groups of four k-steps (8 k values) in layer 1: 4 (in <= 32) or 8
-  size_t w0, b0, w1, b1, wmu, bmu, wlv, blv, wd, bd, total;
+  size_t w0, b0, w1, b1, wmu, bmu, wlv, blv, wd, bd;
+  // the same matrices as 16-column-tile streams (mlp_tiles.h: P16[tile][group of 16 k][lane][4]) for the 16-row
+  // kernel that small batches take
+  size_t w0n, w1n, wmun, wlvn;
+  size_t total;
 };
+constexpr int G1N16 = MAX_IN / 16;   // 16-wide layout, layer 1: 4 groups of 16 k (zero beyond in_dim)
 
 __host__ __device__ inline DiscLayout disc_layout(int in_dim) {
   DiscLayout L;
@@ -59,8 +72,20 @@ __host__ __device__ inline DiscLayout disc_layout(int in_dim) {
   L.blv = L.wlv + (size_t)(ZD / 32) * (H2 / 8) * 256;
   L.wd = L.blv + ZD;
   L.bd = L.wd + ZD;
-  L.total = L.bd + 4;
+  L.w0n = L.bd + 4;
+  L.w1n = L.w0n + (size_t)(H1 / 16) * G1N16 * 256;
+  L.wmun = L.w1n + (size_t)(H2 / 16) * (H1 / 16) * 256;
+  L.wlvn = L.wmun + (size_t)(ZD / 16) * (H2 / 16) * 256;
+  L.total = L.wlvn + (size_t)(ZD / 16) * (H2 / 16) * 256;
   return L;
+}
+
+// P16[tile][group g][lane][q] = W[n = 16 tile + (lane & 15)][k = 16 g + 4 q + (lane >> 4)]     (0 beyond K)
+__device__ __forceinline__ float packed_weight16(const float* __restrict__ W, int K, int groups, size_t r) {
+  const int q = r & 3, lane = (r >> 2) & 63;
+  const int g = (int)((r >> 8) % groups), tile = (int)((r >> 8) / groups);
+  const int k = 16 * g + 4 * q + (lane >> 4), n = 16 * tile + (lane & 15);
+  return k < K ? W[(size_t)n * K + k] : 0.f;
 }
 
 // B operand of v_mfma_f32_32x32x2_f32: lane l holds B[k = l >> 5][n = l & 31].  One 16-byte load per lane feeds
@@ -90,7 +115,11 @@ __global__ void disc_pack_kernel(DiscLayout L, const float* __restrict__ W0, con
     else if (e < L.blv) v = packed_weight(Wlv, H2, H2 / 8, e - L.wlv);
     else if (e < L.wd) v = Blv[e - L.blv];
     else if (e < L.bd) v = Wd[e - L.wd];
-    else v = (e == L.bd) ? Bd[0] : 0.f;
+    else if (e < L.w0n) v = (e == L.bd) ? Bd[0] : 0.f;
+    else if (e < L.w1n) v = packed_weight16(W0, L.in_dim, G1N16, e - L.w0n);
+    else if (e < L.wmun) v = packed_weight16(W1, H1, H1 / 16, e - L.w1n);
+    else if (e < L.wlvn) v = packed_weight16(Wmu, H2, H2 / 16, e - L.wmun);
+    else v = packed_weight16(Wlv, H2, H2 / 16, e - L.wlvn);
     out[e] = v;
   }
 }
@@ -327,6 +356,157 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward_kernel(DiscArgs p) {
   }
 }
 
+// The same chain for 16 samples per workgroup on v_mfma_f32_16x16x4_f32: twice as many tiles, half the matrix work per
+// tile.  A batch of 4096 (the size of one discriminator fit) is 128 of the 32-row tiles on 256 CUs: half the chip idle
+// and 7.7 us of dependent MFMAs per tile; as 256 tiles of 16 rows every CU works and a tile's chain is 3.8 us.  Same
+// arithmetic, value for value (k-ascending fma chains; the 16-row instruction is the same chain): both kernels are
+// bit-exact against the one oracle.  G1: groups of 16 inputs in layer 1 (2: in <= 32, 4: in <= 64).
+constexpr int RT16 = 16;
+template <int G1>
+__global__ __launch_bounds__(THREADS, 2) void disc_forward16_kernel(DiscArgs p) {
+  constexpr int KIN = 16 * G1;               // zero-padded input width
+  constexpr int XPT = KIN * RT16 / THREADS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xT = lds;                           // [MAX_IN x 16]  standardised input image (act16 layout)
+  float* hA = xT + MAX_IN * RT16;            // [H1 x 16]      layer-1 image; later z ([ZD x 16])
+  float* hB = hA + H1 * RT16;                // [H2 x 16]      layer-2 image
+  float* wd = hB + H2 * RT16;                // [ZD + 4]       decoder row + bias
+  double* st = reinterpret_cast<double*>(wd + ZD + 4);   // [2][MAX_IN]  mean, std of the standardiser
+  const DiscLayout L = disc_layout(p.D);
+  const float* Pbase = p.packed;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, h2 = lane >> 4;
+
+  if (tid < ZD + 4) wd[tid] = Pbase[L.wd + tid];
+  const bool standardise = p.mean || p.colstats;
+  if (tid < p.D && standardise) {
+    double mean, sd;
+    if (p.colstats) {
+      const double cnt = p.colstats[tid] + 1e-2;       // Standardizer.update_mean_std (networks.py:76-81)
+      mean = p.colstats[p.D + tid] / cnt;
+      sd = sqrt(fmax((p.colstats[2 * p.D + tid] + 1e-2) / cnt - mean * mean, 1e-2));
+    } else {
+      mean = p.mean[tid];
+      sd = p.sd[tid];
+    }
+    st[tid] = mean;
+    st[MAX_IN + tid] = sd;
+  }
+  __syncthreads();
+
+  float xr[XPT];
+  auto load_x = [&](long tile) {
+    const long row0 = tile * RT16;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int e = tid + THREADS * i, m = e / KIN, k = e - m * KIN;
+      float v = 0.f;
+      if (row0 + m < p.B && k < p.D) v = p.x[(size_t)(row0 + m) * p.Dx + (p.mask ? p.mask[k] : k)];
+      xr[i] = v;
+    }
+  };
+  auto stage_x = [&](long tile) {
+    const long row0 = tile * RT16;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int e = tid + THREADS * i, m = e / KIN, k = e - m * KIN;
+      float v = xr[i];
+      if (standardise && row0 + m < p.B && k < p.D) v = (float)(((double)v - st[k]) / st[MAX_IN + k]);
+      xT[act16_index(k, m)] = v;
+    }
+  };
+
+  long tile = blockIdx.x;
+  if (tile < p.ntiles) {
+    load_x(tile);
+    stage_x(tile);
+  }
+  __syncthreads();
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const long row0 = tile * RT16;
+    const long next = tile + gridDim.x;
+    int opaque0 = 0;                          // (see disc_forward_kernel: keeps the weight loads inside the tile loop)
+    asm volatile("" : "+s"(opaque0));
+    const float* P = Pbase + opaque0;
+    const float4* P4 = reinterpret_cast<const float4*>(P);
+    {  // ---- layer 1: [16, in] x [in, 256]; wave w owns column tiles 4 w .. 4 w + 3
+      f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+      const float4* base = P4 + (L.w0n >> 2) + (size_t)(4 * wave) * G1N16 * 64;
+      const float4* const w[4] = {base, base + G1N16 * 64, base + 2 * G1N16 * 64, base + 3 * G1N16 * 64};
+      layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xT), w, lane, acc);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store_relu16(acc[t], P + L.b0, 4 * wave + t, lane, hA);
+    }
+    __syncthreads();
+    {  // ---- layer 2: [16, 256] x [256, 128]; wave w owns column tiles 2 w, 2 w + 1
+      f32x4 acc[2] = {{0}, {0}};
+      const float4* base = P4 + (L.w1n >> 2) + (size_t)(2 * wave) * (H1 / 16) * 64;
+      const float4* const w[2] = {base, base + (H1 / 16) * 64};
+      layer_tiles16<H1 / 16, 2>(reinterpret_cast<const float4*>(hA), w, lane, acc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) store_relu16(acc[t], P + L.b1, 2 * wave + t, lane, hB);
+    }
+    if (next < p.ntiles) load_x(next);       // in flight behind layer 3
+    // the reparameterisation noise of this wave's columns (tiles 2 w, 2 w + 1; rows 4 h2 .. 4 h2 + 3)
+    float ev[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long row = row0 + 4 * h2 + i;
+        ev[t][i] = (p.eps && row < p.B) ? p.eps[(size_t)row * ZD + 16 * (2 * wave + t) + c] : 0.f;
+      }
+    __syncthreads();
+    {  // ---- mu and logvar: [16, 128] x [128, 128] each; wave w owns column tiles 2 w, 2 w + 1 of BOTH
+      f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+      const float4* bm = P4 + (L.wmun >> 2) + (size_t)(2 * wave) * (H2 / 16) * 64;
+      const float4* bl = P4 + (L.wlvn >> 2) + (size_t)(2 * wave) * (H2 / 16) * 64;
+      const float4* const w[4] = {bm, bm + (H2 / 16) * 64, bl, bl + (H2 / 16) * 64};
+      layer_tiles16<H2 / 16, 4>(reinterpret_cast<const float4*>(hB), w, lane, acc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int col = 16 * (2 * wave + t) + c;
+        const float bmu = P[L.bmu + col], blv = P[L.blv + col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 4 * h2 + i;
+          const float mu = acc[t][i] + bmu, lv = acc[2 + t][i] + blv;
+          float z = mu;
+          if (p.eps) z = mu + exp32(lv / 2.0f) * ev[t][i];
+          hA[act16_index(col, m)] = z;
+          if (row0 + m < p.B) {
+            if (p.mu) p.mu[(size_t)(row0 + m) * ZD + col] = mu;
+            if (p.logvar) p.logvar[(size_t)(row0 + m) * ZD + col] = lv;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {  // ---- decoder + reward: lane (row = lane & 15, half = (lane >> 4) & 1) runs k in [64 half, 64 half + 64)
+      const int r = lane & 15, half = (lane >> 4) & 1;
+      float s = 0.f;
+#pragma unroll 16
+      for (int k = 0; k < 64; ++k) s = fmaf(hA[act16_index(64 * half + k, r)], wd[64 * half + k], s);
+      const float o = __shfl_xor(s, 16, 64);
+      if (lane < 16 && row0 + r < p.B) {
+        const float d = (s + o) + wd[ZD];
+        if (p.logits) p.logits[row0 + r] = d;
+        if (p.reward) {
+          const float e = (float)exp(-(double)d);
+          const float pr = 1.0f / (1.0f + e);
+          const float q = 1.0f - pr + 1e-8f;
+          p.reward[row0 + r] = -(float)log((double)q);
+        }
+      }
+    }
+    if (next < p.ntiles) stage_x(next);      // xT was consumed by layer 1; z (hA) is read by wave 0 only
+    __syncthreads();
+  }
+}
+
+constexpr size_t DISC16_LDS = sizeof(float) * ((MAX_IN + H1 + H2) * RT16 + ZD + 4) + sizeof(double) * 2 * MAX_IN;
+static_assert(((MAX_IN + H1 + H2) * RT16 + ZD + 4) % 2 == 0, "the fp64 statistics must be 8-byte aligned");
+
 constexpr size_t DISC_LDS = sizeof(float) * ((MAX_IN + H1 + H2) * LDP + ZD + 4) + sizeof(double) * 2 * MAX_IN;
 static_assert(((MAX_IN + H1 + H2) * LDP + ZD + 4) % 2 == 0, "the fp64 statistics must be 8-byte aligned");
 
@@ -369,9 +549,18 @@ extern "C" int oly_disc_forward(oly_ctx* ctx, int64_t B, int Dx, int D, const fl
   if (B == 0) return OLY_OK;
   if (!x || !packed || (!reward && !logits && !mu && !logvar)) OLY_FAIL(ctx, OLY_EINVAL, "oly_disc_forward: NULL input or no output");
   if ((reinterpret_cast<uintptr_t>(packed) & 15) != 0) OLY_FAIL(ctx, OLY_EINVAL, "oly_disc_forward: packed must be 16-byte aligned");
-  const long ntiles = (B + RT - 1) / RT;
+  long ntiles = (B + RT - 1) / RT;
   if (ntiles > 0x7fffffffL) OLY_FAIL(ctx, OLY_ERANGE, "oly_disc_forward: B too large");
+  const long slots = 2L * (ctx->num_cu > 0 ? ctx->num_cu : 256);      // two resident workgroups per CU
+  // small batches: 16-row tiles fill the chip (OLY_K12_ROWS = 16 / 32 forces either kernel, for the tests)
+  static const int force_rows = [] { const char* e = getenv("OLY_K12_ROWS"); return e ? atoi(e) : 0; }();
+  const bool rows16 = force_rows == 16 || (force_rows != 32 && ntiles < slots);
+  if (rows16) ntiles = (B + RT16 - 1) / RT16;
   if (!ctx->disc_attr_done) {
+    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(disc_forward16_kernel<2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)DISC16_LDS));
+    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(disc_forward16_kernel<4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)DISC16_LDS));
     OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(disc_forward_kernel<4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DISC_LDS));
     OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(disc_forward_kernel<8>),
@@ -379,9 +568,10 @@ extern "C" int oly_disc_forward(oly_ctx* ctx, int64_t B, int Dx, int D, const fl
     ctx->disc_attr_done = true;
   }
   DiscArgs a{(long)B, Dx, D, (int)ntiles, x, mask, mean, sd, colstats, packed, eps, reward, logits, mu, logvar};
-  const long slots = 2L * (ctx->num_cu > 0 ? ctx->num_cu : 256);      // two resident workgroups per CU
   const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
-  if (D <= 32) hipLaunchKernelGGL(disc_forward_kernel<4>, grid, dim3(THREADS), DISC_LDS, oly_s(stream), a);
+  if (rows16 && D <= 32) hipLaunchKernelGGL(disc_forward16_kernel<2>, grid, dim3(THREADS), DISC16_LDS, oly_s(stream), a);
+  else if (rows16) hipLaunchKernelGGL(disc_forward16_kernel<4>, grid, dim3(THREADS), DISC16_LDS, oly_s(stream), a);
+  else if (D <= 32) hipLaunchKernelGGL(disc_forward_kernel<4>, grid, dim3(THREADS), DISC_LDS, oly_s(stream), a);
   else hipLaunchKernelGGL(disc_forward_kernel<8>, grid, dim3(THREADS), DISC_LDS, oly_s(stream), a);
   OLY_LAUNCH_CHECK(ctx, "disc_forward_kernel");
   return OLY_OK;

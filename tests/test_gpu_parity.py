@@ -586,6 +586,20 @@ def test_disc_forward_full_size_properties(eng, oracle):
     assert np.array_equal(ref["logits"], d[idx]) and np.array_equal(ref["reward"], r[idx])
 
 
+@pytest.mark.parametrize("rows", [16, 32])
+def test_disc_forward_both_tile_heights_on_every_case(rows):
+    """oly_disc_forward picks 16-row tiles (v_mfma_f32_16x16x4_f32, 256 tiles for a batch of 4096) for small batches
+    and 32-row tiles (v_mfma_f32_32x32x2_f32) for large ones; OLY_K12_ROWS forces one kernel onto every K12 test of
+    this file (the knob is read once per process, hence the child): both are bit-exact against the same oracle."""
+    import subprocess
+    import sys
+    env = dict(os.environ, OLY_K12_ROWS=str(rows))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "disc_forward and not both_tile_heights", "-p", "no:cacheprovider"], capture_output=True,
+                         text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_discriminator_reward_fused_matches_layer_by_layer(eng, golden):
     """gail.DiscriminatorReward: the fused launch against the PyTorch-GEMM path it replaces (summation order
     of the Linear layers is the only difference), with the running statistics updated once per call by both,
