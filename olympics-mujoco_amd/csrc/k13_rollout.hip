@@ -108,6 +108,14 @@ static_assert(sizeof(float) * KSPLIT * EPW * PPITCH <= sizeof(float) * HID * EPW
 static_assert((sizeof(float) * MAX_IN * EPW) % 16 == 0 && (sizeof(float) * (MAX_IN + 2 * HID) * EPW) % 8 == 0,
               "image / fp64 regions must stay aligned");
 
+// An environment's 16 lanes sit in ONE wave, and a wave's LDS operations complete in order: rows that only the
+// environment's own lanes write and read need a compiler / memory-model fence, not a workgroup barrier.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // the readback row of one step as the environment's 16 lanes hold it between the request and its use
 struct Readback {
   int nc_raw, g1_0, g2_0;
@@ -429,8 +437,11 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
       request(k0 + (t + 1 - t0), n_t, slot_t, rb);
       if (actor && o_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + tid_t];
     }
-    __syncthreads();
-    if (skip & 16) continue;
+    wave_lds_fence();       // the staged rows are read back by the lanes of the environment that wrote them
+    if (skip & 16) {
+      __syncthreads();
+      continue;
+    }
 
     // ---- level 1: everything without libm
     const double rq0 = se[L_RQ], rq1 = se[L_RQ + 1], rq2 = se[L_RQ + 2], rq3 = se[L_RQ + 3];
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
       if (slot == 8) op[8 + 2 * nu] = (float)se[L_R1 + 2 * 13 + 1];
       if (slot >= 8) op[9 + 2 * nu + slot - 8] = (float)goal[slot - 8];
     }
-    __syncthreads();
+    wave_lds_fence();       // the observation row of an environment is assembled and re-read by its own lanes
     if (env_ok) {
       for (int c = slot; c < n_obs; c += SLOTS) {
         float v = op[c];
