@@ -23,6 +23,11 @@
 // a cross-CU hand-off costs 1-3 us per step (MI355X_MICROARCH.md price list), the replayed step needs no
 // synchronisation at all.  Only one workgroup of a pair stores any given array: the actor one the actions, rewards,
 // flags, bootstrap rows and the final task state, the critic one the stored observations and the values.
+// The two workgroups of a tile are NOT guaranteed to run at the same time (a grid larger than the chip holds, e.g.
+// 20007 environments, dispatches the critic workgroups after actor workgroups have finished), and the actor one ends by
+// overwriting the task state both started from.  So the inputs a step loop starts from (task state, step sequences,
+// cursors, the first observation, the counters) are copied by a small launch into caller-provided scratch first, and
+// both workgroups read THAT: nothing a workgroup reads is written by anyone during the launch.
 //
 // Per step the only global traffic on the critical path is the weight stream (L2 hits).  Readback rows and the
 // noise row of step t + 1 are requested right after step t's own rows were consumed, i.e. a whole libm phase and a
@@ -81,6 +86,57 @@ enum {
   L_ENV = 125
 };
 
+// Device copy of everything the rollout kernel reads AND (at its end) overwrites.  Laid out in the caller's scratch
+// buffer (oly_a3_rollout_scratch_bytes): SoA, 8-byte-aligned segments.
+struct Snapshot {
+  const int32_t *phase, *t1, *t2, *frames, *mode, *seq_len, *traj_len, *pool_count, *side_count, *ctr;
+  const uint8_t* target_reached;
+  const double *goal, *sequence;
+  const float* state;
+};
+
+__host__ __device__ inline size_t snap_align(size_t x) { return (x + 15) & ~(size_t)15; }
+struct SnapLayout {
+  size_t ints, ctr, reached, goal, sequence, state, total;      // byte offsets
+};
+__host__ __device__ inline SnapLayout snap_layout(int N, int n_obs) {
+  SnapLayout L;
+  L.ints = 0;                                                  // 9 arrays of N int32
+  L.ctr = snap_align(L.ints + sizeof(int32_t) * 9 * (size_t)N);
+  L.reached = snap_align(L.ctr + sizeof(int32_t) * (2 * (((size_t)N + 15) / 16) + 2));
+  L.goal = snap_align(L.reached + (size_t)N);
+  L.sequence = snap_align(L.goal + sizeof(double) * 8 * (size_t)N);
+  L.state = snap_align(L.sequence + sizeof(double) * SEQW * (size_t)N);
+  L.total = snap_align(L.state + sizeof(float) * (size_t)n_obs * N);
+  return L;
+}
+
+struct SnapArgs {
+  int N, n_obs;
+  oly_a3_state st;
+  oly_a3_rollout ro;
+  unsigned char* scratch;
+};
+
+__global__ __launch_bounds__(256) void a3_rollout_snapshot_kernel(SnapArgs a) {
+  const SnapLayout L = snap_layout(a.N, a.n_obs);
+  const long stride = (long)gridDim.x * blockDim.x, gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t* ints = reinterpret_cast<int32_t*>(a.scratch + L.ints);
+  const int32_t* src[9] = {a.st.phase, a.st.t1, a.st.t2, a.st.reached_frames, a.st.mode, a.st.seq_len, a.ro.traj_len,
+                           a.ro.pool_count, a.ro.side_count};
+  for (long i = gid; i < (long)a.N; i += stride) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ints[(size_t)k * a.N + i] = src[k][i];
+    (a.scratch + L.reached)[i] = a.st.target_reached[i];
+  }
+  const long nctr = 2 * (((long)a.N + 15) / 16) + 2;
+  for (long i = gid; i < nctr; i += stride) reinterpret_cast<int32_t*>(a.scratch + L.ctr)[i] = a.ro.ctr[i];
+  for (long i = gid; i < 8L * a.N; i += stride) reinterpret_cast<double*>(a.scratch + L.goal)[i] = a.st.goal[i];
+  for (long i = gid; i < (long)SEQW * a.N; i += stride)
+    reinterpret_cast<double*>(a.scratch + L.sequence)[i] = a.st.sequence[i];
+  for (long i = gid; i < (long)a.n_obs * a.N; i += stride) reinterpret_cast<float*>(a.scratch + L.state)[i] = a.ro.state[i];
+}
+
 struct RollArgs {
   const A3Dev* md;
   ContactDev cd;
@@ -92,6 +148,7 @@ struct RollArgs {
   int out_dim[2], normalize[2];
   float* mu_out;       // [N,nu] mean of the LAST forward (what ro.mu holds after the two-kernel loop), or NULL
   float* value_out;    // [N]    value of the last forward, or NULL
+  Snapshot in;         // the launch's inputs (see a3_rollout_snapshot_kernel): read here, never written
   int skip;            // diagnostic (OLY_K13_SKIP, tools/time_k13.py): bit 0 no MFMA layers, bit 1 no environment step;
                        // bits 4..7 leave the environment step early: after the contacts / level 1 / round 1 / round 2
 };
@@ -157,8 +214,8 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
   const PackLayout L = pack_layout(p.in_dim, out_dim);
   const float* __restrict__ Pbase = p.packed[net];
   // K10's private (t, k) pair of this 16-environment group
-  const int t0 = p.ro.ctr[2 * blockIdx.x];
-  const int k0 = p.ro.ctr[2 * blockIdx.x + 1];
+  const int t0 = p.in.ctr[2 * blockIdx.x];
+  const int k0 = p.in.ctr[2 * blockIdx.x + 1];
   if (t0 < 0 || t0 > T) {     // counters the caller never rewound: K10's rule (no write, sticky mark behind the counters)
     if (threadIdx.x == 0) p.ro.ctr[2 * ((N + 15) / 16)] = 1;
     return;
@@ -173,19 +230,19 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
   int reached_last = 0;
   double goal_last = 0.0;
   if (env_ok) {
-    phase0 = p.st.phase[n];
-    t1 = p.st.t1[n];
-    t2 = p.st.t2[n];
-    frames = p.st.reached_frames[n];
-    reached_last = p.st.target_reached[n];
-    mode = p.st.mode[n];
-    seq_len = p.st.seq_len[n];
-    tlen = p.ro.traj_len[n];
-    rc = p.ro.pool_count[n];
-    sc = p.ro.side_count[n];
-    if (slot < 8) goal_last = p.st.goal[8 * (size_t)n + slot];
+    phase0 = p.in.phase[n];
+    t1 = p.in.t1[n];
+    t2 = p.in.t2[n];
+    frames = p.in.frames[n];
+    reached_last = p.in.target_reached[n];
+    mode = p.in.mode[n];
+    seq_len = p.in.seq_len[n];
+    tlen = p.in.traj_len[n];
+    rc = p.in.pool_count[n];
+    sc = p.in.side_count[n];
+    if (slot < 8) goal_last = p.in.goal[8 * (size_t)n + slot];
 #pragma unroll
-    for (int q = 0; q < SEQW / SLOTS; ++q) sq[slot + SLOTS * q] = p.st.sequence[(size_t)n * SEQW + slot + SLOTS * q];
+    for (int q = 0; q < SEQW / SLOTS; ++q) sq[slot + SLOTS * q] = p.in.sequence[(size_t)n * SEQW + slot + SLOTS * q];
   }
   t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
   t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
@@ -196,7 +253,7 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
   const double gear_s = slot < nu ? m->gear[slot] : 1.0;
   for (int e = tid; e < rows * n_obs; e += THREADS) {
     const int r = e / n_obs, c = e - r * n_obs;
-    s_post[r * OBP + c] = p.ro.state[(size_t)row0 * n_obs + e];
+    s_post[r * OBP + c] = p.in.state[(size_t)row0 * n_obs + e];
   }
 
   // per-thread constants of the dense sweeps (the element a thread owns does not change from step to step)
@@ -785,10 +842,16 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
 }
 }  // namespace
 
+extern "C" int64_t oly_a3_rollout_scratch_bytes(int N, int n_obs) {
+  if (N <= 0 || n_obs <= 0) return 0;
+  return (int64_t)snap_layout(N, n_obs).total;
+}
+
 extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_blocks* blocks, const oly_a3_state* st,
                                          const oly_a3_rollout* ro, int in_dim, const float* packed_actor,
                                          int normalize_actor, const float* packed_critic, int normalize_critic,
-                                         float* mu_out, float* value_out, oly_stream stream) {
+                                         float* mu_out, float* value_out, void* scratch, int64_t scratch_bytes,
+                                         oly_stream stream) {
   if (!ctx) return OLY_EINVAL;
   if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_rollout_persistent before oly_a3_configure");
   if (!ctx->contact_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_rollout_persistent before oly_contact_configure");
@@ -814,6 +877,10 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
              ctx->a3_host.n_obs);
   if (((reinterpret_cast<uintptr_t>(packed_actor) | reinterpret_cast<uintptr_t>(packed_critic)) & 15) != 0)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: packed weights must be 16-byte aligned");
+  const SnapLayout SL = snap_layout(N, in_dim);
+  if (!scratch || scratch_bytes < (int64_t)SL.total || (reinterpret_cast<uintptr_t>(scratch) & 15) != 0)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: scratch must be 16-byte aligned and hold %zu bytes "
+             "(oly_a3_rollout_scratch_bytes)", SL.total);
   if (!ctx->roll_attr_done) {
     OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel<3>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROLL_LDS));
@@ -837,6 +904,23 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
   a.normalize[1] = normalize_critic;
   a.mu_out = mu_out;
   a.value_out = value_out;
+  {  // the inputs the step loops start from, copied aside: both workgroups of a tile read these, whenever they run
+    SnapArgs sa{N, in_dim, *st, *ro, static_cast<unsigned char*>(scratch)};
+    long nb = ((long)N * SEQW + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(a3_rollout_snapshot_kernel, dim3((unsigned)nb), dim3(256), 0, oly_s(stream), sa);
+    unsigned char* sc8 = static_cast<unsigned char*>(scratch);
+    const int32_t* ints = reinterpret_cast<const int32_t*>(sc8 + SL.ints);
+    a.in.phase = ints;                     a.in.t1 = ints + (size_t)N;          a.in.t2 = ints + 2 * (size_t)N;
+    a.in.frames = ints + 3 * (size_t)N;    a.in.mode = ints + 4 * (size_t)N;    a.in.seq_len = ints + 5 * (size_t)N;
+    a.in.traj_len = ints + 6 * (size_t)N;  a.in.pool_count = ints + 7 * (size_t)N;
+    a.in.side_count = ints + 8 * (size_t)N;
+    a.in.ctr = reinterpret_cast<const int32_t*>(sc8 + SL.ctr);
+    a.in.target_reached = sc8 + SL.reached;
+    a.in.goal = reinterpret_cast<const double*>(sc8 + SL.goal);
+    a.in.sequence = reinterpret_cast<const double*>(sc8 + SL.sequence);
+    a.in.state = reinterpret_cast<const float*>(sc8 + SL.state);
+  }
   static const int skip = [] { const char* e = getenv("OLY_K13_SKIP"); return e ? atoi(e) : 0; }();
   a.skip = skip;
   const dim3 grid((N + EPW - 1) / EPW, 2);
