@@ -281,6 +281,10 @@ def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K, C)
     g = torch.Generator().manual_seed(1)
     pi.obs_mean = (0.1 * torch.randn(41, generator=g)).cuda()
     pi.obs_std = (1.0 + 0.2 * torch.rand(41, generator=g)).cuda()
+    if N % 2:              # the critic's input normalisation too (critic.py:63-64 applies it in eval mode only)
+        vf.obs_mean = (0.05 * torch.randn(41, generator=g)).cuda()
+        vf.obs_std = (1.0 + 0.1 * torch.rand(41, generator=g)).cuda()
+        vf.eval()
     out = []
     for persistent in (False, True):
         env = _make_env(N, K, seed=3, p_bad=0.03, C=C)
@@ -302,6 +306,7 @@ def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K, C)
         assert ia == ib and ka == kb
     last = (out[1][0][0]["flags"] & _abi.FLAG_LAST).bool()
     assert bool(last[-1].all()) and (N < 32 or int(last[:-1].sum()) > 0), "the case must exercise device-side resets"
+    assert env._dev_rollout._fw.norm_c == bool(N % 2)
 
 
 def test_a_step_past_the_last_row_writes_nothing_and_is_reported(eng, golden, oracle):
