@@ -83,7 +83,18 @@ enum {
   L_AVL = 45,    // act_vel 16
   L_R1 = 61,     // round-1 results [16][2]
   L_R2 = 93,     // round-2 results [16][2]
-  L_ENV = 125
+  L_GR = 125,    // contact reduction: grf_r, grf_l, min_z
+  L_GL = 126,
+  L_MZ = 127,
+  L_ROT = 128,   // root rotation matrix R[3][3] (level-1 task 1 -> round 2 / goal steps)
+  L_ENV = 137
+};
+// per-environment ints in LDS: what the level-1 tasks read (written by the environment's own lanes) and what they
+// hand back
+enum {
+  I_PHASE0 = 0, I_T1, I_T2, I_FRAMES, I_MODE, I_SEQLEN, I_TLEN, I_RC, I_BAD, I_HAVEC,           // inputs
+  O_PHASE, O_T1, O_T2, O_FRAMES, O_REACHED, O_DONE, O_CUT, O_RESET, O_NEWMODE, O_NEWPHASE, O_NEWLEN,   // outputs
+  SI_N = 24
 };
 
 // Device copy of everything the rollout kernel reads AND (at its end) overwrites.  Laid out in the caller's scratch
@@ -149,8 +160,7 @@ struct RollArgs {
   float* mu_out;       // [N,nu] mean of the LAST forward (what ro.mu holds after the two-kernel loop), or NULL
   float* value_out;    // [N]    value of the last forward, or NULL
   Snapshot in;         // the launch's inputs (see a3_rollout_snapshot_kernel): read here, never written
-  int skip;            // diagnostic (OLY_K13_SKIP, tools/time_k13.py): bit 0 no MFMA layers, bit 1 no environment step;
-                       // bits 4..7 leave the environment step early: after the contacts / level 1 / round 1 / round 2
+  int skip;            // diagnostic (OLY_K13_SKIP, tools/time_k13.py): bit 0 no MFMA layers, bit 1 no environment step
 };
 
 // LDS: input image | layer-1 image | layer-2 image (the environment scratch and the output layer's partial tiles
@@ -159,7 +169,8 @@ constexpr int GEOM_LDS = 1024;          // geom -> body table kept in LDS up to 
 constexpr size_t ROLL_LDS = sizeof(float) * (MAX_IN + 2 * HID) * EPW + sizeof(double) * EPW * SEQW +
                             sizeof(float) * 2 * EPW * OBP + sizeof(double) * 4 * OLY_MAX_PERIOD + sizeof(int) * GEOM_LDS;
 static_assert((sizeof(float) * 2 * EPW * OBP) % 8 == 0, "the clock table must stay 8-byte aligned");
-static_assert(sizeof(double) * (EPW * L_ENV + EPW * SLOTS * 2) + EPW * SLOTS <= sizeof(float) * 2 * HID * EPW,
+static_assert(sizeof(double) * (EPW * L_ENV + EPW * SLOTS * 2) + EPW * SLOTS + sizeof(int) * EPW * SI_N <=
+                  sizeof(float) * 2 * HID * EPW,
               "the environment scratch must fit in the activation images it aliases");
 static_assert(sizeof(float) * KSPLIT * EPW * PPITCH <= sizeof(float) * HID * EPW, "partial tiles alias the layer-1 image");
 static_assert((sizeof(float) * MAX_IN * EPW) % 16 == 0 && (sizeof(float) * (MAX_IN + 2 * HID) * EPW) % 8 == 0,
@@ -188,6 +199,7 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
   double* s_env = reinterpret_cast<double*>(hA);                // [EPW][L_ENV]    (environment phase)
   double* s_arg = s_env + EPW * L_ENV;                          // [EPW][SLOTS][2]
   uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_arg + EPW * SLOTS * 2);   // [EPW][SLOTS]
+  int* s_int = reinterpret_cast<int*>(s_cls + EPW * SLOTS);               // [EPW][SI_N]
   double* seqs = reinterpret_cast<double*>(hB + HID * EPW);     // [EPW][SEQW]     step sequences, whole rollout
   float* s_pre = reinterpret_cast<float*>(seqs + EPW * SEQW);   // [EPW][OBP]      observation before a reset
   float* s_post = s_pre + EPW * OBP;                            // [EPW][OBP]      observation the policy sees next
@@ -494,153 +506,158 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
       request(k0 + (t + 1 - t0), n_t, slot_t, rb);
       if (actor && o_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + tid_t];
     }
-    wave_lds_fence();       // the staged rows are read back by the lanes of the environment that wrote them
-    if (skip & 16) {
-      __syncthreads();
-      continue;
+    // what the level-1 tasks need from this environment's lanes
+    if (env_ok && slot == 0) {
+      int* si = s_int + el * SI_N;
+      si[I_PHASE0] = phase0; si[I_T1] = t1; si[I_T2] = t2; si[I_FRAMES] = frames; si[I_MODE] = mode;
+      si[I_SEQLEN] = seq_len; si[I_TLEN] = tlen; si[I_RC] = rc; si[I_BAD] = bad; si[I_HAVEC] = (cnt_r > 0 || cnt_l > 0);
+      se[L_GR] = grf_r; se[L_GL] = grf_l; se[L_MZ] = min_z;
     }
+    __syncthreads();
 
-    // ---- level 1: everything without libm
-    const double rq0 = se[L_RQ], rq1 = se[L_RQ + 1], rq2 = se[L_RQ + 2], rq3 = se[L_RQ + 3];
-    const double rp0 = se[L_RP], rp1 = se[L_RP + 1], rp2 = se[L_RP + 2];
-    const double lf0 = se[L_LF], lf1 = se[L_LF + 1], lf2 = se[L_LF + 2];
-    const double rf0 = se[L_RF], rf1 = se[L_RF + 1], rf2 = se[L_RF + 2];
-
-    // WalkingTask.step (walking_task.py:246-293)
-    int phase = phase0 + 1;
-    if (phase >= period) phase = 0;
-    const double tx = sq[4 * t1], ty = sq[4 * t1 + 1], tz = sq[4 * t1 + 2];
-    const double dl = vnorm3(lf0 - tx, lf1 - ty, lf2 - tz);
-    const double dr = vnorm3(rf0 - tx, rf1 - ty, rf2 - tz);
-    int reached;
-    if (dl < m->target_radius || dr < m->target_radius) {
-      reached = 1;
-      frames += 1;
-    } else {
-      reached = 0;
-      frames = 0;
-    }
-    if (reached && frames >= m->delay_frames) {  // update_target_steps
-      t1 = t2;
-      t2 += 1;
-      if (t2 == seq_len) t2 = seq_len - 1;
-      t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
-      reached = 0;
-      frames = 0;
-    }
-    const int selA = 4 * t1, selB = 4 * t2;   // sequence[t1] / sequence[t2] after the update
-    const double s1x = sq[selA], s1y = sq[selA + 1], s1z = sq[selA + 2], s1w = sq[selA + 3];
-    const double s2x = sq[selB], s2y = sq[selB + 1], s2z = sq[selB + 2], s2w = sq[selB + 3];
-
-    double R[3][3];
-    quat2mat(rq0, rq1, rq2, rq3, R);
-    double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool walking = mode != OLY_MODE_STANDING;
-    if (walking) {
-      const double a0 = s1x - rp0, a1 = s1y - rp1, a2 = s1z - rp2;
-      const double b0 = s2x - rp0, b1 = s2y - rp1, b2 = s2z - rp2;
-      goal[0] = R[0][0] * a0 + R[1][0] * a1 + R[2][0] * a2;
-      goal[2] = R[0][1] * a0 + R[1][1] * a1 + R[2][1] * a2;
-      goal[4] = R[0][2] * a0 + R[1][2] * a1 + R[2][2] * a2;
-      goal[1] = R[0][0] * b0 + R[1][0] * b1 + R[2][0] * b2;
-      goal[3] = R[0][1] * b0 + R[1][1] * b1 + R[2][1] * b2;
-      goal[5] = R[0][2] * b0 + R[1][2] * b1 + R[2][2] * b2;
-    }
-
-    // calc_reward arguments (walking_task.py:74-110, tasks/rewards.py:27-40,65-102,121-126)
-    double c_rfrc, c_rvel, c_lfrc, c_lvel;
-    if (!walking) {
-      c_rfrc = 1.0; c_lfrc = 1.0; c_rvel = -1.0; c_lvel = -1.0;
-    } else {
-      c_rfrc = s_lut[0 * period + phase];
-      c_rvel = s_lut[1 * period + phase];
-      c_lfrc = s_lut[2 * period + phase];
-      c_lvel = s_lut[3 * period + phase];
-    }
-    const double max_frc = m->mass * 9.8 * 0.5;
-    double nl = fmin(grf_l, max_frc) / max_frc;
-    double nr = fmin(grf_r, max_frc) / max_frc;
-    nl *= 2; nl -= 1; nr *= 2; nr -= 1;
-    double vl = fmin(vnorm3(se[L_LV], se[L_LV + 1], se[L_LV + 2]), 0.2) / 0.2;
-    double vr = fmin(vnorm3(se[L_RV], se[L_RV + 1], se[L_RV + 2]), 0.2) / 0.2;
-    vl *= 2; vl -= 1; vr *= 2; vr -= 1;
-    const double contact_point = (cnt_r > 0 || cnt_l > 0) ? min_z : 0.0;
-    double err = fabs((rp2 - contact_point) - m->goal_height_ref);
-    const double deadzone = 0.01 + 0.05 * m->goal_speed_ref;
-    if (err < deadzone) err = 0;
-    const double fd = fmin(vnorm3(lf0 - s1x, lf1 - s1y, lf2 - s1z), vnorm3(rf0 - s1x, rf1 - s1y, rf2 - s1z));
-    const double mpx = (s1x + s2x) / 2, mpy = (s1y + s2y) / 2;
-    const double rx = rp0 - mpx, ry = rp1 - mpy;
-    const double hx = se[L_HP] - rp0, hy = se[L_HP + 1] - rp1;
-    const double hn = sqrt(hx * hx + hy * hy);
-
-    // done (walking_task.py:298-319) and the rollout's cut rule (ppo.py:178,189-196)
-    const double foot_z = fmin(lf2, rf2);
-    const bool done = ((rp2 - foot_z) < 0.6) || bad;
-    const int len = tlen + 1;
-    const bool cut = done || len >= p.ro.max_traj_len || last_step;
-    const bool need_reset = env_ok && cut && !last_step;
-
-    // get_obs: quat2euler(qpos[3:7]) (StickFigureA3.py:160)
-    double Rb[3][3];
-    quat2mat(se[L_BQ], se[L_BQ + 1], se[L_BQ + 2], se[L_BQ + 3], Rb);
-    const double cyb = sqrt(Rb[0][0] * Rb[0][0] + Rb[1][0] * Rb[1][0]);
-    const bool regular = cyb > 4.0 * EPS;
-    const double roll_y = regular ? Rb[2][1] : -Rb[1][2];
-    const double roll_x = regular ? Rb[2][2] : Rb[1][1];
-
-    // env.reset(): the next pool record (mode / phase / local sequence), drawn on the host.  K10 fetches the record
-    // with every step's first loads; a persistent workgroup sees a reset in about one step of ten, so the record is
-    // requested here, where the cut is known: the header is needed by round 1, the rows only after round 2.
-    int new_mode = mode, new_phase = 0, new_len = seq_len;
-    double rec_seq[(OLY_MAX_SEQ + SLOTS - 1) / SLOTS][4];
-#pragma unroll
-    for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q)
-      rec_seq[q][0] = rec_seq[q][1] = rec_seq[q][2] = rec_seq[q][3] = 0.0;
-    if (need_reset) {
-      const oly_a3_reset_record* rec = p.ro.pool + (size_t)n_t * p.ro.pool_depth + (unsigned)rc % (unsigned)p.ro.pool_depth;
-      new_mode = rec->mode;
-      new_phase = rec->phase;
-      new_len = min(max(rec->seq_len, 1), OLY_MAX_SEQ);
-#pragma unroll
-      for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
-        const int r = slot + SLOTS * q;
-        if (r < OLY_MAX_SEQ) {
-          rec_seq[q][0] = rec->seq[r][0]; rec_seq[q][1] = rec->seq[r][1];
-          rec_seq[q][2] = rec->seq[r][2]; rec_seq[q][3] = rec->seq[r][3];
+    // ---- level 1: everything without libm, as FOUR TASKS, one per wave, one LANE per environment.
+    // An environment's 16 lanes used to run this whole block redundantly: ~1100 instructions issued by every wave
+    // (3.3 us of a step).  Issue time depends on the length of a wave's instruction stream, not on how many lanes
+    // are active, so the block is cut by FUNCTION across the workgroup's four waves (as the libm rounds are), each
+    // wave taking all 16 environments on lanes 0..15: ~300 instructions per wave.  Same expressions on the same
+    // inputs: bit-identical.  Each task writes the round-1 arguments of the slots it owns.
+    if (lane < EPW) {
+      const int e = lane;
+      const double* ee_ = s_env + e * L_ENV;
+      const double* esq = seqs + e * SEQW;
+      int* si = s_int + e * SI_N;
+      double* arg = s_arg + e * SLOTS * 2;
+      uint8_t* acl = s_cls + e * SLOTS;
+      auto put = [&](int task, int cls, double a, double b) {
+        arg[2 * task] = a;
+        arg[2 * task + 1] = b;
+        acl[task] = (uint8_t)cls;
+      };
+      const bool live = e < rows;
+      // shared, cheap: done / cut / need_reset (walking_task.py:298-319, ppo.py:178,189-196)
+      const double rp2 = ee_[L_RP + 2];
+      const double foot_z = fmin(ee_[L_LF + 2], ee_[L_RF + 2]);
+      const bool bad_e = si[I_BAD] != 0;
+      const bool done = ((rp2 - foot_z) < 0.6) || bad_e;
+      const int len = si[I_TLEN] + 1;
+      const bool cut = done || len >= p.ro.max_traj_len || last_step;
+      const bool need_reset = live && cut && !last_step;
+      const int mode_e = si[I_MODE];
+      const bool walking = mode_e != OLY_MODE_STANDING;
+      int phase = si[I_PHASE0] + 1;
+      if (phase >= period) phase = 0;
+      if (!live) {
+        if (wave == 0) { put(0, F_NONE, 0, 0); put(1, F_NONE, 0, 0); put(6, F_NONE, 0, 0); put(8, F_NONE, 0, 0); put(9, F_NONE, 0, 0); }
+        else if (wave == 1) { put(13, F_NONE, 0, 0); put(14, F_NONE, 0, 0); put(15, F_NONE, 0, 0); }
+        else if (wave == 2) { put(7, F_NONE, 0, 0); put(10, F_NONE, 0, 0); put(11, F_NONE, 0, 0); put(12, F_NONE, 0, 0); }
+        else { put(2, F_NONE, 0, 0); put(3, F_NONE, 0, 0); put(4, F_NONE, 0, 0); put(5, F_NONE, 0, 0); }
+      } else if (wave == 0) {
+        // WalkingTask.step (walking_task.py:246-293): target reached / delay / update_target_steps; then the
+        // arguments that read the selected sequence rows
+        const double rp0 = ee_[L_RP], rp1 = ee_[L_RP + 1];
+        const double lf0 = ee_[L_LF], lf1 = ee_[L_LF + 1], lf2 = ee_[L_LF + 2];
+        const double rf0 = ee_[L_RF], rf1 = ee_[L_RF + 1], rf2 = ee_[L_RF + 2];
+        int t1e = si[I_T1], t2e = si[I_T2], fr = si[I_FRAMES];
+        const int seq_len_e = si[I_SEQLEN];
+        const double tx = esq[4 * t1e], ty = esq[4 * t1e + 1], tz = esq[4 * t1e + 2];
+        const double dl = vnorm3(lf0 - tx, lf1 - ty, lf2 - tz);
+        const double dr = vnorm3(rf0 - tx, rf1 - ty, rf2 - tz);
+        int reached;
+        if (dl < m->target_radius || dr < m->target_radius) {
+          reached = 1;
+          fr += 1;
+        } else {
+          reached = 0;
+          fr = 0;
         }
+        if (reached && fr >= m->delay_frames) {  // update_target_steps
+          t1e = t2e;
+          t2e += 1;
+          if (t2e == seq_len_e) t2e = seq_len_e - 1;
+          t2e = min(max(t2e, 0), OLY_MAX_SEQ - 1);
+          reached = 0;
+          fr = 0;
+        }
+        const int selA = 4 * t1e, selB = 4 * t2e;   // sequence[t1] / sequence[t2] after the update
+        const double s1x = esq[selA], s1y = esq[selA + 1], s1z = esq[selA + 2], s1w = esq[selA + 3];
+        const double s2x = esq[selB], s2y = esq[selB + 1], s2w = esq[selB + 3];
+        const double fd = fmin(vnorm3(lf0 - s1x, lf1 - s1y, lf2 - s1z), vnorm3(rf0 - s1x, rf1 - s1y, rf2 - s1z));
+        const double mpx = (s1x + s2x) / 2, mpy = (s1y + s2y) / 2;
+        const double rx = rp0 - mpx, ry = rp1 - mpy;
+        put(0, walking ? F_SINCOS : F_NONE, walking ? s1w : 0.0, 0.0);               // goal yaw 1: cos / sin(theta)
+        put(1, walking ? F_SINCOS : F_NONE, walking ? s2w : 0.0, 0.0);
+        put(6, F_SINCOS, s1w / 2.0, 0.0);                                            // euler2quat(0,0,yaw) of the target
+        put(8, F_EXP, -fd / 0.25, 0.0);                                              // target hit
+        put(9, F_EXP, -sqrt(rx * rx + ry * ry) / 2, 0.0);                            // progress
+        si[O_PHASE] = phase; si[O_T1] = t1e; si[O_T2] = t2e; si[O_FRAMES] = fr; si[O_REACHED] = reached;
+        si[O_DONE] = done; si[O_CUT] = cut; si[O_RESET] = need_reset;
+      } else if (wave == 1) {
+        // root rotation (goal steps, round 2) and its yaw for transform_sequence: quat2euler(root xquat)[2]
+        double R[3][3];
+        quat2mat(ee_[L_RQ], ee_[L_RQ + 1], ee_[L_RQ + 2], ee_[L_RQ + 3], R);
+        double* ro_ = s_env + e * L_ENV + L_ROT;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) ro_[3 * i + j] = R[i][j];
+        const double cyr = sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
+        const bool yaw = need_reset && cyr > 4.0 * EPS;
+        put(14, yaw ? F_ATAN2 : F_NONE, yaw ? R[1][0] : 0.0, yaw ? R[0][0] : 0.0);
+        // the clock observation, and env.reset()'s record header: mode / phase / length of the next pool record
+        put(13, F_SINCOS, 2 * PI * phase / (double)period, 0.0);                     // clock
+        int new_mode = mode_e, new_phase = 0, new_len = si[I_SEQLEN];
+        if (need_reset) {
+          const oly_a3_reset_record* rec = p.ro.pool + (size_t)(row0 + e) * p.ro.pool_depth +
+                                           (unsigned)si[I_RC] % (unsigned)p.ro.pool_depth;
+          new_mode = rec->mode;
+          new_phase = rec->phase;
+          new_len = min(max(rec->seq_len, 1), OLY_MAX_SEQ);
+        }
+        put(15, need_reset ? F_SINCOS : F_NONE, need_reset ? 2 * PI * new_phase / (double)period : 0.0, 0.0);   // clock after reset
+        si[O_NEWMODE] = new_mode; si[O_NEWPHASE] = new_phase; si[O_NEWLEN] = new_len;
+      } else if (wave == 2) {
+        // get_obs: quat2euler(qpos[3:7]) (StickFigureA3.py:160); upper body; height
+        double Rb[3][3];
+        quat2mat(ee_[L_BQ], ee_[L_BQ + 1], ee_[L_BQ + 2], ee_[L_BQ + 3], Rb);
+        const double cyb = sqrt(Rb[0][0] * Rb[0][0] + Rb[1][0] * Rb[1][0]);
+        const bool regular = cyb > 4.0 * EPS;
+        const double roll_y = regular ? Rb[2][1] : -Rb[1][2];
+        const double roll_x = regular ? Rb[2][2] : Rb[1][1];
+        const double hx = ee_[L_HP] - ee_[L_RP], hy = ee_[L_HP + 1] - ee_[L_RP + 1];
+        const double hn = sqrt(hx * hx + hy * hy);
+        const double contact_point = si[I_HAVEC] ? ee_[L_MZ] : 0.0;
+        double err = fabs((rp2 - contact_point) - m->goal_height_ref);
+        const double deadzone = 0.01 + 0.05 * m->goal_speed_ref;
+        if (err < deadzone) err = 0;
+        put(7, F_EXP, -40 * (err * err), 0.0);                                       // height
+        put(10, F_EXP, -10 * (hn * hn), 0.0);                                        // upper body
+        put(11, F_ATAN2, roll_y, roll_x);                                            // roll
+        put(12, F_ATAN2, -Rb[2][0], cyb);                                            // pitch
+      } else {
+        // calc_reward clock terms (walking_task.py:74-110, tasks/rewards.py:65-102)
+        double c_rfrc, c_rvel, c_lfrc, c_lvel;
+        if (!walking) {
+          c_rfrc = 1.0; c_lfrc = 1.0; c_rvel = -1.0; c_lvel = -1.0;
+        } else {
+          c_rfrc = s_lut[0 * period + phase];
+          c_rvel = s_lut[1 * period + phase];
+          c_lfrc = s_lut[2 * period + phase];
+          c_lvel = s_lut[3 * period + phase];
+        }
+        const double max_frc = m->mass * 9.8 * 0.5;
+        double nl = fmin(ee_[L_GL], max_frc) / max_frc;
+        double nr = fmin(ee_[L_GR], max_frc) / max_frc;
+        nl *= 2; nl -= 1; nr *= 2; nr -= 1;
+        double vl = fmin(vnorm3(ee_[L_LV], ee_[L_LV + 1], ee_[L_LV + 2]), 0.2) / 0.2;
+        double vr = fmin(vnorm3(ee_[L_RV], ee_[L_RV + 1], ee_[L_RV + 2]), 0.2) / 0.2;
+        vl *= 2; vl -= 1; vr *= 2; vr -= 1;
+        put(2, F_TAN, PI / 4 * c_lfrc * nl, 0.0);                                    // foot-force clock terms
+        put(3, F_TAN, PI / 4 * c_rfrc * nr, 0.0);
+        put(4, F_TAN, PI / 4 * c_lvel * vl, 0.0);                                    // foot-velocity clock terms
+        put(5, F_TAN, PI / 4 * c_rvel * vr, 0.0);
       }
     }
-    // root yaw for transform_sequence: quat2euler(root xquat)[2] = mat2euler's ak
-    const double cyr = sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
-
-    // ---- round 1: one libm call per lane (arguments formed by the environment's lanes, evaluation regrouped by
-    // function over the waves: wave 0 sin-cos, 1 tan, 2 exp, 3 atan2 of the workgroup's 16 environments)
-    int cls = F_NONE;
-    double a = 0.0, b = 0.0;
-    switch (slot) {
-      case 0: if (walking) { cls = F_SINCOS; a = s1w; } break;                       // goal yaw 1: cos / sin(theta)
-      case 1: if (walking) { cls = F_SINCOS; a = s2w; } break;
-      case 2: cls = F_TAN; a = PI / 4 * c_lfrc * nl; break;                          // foot-force clock terms
-      case 3: cls = F_TAN; a = PI / 4 * c_rfrc * nr; break;
-      case 4: cls = F_TAN; a = PI / 4 * c_lvel * vl; break;                          // foot-velocity clock terms
-      case 5: cls = F_TAN; a = PI / 4 * c_rvel * vr; break;
-      case 6: cls = F_SINCOS; a = s1w / 2.0; break;                                  // euler2quat(0,0,yaw) of the target
-      case 7: cls = F_EXP; a = -40 * (err * err); break;                             // height
-      case 8: cls = F_EXP; a = -fd / 0.25; break;                                    // target hit
-      case 9: cls = F_EXP; a = -sqrt(rx * rx + ry * ry) / 2; break;                  // progress
-      case 10: cls = F_EXP; a = -10 * (hn * hn); break;                              // upper body
-      case 11: cls = F_ATAN2; a = roll_y; b = roll_x; break;                         // roll
-      case 12: cls = F_ATAN2; a = -Rb[2][0]; b = cyb; break;                         // pitch
-      case 13: cls = F_SINCOS; a = 2 * PI * phase / (double)period; break;           // clock
-      case 14: if (need_reset && cyr > 4.0 * EPS) { cls = F_ATAN2; a = R[1][0]; b = R[0][0]; } break;   // root yaw
-      default: if (need_reset) { cls = F_SINCOS; a = 2 * PI * new_phase / (double)period; } break;      // clock after reset
-    }
-    s_arg[(el * SLOTS + slot) * 2] = a;
-    s_arg[(el * SLOTS + slot) * 2 + 1] = b;
-    s_cls[el * SLOTS + slot] = (uint8_t)(env_ok ? cls : F_NONE);
     __syncthreads();
-    if (skip & 32) continue;
     double r0, r1;
     const int ee = lane & 15;
     {
@@ -653,13 +670,64 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
       }
     }
     __syncthreads();
-    if (skip & 64) continue;
+
+    // ---- back on the environment's own lanes: what the level-1 tasks decided, and the few values the rest of the
+    // step needs from them (the goal steps are formed here: they need task 0's step indices and task 1's rotation)
+    const int* si_ = s_int + el * SI_N;
+    const int phase = si_[O_PHASE];
+    const int reached = si_[O_REACHED];
+    t1 = si_[O_T1];
+    t2 = si_[O_T2];
+    frames = si_[O_FRAMES];
+    const bool done = si_[O_DONE] != 0, cut = si_[O_CUT] != 0;
+    const bool need_reset = env_ok && si_[O_RESET] != 0;
+    const int new_mode = si_[O_NEWMODE], new_phase = si_[O_NEWPHASE], new_len = si_[O_NEWLEN];
+    const int len = tlen + 1;
+    const bool walking = mode != OLY_MODE_STANDING;
+    const double rq0 = se[L_RQ], rq1 = se[L_RQ + 1], rq2 = se[L_RQ + 2], rq3 = se[L_RQ + 3];
+    const double rp0 = se[L_RP], rp1 = se[L_RP + 1], rp2 = se[L_RP + 2];
+    const double lf0 = se[L_LF], lf1 = se[L_LF + 1];
+    const double rf0 = se[L_RF], rf1 = se[L_RF + 1];
+    double R[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[i][j] = se[L_ROT + 3 * i + j];
+    double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (walking) {
+      const int selA = 4 * t1, selB = 4 * t2;   // sequence[t1] / sequence[t2] after the update
+      const double s1x = sq[selA], s1y = sq[selA + 1], s1z = sq[selA + 2];
+      const double s2x = sq[selB], s2y = sq[selB + 1], s2z = sq[selB + 2];
+      const double a0 = s1x - rp0, a1 = s1y - rp1, a2 = s1z - rp2;
+      const double b0 = s2x - rp0, b1 = s2y - rp1, b2 = s2z - rp2;
+      goal[0] = R[0][0] * a0 + R[1][0] * a1 + R[2][0] * a2;
+      goal[2] = R[0][1] * a0 + R[1][1] * a1 + R[2][1] * a2;
+      goal[4] = R[0][2] * a0 + R[1][2] * a1 + R[2][2] * a2;
+      goal[1] = R[0][0] * b0 + R[1][0] * b1 + R[2][0] * b2;
+      goal[3] = R[0][1] * b0 + R[1][1] * b1 + R[2][1] * b2;
+      goal[5] = R[0][2] * b0 + R[1][2] * b1 + R[2][2] * b2;
+    }
+    // env.reset(): the rows of the next pool record (its header went through task 3); needed after round 2 only
+    double rec_seq[(OLY_MAX_SEQ + SLOTS - 1) / SLOTS][4];
+#pragma unroll
+    for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q)
+      rec_seq[q][0] = rec_seq[q][1] = rec_seq[q][2] = rec_seq[q][3] = 0.0;
+    if (need_reset) {
+      const oly_a3_reset_record* rec = p.ro.pool + (size_t)n_t * p.ro.pool_depth + (unsigned)rc % (unsigned)p.ro.pool_depth;
+#pragma unroll
+      for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
+        const int r = slot + SLOTS * q;
+        if (r < OLY_MAX_SEQ) {
+          rec_seq[q][0] = rec->seq[r][0]; rec_seq[q][1] = rec->seq[r][1];
+          rec_seq[q][2] = rec->seq[r][2]; rec_seq[q][3] = rec->seq[r][3];
+        }
+      }
+    }
 
     // ---- round 2
     const double root_yaw = se[L_R1 + 2 * 14];
-    cls = F_NONE;
-    a = 0.0;
-    b = 0.0;
+    int cls = F_NONE;
+    double a = 0.0, b = 0.0;
     switch (slot) {
       case 0:
       case 1:
@@ -700,7 +768,6 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
       }
     }
     __syncthreads();
-    if (skip & 128) continue;
 
     // ---- combine, observation rows
     float* op = s_pre + el * OBP;

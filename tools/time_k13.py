@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Where a step of the persistent rollout kernel (K13) spends its time: HIP-event time of the launch at
 N = 4096, T = 400 with phases switched off (OLY_K13_SKIP: bit 0 = no MFMA layers, bit 1 = no environment step:
-outputs are garbage; bits 4..7 leave the environment step after its contacts / level-1 arithmetic and round-1
-arguments / round-1 libm results / round-2 libm results).  One process per variant (the knob is read once)."""
+outputs are garbage).  One process per variant (the knob is read once)."""
 import json
 import os
 import subprocess
@@ -39,9 +38,7 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     out = {}
-    variants = [(0, "everything", None), (1, "no_mfma_layers", None), (2, "no_environment_step", None), (3, "neither", None),
-                (1 + 16, "env_until_contacts", None), (1 + 32, "env_until_round1_arguments", None),
-                (1 + 64, "env_until_round1_results", None), (1 + 128, "env_until_round2_results", None)]
+    variants = [(0, "everything", None), (1, "no_mfma_layers", None), (2, "no_environment_step", None), (3, "neither", None)]
     for skip, label, _ in variants:
         env = dict(os.environ, OLY_K13_SKIP=str(skip))
         r = subprocess.run([sys.executable, "-c", CHILD, str(N), str(T)], env=env, capture_output=True, text=True)
