@@ -395,6 +395,7 @@ class Engine:
                 check(h, rc, "oly_a3_rollout_persistent")
             return keep
         launch.persistent = persistent
+        launch.structs = (cb, cst, cr)       # the C structs of this launch (tests call the C entry points with them)
         return launch
 
     def a3_pd_target(self, action):
