@@ -632,6 +632,48 @@ def test_vec_step_random_configurations(eng, golden, oracle, seed):
     assert (c[:-1, 0] == ro["ctr"][0]).all() and (c[:-1, 1] == ro["ctr"][1]).all() and c[-1, 0] == 0
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_persistent_rollout_random_configurations(seed):
+    """Differential fuzz of K13 against the K11 + K10 loop (itself fuzzed against the oracle above) over the launch
+    shape: environment counts around the 16-environment tile, one readback row, one-step trajectories (every step
+    cuts and resets), a one-record reset ring (records re-used), 1 to 40 contact slots, deterministic / stochastic,
+    T = 1.  Everything bit-identical."""
+    from olympic_hip.a3 import ReplayA3Physics, VecA3Env
+    from olympic_hip.engine import Engine
+    from olympic_hip.ppo import MLPCritic, MLPGaussianActor
+    from olympic_hip.vecstep import A3DeviceRollout
+    cfg = np.random.default_rng(7000 + seed)
+    N = int(cfg.choice([1, 2, 15, 16, 17, 31, 33, 130, 257, 1023]))
+    K = int(cfg.choice([1, 2, 7]))
+    T = int(cfg.integers(1, 9))
+    max_len = int(cfg.choice([1, 2, 3, 50]))
+    depth = int(cfg.choice([1, 2, 5]))
+    C = int(cfg.choice([1, 3, 16, 17, 40]))
+    det = bool(cfg.integers(0, 2))
+    torch.manual_seed(seed)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    host = a3_synthetic_blocks(N, K, seed=seed, C=C, p_bad=0.1, p_low=0.05)
+    host["ncon"] = cfg.integers(0, C + 1, host["ncon"].shape).astype(np.int32)
+    out = []
+    for persistent in (False, True):
+        blocks = {k: dev(v) for k, v in host.items()}
+        env = VecA3Env(specs.A3Spec(mass=41.5), N, Engine(0), ReplayA3Physics(blocks), *CONTACT, rs=np.random.RandomState(seed))
+        env._dev_rollout = A3DeviceRollout(env, blocks, pool_depth=depth, rs=np.random.RandomState(seed + 1), keep_rew6=True)
+        torch.manual_seed(100 + seed)
+        env.device_rollout(pi, vf, T, max_len, deterministic=det, anneal=0.6, graph=False, persistent=persistent)
+        r = env._dev_rollout
+        named = dict(states=r.buf.states, actions=r.buf.actions, rewards=r.buf.rewards, values=r.buf.values,
+                     next_values=r.buf.next_values, flags=r.buf.flags, rew6=r.rew6, state_obs=r.state_obs,
+                     pd_target=r.pd_target, traj_len=r.traj_len, side_obs=r.side_obs, side_t=r.side_t,
+                     side_count=r.side_count, ctr=r.ctr)
+        named.update({"st_" + k: v for k, v in env.state.items()})
+        out.append(({k: v.clone() for k, v in named.items()}, dict(r.last_info)))
+    what = dict(seed=seed, N=N, K=K, T=T, max_len=max_len, depth=depth, C=C, det=det)
+    for name in out[0][0]:
+        assert torch.equal(out[0][0][name], out[1][0][name]), (name, what)
+    assert out[0][1] == out[1][1], what
+
+
 @pytest.mark.parametrize("in_dim,out_a,out_b,N", [(1, 1, 1, 5), (7, 32, 1, 33), (40, 5, 32, 64), (64, 12, 1, 97),
                                                   (63, 31, 2, 200), (33, 1, 17, 31)])
 def test_fused_mlp_other_dimensions_vs_oracle(eng, oracle, in_dim, out_a, out_b, N):
