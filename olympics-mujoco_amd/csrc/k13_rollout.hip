@@ -56,7 +56,7 @@ using oly_mlp::store_relu16;
 
 namespace {
 constexpr int THREADS = 256;            // 4 waves; two workgroups per CU
-constexpr int SLOTS = 16;               // lanes per environment
+constexpr int SLOTS = A3V_SLOTS;        // lanes per environment
 constexpr int EPW = THREADS / SLOTS;    // environments per workgroup = rows of the MFMA tile
 static_assert(EPW == 16, "a workgroup's environments are one 16-row MFMA tile");
 constexpr int KSPLIT = 8;               // output layer: partial chains over k in [32 j, 32 j + 32), as K11's eight waves
@@ -64,38 +64,8 @@ constexpr int PPITCH = 17;              // pitch of the output layer's partial t
 constexpr int MAX_NU = 16;
 constexpr int MAX_NOBS = 7 + 2 * MAX_NU + 10;
 constexpr int OBP = MAX_NOBS + 1;       // pitch of the observation rows in LDS
-constexpr int SEQW = OLY_MAX_SEQ * 4;   // doubles of one environment's step sequence
+constexpr int SEQW = A3V_SEQW;          // doubles of one environment's step sequence
 constexpr int OBS_PT = (EPW * MAX_NOBS + THREADS - 1) / THREADS;
-
-// per-environment LDS scratch of the environment step (doubles); lives where the MLP activations live during
-// the forward (the two phases never overlap)
-enum {
-  L_RQ = 0,      // root quat 4
-  L_RP = 4,      // root pos 3
-  L_HP = 7,      // head pos 3
-  L_LF = 10,     // lf pos 3
-  L_RF = 13,     // rf pos 3
-  L_LV = 16,     // lf vel 3
-  L_RV = 19,     // rf vel 3
-  L_BQ = 22,     // body quat qpos[3:7]
-  L_AV = 26,     // qvel[3:6]
-  L_AL = 29,     // act_len 16
-  L_AVL = 45,    // act_vel 16
-  L_R1 = 61,     // round-1 results [16][2]
-  L_R2 = 93,     // round-2 results [16][2]
-  L_GR = 125,    // contact reduction: grf_r, grf_l, min_z
-  L_GL = 126,
-  L_MZ = 127,
-  L_ROT = 128,   // root rotation matrix R[3][3] (level-1 task 1 -> round 2 / goal steps)
-  L_ENV = 137
-};
-// per-environment ints in LDS: what the level-1 tasks read (written by the environment's own lanes) and what they
-// hand back
-enum {
-  I_PHASE0 = 0, I_T1, I_T2, I_FRAMES, I_MODE, I_SEQLEN, I_TLEN, I_RC, I_BAD, I_HAVEC,           // inputs
-  O_PHASE, O_T1, O_T2, O_FRAMES, O_REACHED, O_DONE, O_CUT, O_RESET, O_NEWMODE, O_NEWPHASE, O_NEWLEN,   // outputs
-  SI_N = 24
-};
 
 // Device copy of everything the rollout kernel reads AND (at its end) overwrites.  Laid out in the caller's scratch
 // buffer (oly_a3_rollout_scratch_bytes): SoA, 8-byte-aligned segments.
@@ -515,147 +485,13 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
     }
     __syncthreads();
 
-    // ---- level 1: everything without libm, as FOUR TASKS, one per wave, one LANE per environment.
-    // An environment's 16 lanes used to run this whole block redundantly: ~1100 instructions issued by every wave
-    // (3.3 us of a step).  Issue time depends on the length of a wave's instruction stream, not on how many lanes
-    // are active, so the block is cut by FUNCTION across the workgroup's four waves (as the libm rounds are), each
-    // wave taking all 16 environments on lanes 0..15: ~300 instructions per wave.  Same expressions on the same
-    // inputs: bit-identical.  Each task writes the round-1 arguments of the slots it owns.
-    if (lane < EPW) {
-      const int e = lane;
-      const double* ee_ = s_env + e * L_ENV;
-      const double* esq = seqs + e * SEQW;
-      int* si = s_int + e * SI_N;
-      double* arg = s_arg + e * SLOTS * 2;
-      uint8_t* acl = s_cls + e * SLOTS;
-      auto put = [&](int task, int cls, double a, double b) {
-        arg[2 * task] = a;
-        arg[2 * task + 1] = b;
-        acl[task] = (uint8_t)cls;
-      };
-      const bool live = e < rows;
-      // shared, cheap: done / cut / need_reset (walking_task.py:298-319, ppo.py:178,189-196)
-      const double rp2 = ee_[L_RP + 2];
-      const double foot_z = fmin(ee_[L_LF + 2], ee_[L_RF + 2]);
-      const bool bad_e = si[I_BAD] != 0;
-      const bool done = ((rp2 - foot_z) < 0.6) || bad_e;
-      const int len = si[I_TLEN] + 1;
-      const bool cut = done || len >= p.ro.max_traj_len || last_step;
-      const bool need_reset = live && cut && !last_step;
-      const int mode_e = si[I_MODE];
-      const bool walking = mode_e != OLY_MODE_STANDING;
-      int phase = si[I_PHASE0] + 1;
-      if (phase >= period) phase = 0;
-      if (!live) {
-        if (wave == 0) { put(0, F_NONE, 0, 0); put(1, F_NONE, 0, 0); put(6, F_NONE, 0, 0); put(8, F_NONE, 0, 0); put(9, F_NONE, 0, 0); }
-        else if (wave == 1) { put(13, F_NONE, 0, 0); put(14, F_NONE, 0, 0); put(15, F_NONE, 0, 0); }
-        else if (wave == 2) { put(7, F_NONE, 0, 0); put(10, F_NONE, 0, 0); put(11, F_NONE, 0, 0); put(12, F_NONE, 0, 0); }
-        else { put(2, F_NONE, 0, 0); put(3, F_NONE, 0, 0); put(4, F_NONE, 0, 0); put(5, F_NONE, 0, 0); }
-      } else if (wave == 0) {
-        // WalkingTask.step (walking_task.py:246-293): target reached / delay / update_target_steps; then the
-        // arguments that read the selected sequence rows
-        const double rp0 = ee_[L_RP], rp1 = ee_[L_RP + 1];
-        const double lf0 = ee_[L_LF], lf1 = ee_[L_LF + 1], lf2 = ee_[L_LF + 2];
-        const double rf0 = ee_[L_RF], rf1 = ee_[L_RF + 1], rf2 = ee_[L_RF + 2];
-        int t1e = si[I_T1], t2e = si[I_T2], fr = si[I_FRAMES];
-        const int seq_len_e = si[I_SEQLEN];
-        const double tx = esq[4 * t1e], ty = esq[4 * t1e + 1], tz = esq[4 * t1e + 2];
-        const double dl = vnorm3(lf0 - tx, lf1 - ty, lf2 - tz);
-        const double dr = vnorm3(rf0 - tx, rf1 - ty, rf2 - tz);
-        int reached;
-        if (dl < m->target_radius || dr < m->target_radius) {
-          reached = 1;
-          fr += 1;
-        } else {
-          reached = 0;
-          fr = 0;
-        }
-        if (reached && fr >= m->delay_frames) {  // update_target_steps
-          t1e = t2e;
-          t2e += 1;
-          if (t2e == seq_len_e) t2e = seq_len_e - 1;
-          t2e = min(max(t2e, 0), OLY_MAX_SEQ - 1);
-          reached = 0;
-          fr = 0;
-        }
-        const int selA = 4 * t1e, selB = 4 * t2e;   // sequence[t1] / sequence[t2] after the update
-        const double s1x = esq[selA], s1y = esq[selA + 1], s1z = esq[selA + 2], s1w = esq[selA + 3];
-        const double s2x = esq[selB], s2y = esq[selB + 1], s2w = esq[selB + 3];
-        const double fd = fmin(vnorm3(lf0 - s1x, lf1 - s1y, lf2 - s1z), vnorm3(rf0 - s1x, rf1 - s1y, rf2 - s1z));
-        const double mpx = (s1x + s2x) / 2, mpy = (s1y + s2y) / 2;
-        const double rx = rp0 - mpx, ry = rp1 - mpy;
-        put(0, walking ? F_SINCOS : F_NONE, walking ? s1w : 0.0, 0.0);               // goal yaw 1: cos / sin(theta)
-        put(1, walking ? F_SINCOS : F_NONE, walking ? s2w : 0.0, 0.0);
-        put(6, F_SINCOS, s1w / 2.0, 0.0);                                            // euler2quat(0,0,yaw) of the target
-        put(8, F_EXP, -fd / 0.25, 0.0);                                              // target hit
-        put(9, F_EXP, -sqrt(rx * rx + ry * ry) / 2, 0.0);                            // progress
-        si[O_PHASE] = phase; si[O_T1] = t1e; si[O_T2] = t2e; si[O_FRAMES] = fr; si[O_REACHED] = reached;
-        si[O_DONE] = done; si[O_CUT] = cut; si[O_RESET] = need_reset;
-      } else if (wave == 1) {
-        // root rotation (goal steps, round 2) and its yaw for transform_sequence: quat2euler(root xquat)[2]
-        double R[3][3];
-        quat2mat(ee_[L_RQ], ee_[L_RQ + 1], ee_[L_RQ + 2], ee_[L_RQ + 3], R);
-        double* ro_ = s_env + e * L_ENV + L_ROT;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) ro_[3 * i + j] = R[i][j];
-        const double cyr = sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
-        const bool yaw = need_reset && cyr > 4.0 * EPS;
-        put(14, yaw ? F_ATAN2 : F_NONE, yaw ? R[1][0] : 0.0, yaw ? R[0][0] : 0.0);
-        // the clock observation, and env.reset()'s record header: mode / phase / length of the next pool record
-        put(13, F_SINCOS, 2 * PI * phase / (double)period, 0.0);                     // clock
-        int new_mode = mode_e, new_phase = 0, new_len = si[I_SEQLEN];
-        if (need_reset) {
-          const oly_a3_reset_record* rec = p.ro.pool + (size_t)(row0 + e) * p.ro.pool_depth +
-                                           (unsigned)si[I_RC] % (unsigned)p.ro.pool_depth;
-          new_mode = rec->mode;
-          new_phase = rec->phase;
-          new_len = min(max(rec->seq_len, 1), OLY_MAX_SEQ);
-        }
-        put(15, need_reset ? F_SINCOS : F_NONE, need_reset ? 2 * PI * new_phase / (double)period : 0.0, 0.0);   // clock after reset
-        si[O_NEWMODE] = new_mode; si[O_NEWPHASE] = new_phase; si[O_NEWLEN] = new_len;
-      } else if (wave == 2) {
-        // get_obs: quat2euler(qpos[3:7]) (StickFigureA3.py:160); upper body; height
-        double Rb[3][3];
-        quat2mat(ee_[L_BQ], ee_[L_BQ + 1], ee_[L_BQ + 2], ee_[L_BQ + 3], Rb);
-        const double cyb = sqrt(Rb[0][0] * Rb[0][0] + Rb[1][0] * Rb[1][0]);
-        const bool regular = cyb > 4.0 * EPS;
-        const double roll_y = regular ? Rb[2][1] : -Rb[1][2];
-        const double roll_x = regular ? Rb[2][2] : Rb[1][1];
-        const double hx = ee_[L_HP] - ee_[L_RP], hy = ee_[L_HP + 1] - ee_[L_RP + 1];
-        const double hn = sqrt(hx * hx + hy * hy);
-        const double contact_point = si[I_HAVEC] ? ee_[L_MZ] : 0.0;
-        double err = fabs((rp2 - contact_point) - m->goal_height_ref);
-        const double deadzone = 0.01 + 0.05 * m->goal_speed_ref;
-        if (err < deadzone) err = 0;
-        put(7, F_EXP, -40 * (err * err), 0.0);                                       // height
-        put(10, F_EXP, -10 * (hn * hn), 0.0);                                        // upper body
-        put(11, F_ATAN2, roll_y, roll_x);                                            // roll
-        put(12, F_ATAN2, -Rb[2][0], cyb);                                            // pitch
-      } else {
-        // calc_reward clock terms (walking_task.py:74-110, tasks/rewards.py:65-102)
-        double c_rfrc, c_rvel, c_lfrc, c_lvel;
-        if (!walking) {
-          c_rfrc = 1.0; c_lfrc = 1.0; c_rvel = -1.0; c_lvel = -1.0;
-        } else {
-          c_rfrc = s_lut[0 * period + phase];
-          c_rvel = s_lut[1 * period + phase];
-          c_lfrc = s_lut[2 * period + phase];
-          c_lvel = s_lut[3 * period + phase];
-        }
-        const double max_frc = m->mass * 9.8 * 0.5;
-        double nl = fmin(ee_[L_GL], max_frc) / max_frc;
-        double nr = fmin(ee_[L_GR], max_frc) / max_frc;
-        nl *= 2; nl -= 1; nr *= 2; nr -= 1;
-        double vl = fmin(vnorm3(ee_[L_LV], ee_[L_LV + 1], ee_[L_LV + 2]), 0.2) / 0.2;
-        double vr = fmin(vnorm3(ee_[L_RV], ee_[L_RV + 1], ee_[L_RV + 2]), 0.2) / 0.2;
-        vl *= 2; vl -= 1; vr *= 2; vr -= 1;
-        put(2, F_TAN, PI / 4 * c_lfrc * nl, 0.0);                                    // foot-force clock terms
-        put(3, F_TAN, PI / 4 * c_rfrc * nr, 0.0);
-        put(4, F_TAN, PI / 4 * c_lvel * vl, 0.0);                                    // foot-velocity clock terms
-        put(5, F_TAN, PI / 4 * c_rvel * vr, 0.0);
-      }
+    // ---- level 1: everything without libm, as four tasks, one per wave, one LANE per environment (a3_vec_core.h)
+    {
+      Level1Ctx lc;
+      lc.m = m; lc.s_env = s_env; lc.seqs = seqs; lc.s_int = s_int; lc.s_arg = s_arg; lc.s_cls = s_cls; lc.s_lut = s_lut;
+      lc.period = period; lc.rows = rows; lc.last_step = last_step; lc.max_traj_len = p.ro.max_traj_len;
+      lc.pool = p.ro.pool; lc.pool_depth = p.ro.pool_depth; lc.row0 = row0;
+      level1_tasks(lc, wave, lane);
     }
     __syncthreads();
     double r0, r1;

@@ -11,13 +11,16 @@
 // stream.  Integer state (phase, t1, t2, frame counters, flags) is bit-exact; every fp64
 // expression keeps the reference's evaluation order (compiled with -ffp-contract=off).
 // Bound: HBM, ~930 B read + ~257 B written per env.
+#include <cstdlib>
 #include <type_traits>
 
+#include "a3_vec_core.h"
 #include "oly_common.h"
 
 namespace {
 constexpr int THREADS = 128;
 constexpr double PI = 3.141592653589793;
+constexpr int K2_LANES16_MAX_N = 16384;    // up to here the 16-lane kernel wins (measured: tools/bench_kernels.py)
 
 struct A3Args {
   const A3Dev* md;
@@ -237,6 +240,225 @@ __global__ __launch_bounds__(THREADS) void a3_step_kernel(A3Args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same step with SIXTEEN lanes per environment (K10's layout) for the sizes a vectorised env.step() really has.
+// One lane per environment is a dependent chain of ~27 fp64 libm calls and ~1100 libm-free fp64 instructions on 128
+// threads per workgroup: 4096 environments are 32 workgroups on 256 CUs and 24 us.  Here a 256-thread workgroup owns
+// 16 environments: the libm-free arithmetic runs as four per-wave tasks (a3_vec_core.h: level1_tasks), every libm
+// call is one lane's job in two rounds regrouped by function across the waves, the observation row is assembled by
+// the environment's 16 lanes.  Same expressions on the same inputs as a3_step_kernel (the arithmetic K10 and K13
+// share): identical results, bit for bit (tests/test_gpu_parity.py forces either kernel onto every A3 test).
+template <bool OBS64>
+__global__ __launch_bounds__(256) void a3_step16_kernel(A3Args p) {
+  using namespace oly_a3v;
+  using obs_t = typename std::conditional<OBS64, double, float>::type;
+  constexpr int SLOTS = A3V_SLOTS, EPW = A3V_EPW, MAXOBS = 7 + 2 * 16 + 10;
+  __shared__ double s_env[EPW * L_ENV];
+  __shared__ double seqs[EPW * A3V_SEQW];
+  __shared__ double s_arg[EPW * SLOTS * 2];
+  __shared__ uint8_t s_cls[EPW * SLOTS];
+  __shared__ int s_int[EPW * SI_N];
+  __shared__ obs_t s_obs[EPW * (MAXOBS + 1)];
+  const A3Dev* __restrict__ m = p.md;
+  const int nu = m->nu, n_obs = m->n_obs, period = m->period;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, slot = lane & (SLOTS - 1);
+  const int el = wave * 4 + grp;
+  const int row0 = blockIdx.x * EPW;
+  const int n = row0 + el;
+  const bool env_ok = n < p.N;
+  const int rows = min(EPW, p.N - row0);
+  double* se = s_env + el * L_ENV;
+  double* sq = seqs + el * A3V_SEQW;
+
+  // ---- every load up front, one piece per lane; staged in LDS
+  if (env_ok) {
+    const size_t r3 = (size_t)n * 3, r4 = (size_t)n * 4;
+    double va;
+    if (slot < 4) va = p.in.root_quat[r4 + slot];
+    else if (slot < 7) va = p.in.root_pos[r3 + slot - 4];
+    else if (slot < 10) va = p.in.head_pos[r3 + slot - 7];
+    else if (slot < 13) va = p.in.lf_pos[r3 + slot - 10];
+    else va = p.in.rf_pos[r3 + slot - 13];
+    se[slot] = va;
+    if (slot < 3) se[L_LV + slot] = p.in.lf_vel[r3 + slot];
+    else if (slot < 6) se[L_RV + slot - 3] = p.in.rf_vel[r3 + slot - 3];
+    else if (slot < 10) se[L_BQ + slot - 6] = p.in.qpos[(size_t)n * p.qpos_stride + p.qpos_off + slot - 6];
+    else if (slot < 13) se[L_AV + slot - 10] = p.in.qvel[(size_t)n * p.qvel_stride + p.qvel_off + slot - 10];
+    if (slot < nu) {
+      se[L_AL + slot] = p.in.act_len[(size_t)n * nu + slot];
+      se[L_AVL + slot] = p.in.act_vel[(size_t)n * nu + slot];
+    }
+#pragma unroll
+    for (int q = 0; q < A3V_SEQW / SLOTS; ++q) sq[slot + SLOTS * q] = p.st.sequence[(size_t)n * A3V_SEQW + slot + SLOTS * q];
+    if (slot == 0) {
+      int* si = s_int + el * SI_N;
+      si[I_PHASE0] = p.st.phase[n];
+      si[I_T1] = min(max(p.st.t1[n], 0), OLY_MAX_SEQ - 1);
+      si[I_T2] = min(max(p.st.t2[n], 0), OLY_MAX_SEQ - 1);
+      si[I_FRAMES] = p.st.reached_frames[n];
+      si[I_MODE] = p.st.mode[n];
+      si[I_SEQLEN] = p.st.seq_len[n];
+      si[I_TLEN] = 0;
+      si[I_RC] = 0;
+      si[I_BAD] = p.in.bad[n];
+      si[I_HAVEC] = (p.in.n_r[n] > 0 || p.in.n_l[n] > 0);
+      se[L_GR] = p.in.grf_r[n];
+      se[L_GL] = p.in.grf_l[n];
+      se[L_MZ] = p.in.min_z[n];
+    }
+  }
+  __syncthreads();
+
+  // ---- level 1 (no rollout bookkeeping: last_step = true means no cut-driven reset)
+  {
+    Level1Ctx lc;
+    lc.m = m; lc.s_env = s_env; lc.seqs = seqs; lc.s_int = s_int; lc.s_arg = s_arg; lc.s_cls = s_cls;
+    lc.s_lut = m->clock_lut; lc.period = period; lc.rows = rows; lc.last_step = true; lc.max_traj_len = 0x7fffffff;
+    lc.pool = nullptr; lc.pool_depth = 1; lc.row0 = row0;
+    level1_tasks(lc, wave, lane);
+  }
+  __syncthreads();
+  double r0, r1;
+  const int ee = lane & 15;
+  {  // ---- libm round 1: wave 0 sin-cos, 1 tan, 2 exp, 3 atan2 of the group's 16 environments
+    constexpr int R1_TASK[4][4] = {{0, 1, 6, 13}, {2, 3, 4, 5}, {7, 8, 9, 10}, {11, 12, -1, -1}};
+    const int task = R1_TASK[wave][lane >> 4];
+    if (task >= 0) {
+      eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
+      s_env[ee * L_ENV + L_R1 + 2 * task] = r0;
+      s_env[ee * L_ENV + L_R1 + 2 * task + 1] = r1;
+    }
+  }
+  __syncthreads();
+
+  // ---- back on the environment's own lanes
+  const int* si_ = s_int + el * SI_N;
+  const int t1 = env_ok ? si_[O_T1] : 0, t2 = env_ok ? si_[O_T2] : 0;      // (rows past N hold nothing)
+  const bool walking = env_ok && si_[I_MODE] != OLY_MODE_STANDING;
+  const double rq0 = se[L_RQ], rq1 = se[L_RQ + 1], rq2 = se[L_RQ + 2], rq3 = se[L_RQ + 3];
+  const double rp0 = se[L_RP], rp1 = se[L_RP + 1], rp2 = se[L_RP + 2];
+  double R[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i][j] = se[L_ROT + 3 * i + j];
+  double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (walking) {
+    const int selA = 4 * t1, selB = 4 * t2;
+    const double s1x = sq[selA], s1y = sq[selA + 1], s1z = sq[selA + 2];
+    const double s2x = sq[selB], s2y = sq[selB + 1], s2z = sq[selB + 2];
+    const double a0 = s1x - rp0, a1 = s1y - rp1, a2 = s1z - rp2;
+    const double b0 = s2x - rp0, b1 = s2y - rp1, b2 = s2z - rp2;
+    goal[0] = R[0][0] * a0 + R[1][0] * a1 + R[2][0] * a2;
+    goal[2] = R[0][1] * a0 + R[1][1] * a1 + R[2][1] * a2;
+    goal[4] = R[0][2] * a0 + R[1][2] * a1 + R[2][2] * a2;
+    goal[1] = R[0][0] * b0 + R[1][0] * b1 + R[2][0] * b2;
+    goal[3] = R[0][1] * b0 + R[1][1] * b1 + R[2][1] * b2;
+    goal[5] = R[0][2] * b0 + R[1][2] * b1 + R[2][2] * b2;
+  }
+  {  // ---- round 2 arguments
+    int cls = F_NONE;
+    double a = 0.0, b = 0.0;
+    switch (slot) {
+      case 0:
+      case 1:
+        if (walking) {   // theta = mat2euler(R^T Rz(yaw))[2] = atan2(M10, M00)
+          const double c = se[L_R1 + 2 * slot + 1], sn = se[L_R1 + 2 * slot];
+          cls = F_ATAN2;
+          a = R[0][1] * c + R[1][1] * sn;
+          b = R[0][0] * c + R[1][0] * sn;
+        }
+        break;
+      case 2: {          // body orientation: exp(-10 (1 - <q_ref, q>^2))
+        const double tq0 = se[L_R1 + 2 * 6 + 1], tq3 = se[L_R1 + 2 * 6];
+        const double ip = tq0 * rq0 + 0.0 * rq1 + 0.0 * rq2 + tq3 * rq3;
+        cls = F_EXP;
+        a = -(10 * (1 - ip * ip));
+      } break;
+      case 3: cls = F_SINCOS; a = se[L_R1 + 2 * 11] / 2.0; break;                    // roll / 2
+      case 4: cls = F_SINCOS; a = se[L_R1 + 2 * 12] / 2.0; break;                    // pitch / 2
+      default: break;
+    }
+    if (slot < 5) {
+      s_arg[(el * SLOTS + slot) * 2] = a;
+      s_arg[(el * SLOTS + slot) * 2 + 1] = b;
+      s_cls[el * SLOTS + slot] = (uint8_t)(env_ok ? cls : F_NONE);
+    }
+  }
+  __syncthreads();
+  {  // ---- libm round 2: wave 0 sin-cos (roll / 2, pitch / 2), wave 1 atan2 (the goal yaws), wave 2 exp (orientation)
+    constexpr int R2_TASK[4][4] = {{3, 4, -1, -1}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
+    const int task = R2_TASK[wave][lane >> 4];
+    if (task >= 0) {
+      eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
+      s_env[ee * L_ENV + L_R2 + 2 * task] = r0;
+      s_env[ee * L_ENV + L_R2 + 2 * task + 1] = r1;
+    }
+  }
+  __syncthreads();
+
+  // ---- combine: observation row (the output type is formed once, as a3_step_kernel does), rewards, state
+  if (env_ok) {
+    if (walking) {
+      goal[6] = se[L_R2 + 0];
+      goal[7] = se[L_R2 + 2];
+    }
+    obs_t* op = s_obs + el * (MAXOBS + 1);
+    const double ci = se[L_R2 + 2 * 3 + 1], si = se[L_R2 + 2 * 3], cj = se[L_R2 + 2 * 4 + 1], sj = se[L_R2 + 2 * 4];
+    if (slot == 0) op[0] = (obs_t)(ci * cj);
+    if (slot == 1) op[1] = (obs_t)(si * cj);
+    if (slot == 2) op[2] = (obs_t)(ci * sj);
+    if (slot == 3) op[3] = (obs_t)(-(si * sj));
+    if (slot >= 4 && slot < 7) op[slot] = (obs_t)se[L_AV + slot - 4];
+    if (slot < nu) {
+      const double g = m->gear[slot];
+      op[7 + slot] = (obs_t)(se[L_AL + slot] / g);
+      op[7 + nu + slot] = (obs_t)(se[L_AVL + slot] / g);
+    }
+    if (slot == 7) op[7 + 2 * nu] = (obs_t)se[L_R1 + 2 * 13];
+    if (slot == 8) op[8 + 2 * nu] = (obs_t)se[L_R1 + 2 * 13 + 1];
+    if (slot >= 8) op[9 + 2 * nu + slot - 8] = (obs_t)goal[slot - 8];
+    if (slot < 8) p.st.goal[8 * (size_t)n + slot] = goal[slot];
+    if (slot == 0) {
+      const int reached = si_[O_REACHED];
+      const double frc = (se[L_R1 + 2 * 2] + se[L_R1 + 2 * 3]) / 2;
+      const double vel = (se[L_R1 + 2 * 4] + se[L_R1 + 2 * 5]) / 2;
+      const double orient = se[L_R2 + 2 * 2];
+      const double height = se[L_R1 + 2 * 7];
+      const double hit = reached ? se[L_R1 + 2 * 8] : 0.0;
+      const double progress = se[L_R1 + 2 * 9];
+      const double step_r = 0.8 * hit + 0.2 * progress;
+      const double upper = se[L_R1 + 2 * 10];
+      double rew[6];
+      rew[0] = 0.150 * frc;
+      rew[1] = 0.150 * vel;
+      rew[2] = 0.050 * orient;
+      rew[3] = 0.050 * height;
+      rew[4] = 0.450 * step_r;
+      rew[5] = 0.050 * upper;
+      double tot = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        tot += rew[i];
+        p.rew6[6 * (size_t)n + i] = (float)rew[i];
+      }
+      p.reward[n] = (float)tot;
+      p.done[n] = (uint8_t)(si_[O_DONE] != 0);
+      p.st.phase[n] = si_[O_PHASE];
+      p.st.t1[n] = t1;
+      p.st.t2[n] = t2;
+      p.st.reached_frames[n] = si_[O_FRAMES];
+      p.st.target_reached[n] = (uint8_t)reached;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < rows * n_obs; e += 256) {
+    const int r = e / n_obs, c = e - r * n_obs;
+    static_cast<obs_t*>(p.obs)[(size_t)row0 * n_obs + e] = s_obs[r * (MAXOBS + 1) + c];
+  }
+}
+
 __global__ void pd_target_kernel(const A3Dev* __restrict__ m, long total, const float* __restrict__ action,
                                  double* __restrict__ target) {
   const long stride = (long)gridDim.x * blockDim.x;
@@ -319,6 +541,17 @@ int oly_a3_step_strided(oly_ctx* ctx, int N, const oly_a3_inputs* in, const oly_
   a.done = done;
   a.qpos_stride = compact_base ? 4 : ctx->a3_host.nq; a.qpos_off = compact_base ? 0 : 3;
   a.qvel_stride = compact_base ? 3 : ctx->a3_host.nv; a.qvel_off = compact_base ? 0 : 3;
+  // 16 lanes per environment while that fills the chip better than one (OLY_K2_LANES = 1 / 16 forces either kernel)
+  const char* lanes_env = getenv("OLY_K2_LANES");
+  const int force_lanes = lanes_env ? atoi(lanes_env) : 0;
+  const bool lanes16 = force_lanes == 16 || (force_lanes != 1 && N <= K2_LANES16_MAX_N);
+  if (lanes16) {
+    dim3 grid16((N + 15) / 16), block16(256);
+    if (out_flags & OLY_OUT_OBS_F64) hipLaunchKernelGGL(a3_step16_kernel<true>, grid16, block16, 0, oly_s(stream), a);
+    else hipLaunchKernelGGL(a3_step16_kernel<false>, grid16, block16, 0, oly_s(stream), a);
+    OLY_LAUNCH_CHECK(ctx, "a3_step16_kernel");
+    return OLY_OK;
+  }
   const size_t lds = ((out_flags & OLY_OUT_OBS_F64) ? sizeof(double) : sizeof(float)) * THREADS * ctx->a3_host.n_obs;
   dim3 grid((N + THREADS - 1) / THREADS), block(THREADS);
   if (out_flags & OLY_OUT_OBS_F64)
