@@ -20,7 +20,7 @@
 namespace {
 constexpr int THREADS = 128;
 constexpr double PI = 3.141592653589793;
-constexpr int K2_LANES16_MAX_N = 16384;    // up to here the 16-lane kernel wins (measured: tools/bench_kernels.py)
+constexpr int K2_LANES16_MAX_N = 16384;    // up to here the 16-lane kernel wins (tools/time_k2.py, profiles/r03/k2_lane_layouts.csv)
 
 struct A3Args {
   const A3Dev* md;
@@ -243,11 +243,14 @@ __global__ __launch_bounds__(THREADS) void a3_step_kernel(A3Args p) {
 // ---------------------------------------------------------------------------------------------------------------
 // The same step with SIXTEEN lanes per environment (K10's layout) for the sizes a vectorised env.step() really has.
 // One lane per environment is a dependent chain of ~27 fp64 libm calls and ~1100 libm-free fp64 instructions on 128
-// threads per workgroup: 4096 environments are 32 workgroups on 256 CUs and 24 us.  Here a 256-thread workgroup owns
-// 16 environments: the libm-free arithmetic runs as four per-wave tasks (a3_vec_core.h: level1_tasks), every libm
-// call is one lane's job in two rounds regrouped by function across the waves, the observation row is assembled by
-// the environment's 16 lanes.  Same expressions on the same inputs as a3_step_kernel (the arithmetic K10 and K13
-// share): identical results, bit for bit (tests/test_gpu_parity.py forces either kernel onto every A3 test).
+// threads per workgroup: 4096 environments are 32 workgroups on 256 CUs and 13.9 us (16384: 14.9).  Here a
+// 256-thread workgroup owns 16 environments: the libm-free arithmetic runs as four per-wave tasks (a3_vec_core.h:
+// level1_tasks), every libm call is one lane's job in two rounds regrouped by function across the waves, the
+// observation row is assembled by the environment's 16 lanes: 8.4 us at 4096, 12.9 at 16384.  Past that the 37 KB
+// of LDS per 16 environments limits the resident groups and the lane-per-environment kernel is ahead (65536: 23.5 us
+// against 40.7), so oly_a3_step picks by N.  Same expressions on the same inputs as a3_step_kernel (the arithmetic
+// K10 and K13 share): identical results, byte for byte (tests/test_gpu_parity.py: the two kernels against each
+// other, and every K2 test under either).
 template <bool OBS64>
 __global__ __launch_bounds__(256) void a3_step16_kernel(A3Args p) {
   using namespace oly_a3v;

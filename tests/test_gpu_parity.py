@@ -788,7 +788,53 @@ def test_contacts_random(eng, oracle, seed):
 
 
 # --------------------------------------------------------------------------------- K2
-def test_a3_golden_sequence(eng, golden, oracle):
+@pytest.fixture(params=[1, 16])
+def k2_lanes(request, monkeypatch):
+    """oly_a3_step has two kernels, one lane per environment and sixteen (chosen by N; OLY_K2_LANES, read on every
+    call, forces one): every K2 test runs under both."""
+    monkeypatch.setenv("OLY_K2_LANES", str(request.param))
+    return request.param
+
+
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 1000, 4099, 70001])
+@pytest.mark.parametrize("obs_f64", [False, True])
+def test_a3_step_lane_layouts_give_identical_bytes(eng, golden, monkeypatch, N, obs_f64):
+    """The 16-lane kernel evaluates the same expressions on the same inputs as the lane-per-environment kernel:
+    observations, rewards, flags and the task state agree byte for byte (ragged last group, both output types)."""
+    g = golden("a3_task.npz")
+    eng.a3_configure(specs.A3Spec(mass=41.5), g["clock_lut"])
+    rng = np.random.default_rng(N)
+    seq_len = rng.choice([1, 2, 5, 20], N).astype(np.int32)
+    st_h = dict(phase=rng.integers(0, 88, N).astype(np.int32), t1=rng.integers(-1, 21, N).astype(np.int32),
+                t2=rng.integers(-1, 21, N).astype(np.int32), reached_frames=rng.integers(0, 36, N).astype(np.int32),
+                target_reached=rng.integers(0, 2, N).astype(np.uint8), mode=rng.integers(0, 4, N).astype(np.int32),
+                seq_len=seq_len, sequence=rng.normal(0, 0.3, (N, 20, 4)), goal=np.zeros((N, 8)))
+    inp = dict(qpos=rng.normal(0, 1, (N, 25)), qvel=rng.normal(0, 1, (N, 24)), act_len=rng.uniform(-1, 1, (N, 12)),
+               act_vel=rng.normal(0, 2, (N, 12)), lf_pos=rng.normal(0, 0.2, (N, 3)), rf_pos=rng.normal(0, 0.3, (N, 3)),
+               lf_vel=rng.normal(0, 0.2, (N, 3)), rf_vel=rng.normal(0, 0.2, (N, 3)),
+               root_pos=np.array([0, 0, 0.7]) + rng.normal(0, 0.2, (N, 3)), root_quat=rng.normal(0, 1, (N, 4)),
+               head_pos=np.array([0, 0, 1.2]) + rng.normal(0, 0.1, (N, 3)), grf_l=rng.uniform(0, 400, N),
+               grf_r=rng.uniform(0, 400, N), min_z=rng.uniform(-0.01, 0.03, N), n_r=rng.integers(0, 3, N).astype(np.int32),
+               n_l=rng.integers(0, 3, N).astype(np.int32), bad=(rng.uniform(size=N) < 0.1).astype(np.uint8))
+    inp["qpos"][: max(N // 7, 1), 3:7] = [0.5, 0.5, -0.5, 0.5]          # the gimbal branch of quat2euler
+    d_in = {k: dev(v) for k, v in inp.items()}
+    res = {}
+    for lanes in (1, 16):
+        monkeypatch.setenv("OLY_K2_LANES", str(lanes))
+        st_d = {k: dev(v) for k, v in st_h.items()}
+        outs = []
+        for _ in range(3):
+            o = eng.a3_step(d_in, st_d, obs_f64=obs_f64)
+            outs.append({k: host(v).copy() for k, v in o.items()})
+        res[lanes] = (outs, {k: host(v) for k, v in st_d.items()})
+    for a, b in zip(res[1][0], res[16][0]):
+        for k in a:
+            assert a[k].tobytes() == b[k].tobytes(), (k, N)
+    for k in res[1][1]:
+        assert res[1][1][k].tobytes() == res[16][1][k].tobytes(), (k, N)
+
+
+def test_a3_golden_sequence(eng, golden, oracle, k2_lanes):
     g = golden("a3_task.npz")
     spec = specs.A3Spec(mass=float(g["mass"]))
     eng.a3_configure(spec, g["clock_lut"])
@@ -824,7 +870,7 @@ def test_a3_golden_sequence(eng, golden, oracle):
         np.testing.assert_allclose(host(o["obs"]), eo["obs"], rtol=1e-13, atol=1e-14)
 
 
-def test_a3_orientation_analytic_cases(eng, golden):
+def test_a3_orientation_analytic_cases(eng, golden, k2_lanes):
     """transforms3d is absent (parity unpinned): get_obs' quat -> euler -> quat with the yaw dropped
     and update_goal_steps' frame change are pinned on closed-form cases through oly_a3_step
     (helpers.a3_analytic_cases: identity, pure yaw, +-90 deg about each axis, the gimbal branch,
@@ -838,7 +884,7 @@ def test_a3_orientation_analytic_cases(eng, golden):
 
 
 @pytest.mark.parametrize("N", [1500, 4096])
-def test_a3_many_envs_vs_oracle(eng, golden, oracle, N):
+def test_a3_many_envs_vs_oracle(eng, golden, oracle, N, k2_lanes):
     g = golden("a3_task.npz")
     spec = specs.A3Spec(mass=41.5)
     eng.a3_configure(spec, g["clock_lut"])
@@ -874,7 +920,7 @@ def test_a3_many_envs_vs_oracle(eng, golden, oracle, N):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("OLY_FUZZ", "12"))))
-def test_a3_state_machine_random(eng, golden, oracle, seed):
+def test_a3_state_machine_random(eng, golden, oracle, seed, k2_lanes):
     """WalkingTask's integer state machine at its edges: frame counters around the 30-frame delay,
     target indices at the end of short sequences, all walk modes, feet inside / outside the
     target radius; integer state and done bit-exact over several steps."""
