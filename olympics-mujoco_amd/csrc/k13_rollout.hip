@@ -743,6 +743,687 @@ __global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
     }
   }
 }
+
+// ===============================================================================================================
+// The shipped form: ONE 8-wave workgroup per 16 environments, the two halves of the step on DIFFERENT WAVES.
+//
+// In the staged-readback regime the environment step of t does not read action t: the physics that consumed the
+// action has already run, its readback is what is staged (with live physics there is no persistent launch at all:
+// host batcher + K10).  So forward(obs_t) and the environment step that turns readback row t into obs_{t+1} are
+// independent, and the first form's alternation of a matrix phase and a libm phase is not needed: here waves 0-3
+// ("forward") run actor and critic of obs_t while waves 4-7 ("environment") run step t, side by side on the same
+// SIMDs (one wave of each kind per SIMD), meeting once per step.  What that buys over the first form (grid (N / 16, 2),
+// two 4-wave workgroups per tile): the environment step is computed ONCE per tile instead of once per network,
+// the matrix pipes always have a wave with MFMAs to issue, nothing aliases in LDS (no barrier between the phases),
+// no snapshot launch (one workgroup reads and finally overwrites its own tile's state).  s_barrier is workgroup-wide,
+// so both kinds of wave execute the same SIX barriers per step; each role's intervals are placed against the
+// other's (forward: actor L1 | L2 | L3 | critic L1 + actor sampling | L2 | L3; environment: contacts | level 1 |
+// libm round 1 | round-2 arguments | libm round 2 | combination).
+// Arithmetic, stores and final state: exactly the first form's (the tests compare with the two-kernel loop).
+constexpr int THREADS_S = 512;
+constexpr int RTH = 256;                 // threads of one role
+constexpr int OBS_PT_S = (EPW * MAX_NOBS + RTH - 1) / RTH;
+constexpr int IMG = MAX_IN * EPW;        // floats of one input image
+constexpr int PART = KSPLIT * EPW * PPITCH;
+// LDS (bytes): fp64 regions first
+constexpr size_t S_ENV = 0;
+constexpr size_t S_ARG = S_ENV + sizeof(double) * EPW * L_ENV;
+constexpr size_t S_SEQ = S_ARG + sizeof(double) * EPW * SLOTS * 2;
+constexpr size_t S_LUT = S_SEQ + sizeof(double) * EPW * SEQW;
+constexpr size_t S_IMG = S_LUT + sizeof(double) * 4 * OLY_MAX_PERIOD;            // [2 buffers][2 networks][IMG]
+constexpr size_t S_HA = S_IMG + sizeof(float) * 4 * IMG;
+constexpr size_t S_HB = S_HA + sizeof(float) * HID * EPW;
+constexpr size_t S_PART = S_HB + sizeof(float) * HID * EPW;                      // [2 networks][PART]
+constexpr size_t S_PRE = S_PART + sizeof(float) * 2 * PART;
+constexpr size_t S_POST = S_PRE + sizeof(float) * EPW * OBP;                     // [2 buffers][EPW][OBP]
+constexpr size_t S_NORM = S_POST + sizeof(float) * 2 * EPW * OBP;                // [2 networks][mean, std][MAX_IN]
+constexpr size_t S_INT = S_NORM + sizeof(float) * 4 * MAX_IN;
+constexpr size_t S_GB = S_INT + sizeof(int) * EPW * SI_N;
+constexpr size_t S_CLS = S_GB + sizeof(int) * GEOM_LDS;
+constexpr size_t SPLIT_LDS = S_CLS + EPW * SLOTS;
+static_assert(S_IMG % 16 == 0 && S_HA % 16 == 0 && S_HB % 16 == 0 && S_PART % 4 == 0, "image alignment");
+static_assert(SPLIT_LDS <= 160 * 1024, "one workgroup per CU");
+
+template <int G1>      // groups of layer 1: 3 (inputs <= 48) or 4
+__global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+  double* s_env = reinterpret_cast<double*>(lds8 + S_ENV);      // [EPW][L_ENV]
+  double* s_arg = reinterpret_cast<double*>(lds8 + S_ARG);      // [EPW][SLOTS][2]
+  double* seqs = reinterpret_cast<double*>(lds8 + S_SEQ);       // [EPW][SEQW]   step sequences, whole rollout
+  double* s_lut = reinterpret_cast<double*>(lds8 + S_LUT);      // [4][period]   clock LUT
+  float* s_img = reinterpret_cast<float*>(lds8 + S_IMG);        // input images of the two networks, double-buffered
+  float* hA = reinterpret_cast<float*>(lds8 + S_HA);
+  float* hB = reinterpret_cast<float*>(lds8 + S_HB);
+  float* s_part = reinterpret_cast<float*>(lds8 + S_PART);      // output-layer partial tiles [network][chain][row][col]
+  float* s_pre = reinterpret_cast<float*>(lds8 + S_PRE);        // [EPW][OBP]    observation before a reset
+  float* s_post = reinterpret_cast<float*>(lds8 + S_POST);      // [2][EPW][OBP] observation the policy sees
+  float* s_norm = reinterpret_cast<float*>(lds8 + S_NORM);
+  int* s_int = reinterpret_cast<int*>(lds8 + S_INT);            // [EPW][SI_N]
+  int* s_gb = reinterpret_cast<int*>(lds8 + S_GB);              // [ngeom]       geom -> body
+  uint8_t* s_cls = lds8 + S_CLS;                                // [EPW][SLOTS]
+
+  const A3Dev* __restrict__ m = p.md;
+  const int nu = m->nu, n_obs = m->n_obs, period = m->period, nq = m->nq, nv = m->nv;
+  const int N = p.N, T = p.ro.T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 8);      // 0: forward waves, 1: environment waves
+  const int rtid = tid & (RTH - 1);
+  const int wq = __builtin_amdgcn_readfirstlane(rtid >> 6);        // wave of the role
+  const int row0 = blockIdx.x * EPW;
+  const int rows = min(EPW, N - row0);
+  const bool det = p.ro.deterministic != 0;
+  const PackLayout L = pack_layout(p.in_dim, 1);      // (the offsets do not depend on the output width)
+  const int t0 = p.ro.ctr[2 * blockIdx.x];
+  const int k0 = p.ro.ctr[2 * blockIdx.x + 1];
+  if (t0 < 0 || t0 > T) {     // counters the caller never rewound: K10's rule (no write, sticky mark behind the counters)
+    if (threadIdx.x == 0) p.ro.ctr[2 * ((N + 15) / 16)] = 1;
+    return;
+  }
+  const int skip = p.skip;
+
+  // ---------------------------------------------------------------- prologue (all 512 threads)
+  for (int i = tid; i < 4 * IMG; i += THREADS_S) s_img[i] = 0.f;
+  for (int i = tid; i < 4 * MAX_IN; i += THREADS_S) {
+    const int net = i / (2 * MAX_IN), which = (i / MAX_IN) & 1, k = i & (MAX_IN - 1);
+    float v = which ? 1.f : 0.f;
+    if (p.normalize[net] && k < p.in_dim) v = p.packed[net][(which ? L.std : L.mean) + k];
+    s_norm[i] = v;
+  }
+  for (int i = tid; i < 4 * period; i += THREADS_S) s_lut[i] = m->clock_lut[i];
+  const bool gb_lds = p.cd.ngeom <= GEOM_LDS;
+  if (gb_lds)
+    for (int i = tid; i < p.cd.ngeom; i += THREADS_S) s_gb[i] = p.cd.geom_bodyid[i];
+  for (int e = tid; e < rows * n_obs; e += THREADS_S) {
+    const int r = e / n_obs, c = e - r * n_obs;
+    s_post[r * OBP + c] = p.ro.state[(size_t)row0 * n_obs + e];
+  }
+  __syncthreads();
+  for (int e = tid; e < 2 * rows * n_obs; e += THREADS_S) {      // the first input images
+    const int net = e / (rows * n_obs), e1 = e - net * rows * n_obs;
+    const int r = e1 / n_obs, c = e1 - r * n_obs;
+    float v = s_post[r * OBP + c];
+    if (p.normalize[net]) v = (v - s_norm[(2 * net) * MAX_IN + c]) / s_norm[(2 * net + 1) * MAX_IN + c];
+    s_img[net * IMG + act16_index(c, r)] = v;
+  }
+
+  if (role == 0) {
+    // ============================================================================================ forward waves
+    const float* __restrict__ PA = p.packed[0];
+    const float* __restrict__ PC = p.packed[1];
+    int ob_src[OBS_PT_S];
+#pragma unroll
+    for (int q = 0; q < OBS_PT_S; ++q) {
+      const int e = rtid + q * RTH, r = e / n_obs;
+      ob_src[q] = r * OBP + (e - r * n_obs);
+    }
+    const int a_row = rtid / nu, a_col = rtid - a_row * nu;      // actor output element this thread finishes
+    const bool a_ok = rtid < rows * nu;
+    const float a_bias = a_ok ? PA[L.b3 + a_col] : 0.f;
+    const float a_scale = (a_ok && !det) ? p.ro.scale[a_col] : 0.f;
+    const bool c_ok = rtid < rows;                               // critic: one value per row
+    const float c_bias = PC[L.b3];
+    float eps_next = 0.f;
+    if (a_ok && !det && t0 < T) eps_next = p.ro.eps[((size_t)t0 * N + row0) * nu + rtid];
+    float* partA = s_part;
+    float* partC = s_part + PART;
+    auto critic_out = [&](int t) {       // the value of step t from the partial tiles (bias last)
+      float s = partC[rtid * PPITCH];
+#pragma unroll
+      for (int w = 1; w < KSPLIT; ++w) s += partC[(w * EPW + rtid) * PPITCH];
+      s += c_bias;
+      p.ro.buf_values[(size_t)t * N + row0 + rtid] = s;
+      if (t == T - 1 && p.value_out) p.value_out[row0 + rtid] = s;
+    };
+    __syncthreads();
+    int it = 0;
+    for (int t = t0; t < T; ++t, ++it) {
+      const size_t tN = (size_t)t * N;
+      const bool last_step = t == T - 1;
+      const int buf = it & 1;
+      // (see the first form: opaque copies keep loop-invariant weight loads and addresses from being hoisted and spilled)
+      int opaque0 = 0;
+      asm volatile("" : "+s"(opaque0));
+      const float* Pa = PA + opaque0;
+      const float* Pc = PC + opaque0;
+      const float4* Pa4 = reinterpret_cast<const float4*>(Pa);
+      const float4* Pc4 = reinterpret_cast<const float4*>(Pc);
+      int rtid_t = rtid;
+      asm volatile("" : "+v"(rtid_t));
+      const float* xA = s_img + (2 * buf) * IMG;
+      const float* xC = s_img + (2 * buf + 1) * IMG;
+      const float* obs_rows = s_post + buf * EPW * OBP;
+      const bool run_mlp = !(skip & 1);
+
+      // ---- interval 1: the value of the step before (its partial tiles are complete since the last barrier);
+      // memory.store(state, ...) (ppo.py:186); actor layer 1
+      if (it > 0 && c_ok) critic_out(t - 1);
+#pragma unroll
+      for (int q = 0; q < OBS_PT_S; ++q) {
+        const int e = rtid + q * RTH;
+        if (e < rows * n_obs) p.ro.buf_states[(tN + row0) * n_obs + rtid_t + q * RTH] = obs_rows[ob_src[q]];
+      }
+      const float eps_t = eps_next;
+      if (!last_step && a_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + rtid_t];
+      if (run_mlp) {
+        f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+        const float4* base = Pa4 + (L.w1n >> 2) + (size_t)(4 * wq) * G1N * 64;
+        const float4* const w[4] = {base, base + G1N * 64, base + 2 * G1N * 64, base + 3 * G1N * 64};
+        layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xA), w, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_relu16(acc[q], Pa + L.b1, 4 * wq + q, lane, hA);
+      }
+      __syncthreads();
+      if (run_mlp) {  // ---- interval 2: actor layer 2
+        f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+        const float4* base = Pa4 + (L.w2n >> 2) + (size_t)(4 * wq) * (HID / 16) * 64;
+        const float4* const w[4] = {base, base + (HID / 16) * 64, base + 2 * (HID / 16) * 64, base + 3 * (HID / 16) * 64};
+        layer_tiles16<HID / 16, 4>(reinterpret_cast<const float4*>(hA), w, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_relu16(acc[q], Pa + L.b2, 4 * wq + q, lane, hB);
+      }
+      __syncthreads();
+      if (run_mlp) {  // ---- interval 3: actor output layer as eight partial chains; wave w runs chains 2 w, 2 w + 1
+        const int c = lane & 15, h2 = lane >> 4;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * wq + jj;
+          f32x4 acc[1] = {{0}};
+          const float4* const w[1] = {Pa4 + (L.w3n >> 2) + (size_t)(2 * j) * 64};
+          layer_tiles16<2, 1>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * j) * 64, w, lane, acc);
+          float* part = partA + (size_t)j * EPW * PPITCH;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + c] = acc[0][i];
+        }
+      }
+      __syncthreads();
+      // ---- interval 4: critic layer 1, then the actor's sampling (its partial tiles are complete)
+      if (run_mlp) {
+        f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+        const float4* base = Pc4 + (L.w1n >> 2) + (size_t)(4 * wq) * G1N * 64;
+        const float4* const w[4] = {base, base + G1N * 64, base + 2 * G1N * 64, base + 3 * G1N * 64};
+        layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xC), w, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_relu16(acc[q], Pc + L.b1, 4 * wq + q, lane, hA);
+      }
+      if (a_ok) {
+        float s = partA[a_row * PPITCH + a_col];
+#pragma unroll
+        for (int w = 1; w < KSPLIT; ++w) s += partA[(w * EPW + a_row) * PPITCH + a_col];
+        s += a_bias;
+        // Normal(mu, std * anneal).sample() from the pre-drawn noise (ppo.py:181), memory.store's action and the
+        // PD target the physics would receive (robot.py:88-95)
+        float a = s;
+        if (!det) {
+          const float scl = a_scale * eps_t;
+          a = s + scl;
+        }
+        p.ro.buf_actions[(tN + row0) * nu + rtid_t] = a;
+        if (last_step) {
+          p.ro.pd_target[(size_t)row0 * nu + rtid_t] = (double)a + m->motor_offset[a_col];
+          if (p.mu_out) p.mu_out[(size_t)row0 * nu + rtid_t] = s;
+        }
+      }
+      __syncthreads();
+      if (run_mlp) {  // ---- interval 5: critic layer 2
+        f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+        const float4* base = Pc4 + (L.w2n >> 2) + (size_t)(4 * wq) * (HID / 16) * 64;
+        const float4* const w[4] = {base, base + (HID / 16) * 64, base + 2 * (HID / 16) * 64, base + 3 * (HID / 16) * 64};
+        layer_tiles16<HID / 16, 4>(reinterpret_cast<const float4*>(hA), w, lane, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_relu16(acc[q], Pc + L.b2, 4 * wq + q, lane, hB);
+      }
+      __syncthreads();
+      if (run_mlp) {  // ---- interval 6: critic output layer
+        const int c = lane & 15, h2 = lane >> 4;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * wq + jj;
+          f32x4 acc[1] = {{0}};
+          const float4* const w[1] = {Pc4 + (L.w3n >> 2) + (size_t)(2 * j) * 64};
+          layer_tiles16<2, 1>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * j) * 64, w, lane, acc);
+          float* part = partC + (size_t)j * EPW * PPITCH;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + c] = acc[0][i];
+        }
+      }
+      __syncthreads();     // obs_{t+1} and its images are complete (environment waves)
+    }
+    if (t0 < T && c_ok) critic_out(T - 1);
+    return;
+  }
+
+  // ============================================================================================== environment waves
+  const int grp = lane >> 4, slot = lane & (SLOTS - 1);
+  const int el = wq * 4 + grp;
+  const int n = row0 + el;
+  const bool env_ok = n < N;
+  const int C = p.b.C;
+  const int passes = (C + SLOTS - 1) / SLOTS;
+  double* se = s_env + el * L_ENV;
+  double* sq = seqs + el * SEQW;
+  // ---- task state: registers for the whole rollout
+  int phase0 = 0, t1 = 0, t2 = 0, frames = 0, mode = OLY_MODE_STANDING, seq_len = 1, tlen = 0, rc = 0, sc = 0;
+  int reached_last = 0;
+  double goal_last = 0.0;
+  if (env_ok) {
+    phase0 = p.st.phase[n];
+    t1 = p.st.t1[n];
+    t2 = p.st.t2[n];
+    frames = p.st.reached_frames[n];
+    reached_last = p.st.target_reached[n];
+    mode = p.st.mode[n];
+    seq_len = p.st.seq_len[n];
+    tlen = p.ro.traj_len[n];
+    rc = p.ro.pool_count[n];
+    sc = p.ro.side_count[n];
+    if (slot < 8) goal_last = p.st.goal[8 * (size_t)n + slot];
+#pragma unroll
+    for (int q = 0; q < SEQW / SLOTS; ++q) sq[slot + SLOTS * q] = p.st.sequence[(size_t)n * SEQW + slot + SLOTS * q];
+  }
+  t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
+  t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
+  const double gear_s = slot < nu ? m->gear[slot] : 1.0;
+  int dst_b = -1;
+  if (slot < 3) dst_b = L_LV + slot;
+  else if (slot < 6) dst_b = L_RV + slot - 3;
+  else if (slot < 10) dst_b = L_BQ + slot - 6;
+  else if (slot < 13) dst_b = L_AV + slot - 10;
+  auto request = [&](int k, int n, int slot, Readback& rb) {
+    rb.nc_raw = 0; rb.g1_0 = -1; rb.g2_0 = -1;
+    rb.va = rb.vb = rb.v_len = rb.v_vel = rb.pz0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rb.f0[q] = 0.0;
+    if (!env_ok) return;
+    const size_t kN = (size_t)((unsigned)k % (unsigned)p.b.K) * N;
+    rb.nc_raw = p.b.ncon[kN + n];
+    const size_t r3 = (kN + n) * 3, r4 = (kN + n) * 4;
+    if (slot < 4) rb.va = p.b.root_quat[r4 + slot];
+    else if (slot < 7) rb.va = p.b.root_pos[r3 + slot - 4];
+    else if (slot < 10) rb.va = p.b.head_pos[r3 + slot - 7];
+    else if (slot < 13) rb.va = p.b.lf_pos[r3 + slot - 10];
+    else rb.va = p.b.rf_pos[r3 + slot - 13];
+    if (slot < 3) rb.vb = p.b.lf_vel[r3 + slot];
+    else if (slot < 6) rb.vb = p.b.rf_vel[r3 + slot - 3];
+    else if (slot < 10) rb.vb = p.b.qpos[(kN + n) * nq + 3 + slot - 6];
+    else if (slot < 13) rb.vb = p.b.qvel[(kN + n) * nv + 3 + slot - 10];
+    if (slot < nu) {
+      rb.v_len = p.b.act_len[(kN + n) * nu + slot];
+      rb.v_vel = p.b.act_vel[(kN + n) * nu + slot];
+    }
+    if (slot < C) {
+      const size_t e0 = (kN + n) * C + slot;
+      rb.g1_0 = p.b.geom1[e0];
+      rb.g2_0 = p.b.geom2[e0];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rb.f0[q] = p.b.force6[e0 * 6 + q];
+      rb.pz0 = p.b.cpos_z[e0];
+    }
+  };
+  Readback rb;
+  request(k0, n, slot, rb);
+  __syncthreads();
+
+  int it = 0;
+  for (int t = t0; t < T; ++t, ++it) {
+    const size_t tN = (size_t)t * N;
+    const bool last_step = t == T - 1;
+    const int nbuf = (it & 1) ^ 1;          // the buffer obs_{t+1} goes to
+    int n_t = n, slot_t = slot;
+    asm volatile("" : "+v"(n_t), "+v"(slot_t));
+    if (skip & 2) {
+      __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+      continue;
+    }
+    // ---- interval 1: the readback row into the scratch; K3: foot contacts
+    if (env_ok) {
+      se[slot] = rb.va;
+      if (dst_b >= 0) se[dst_b] = rb.vb;
+      if (slot < nu) {
+        se[L_AL + slot] = rb.v_len;
+        se[L_AVL + slot] = rb.v_vel;
+      }
+    }
+    const int nc_raw = rb.nc_raw;
+    const int nc = min(max(nc_raw, 0), C);
+    int cnt_r = 0, cnt_l = 0;
+    double sum_r = 0.0, sum_l = 0.0, mz = 0.0;
+    bool have = false;
+    for (int ps = 0; ps < passes; ++ps) {
+      const int i = ps * SLOTS + slot;
+      bool is_r = false, is_l = false;
+      double nrm = 0.0, pz = 0.0;
+      if (env_ok && i < nc) {
+        int g1 = rb.g1_0, g2 = rb.g2_0;
+        double f[6] = {rb.f0[0], rb.f0[1], rb.f0[2], rb.f0[3], rb.f0[4], rb.f0[5]};
+        pz = rb.pz0;
+        if (ps > 0) {            // more than 16 contact slots: the later passes load on demand
+          const size_t kN = (size_t)((unsigned)(k0 + (t - t0)) % (unsigned)p.b.K) * N;
+          const size_t e = (kN + n_t) * C + i;
+          g1 = p.b.geom1[e];
+          g2 = p.b.geom2[e];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) f[q] = p.b.force6[e * 6 + q];
+          pz = p.b.cpos_z[e];
+        }
+        if (g1 >= 0 && g1 < p.cd.ngeom && g2 >= 0 && g2 < p.cd.ngeom) {
+          const int b1 = gb_lds ? s_gb[g1] : p.cd.geom_bodyid[g1], b2 = gb_lds ? s_gb[g2] : p.cd.geom_bodyid[g2];
+          is_r = (b1 == p.cd.floor_body) && (b2 == p.cd.rfoot_body);
+          is_l = (b1 == p.cd.floor_body) && (b2 == p.cd.lfoot_body);
+        }
+        if (is_r || is_l) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) s += f[q] * f[q];
+          nrm = sqrt(s);
+        } else {
+          pz = 0.0;
+        }
+      }
+      const unsigned long long br = __ballot(is_r), bl = __ballot(is_l);
+      const unsigned mr = (unsigned)((br >> (grp * SLOTS)) & 0xffffu);
+      const unsigned ml = (unsigned)((bl >> (grp * SLOTS)) & 0xffffu);
+      cnt_r += __popc(mr);
+      cnt_l += __popc(ml);
+      // In-order chain over the matching slots (contact order), as contact_kernel / K10: ((0 + n_a) + n_b) + ...
+      // Every lane parks its norm / height in the environment's scratch row (same wave: LDS operations of a wave
+      // complete in order, no barrier needed) and each lane runs the chain over the 16 slots from LDS broadcasts.
+      double* cn = se + L_R1;            // [16] norms, [16] heights: the libm result rows, unused until round 1
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (a later pass overwrites what this one read)
+      cn[slot] = nrm;
+      cn[SLOTS + slot] = pz;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned any = mr | ml;
+#pragma unroll
+      for (int q = 0; q < SLOTS; ++q) {
+        const double vk = cn[q], zk = cn[SLOTS + q];
+        if ((any >> q) & 1u) {
+          if ((mr >> q) & 1u) sum_r += vk;
+          if ((ml >> q) & 1u) sum_l += vk;
+          if (!have || zk < mz) mz = zk;
+          have = true;
+        }
+      }
+    }
+    const double grf_r = sum_r, grf_l = sum_l;
+    const double min_z = have ? mz : 0.0;
+    const bool bad = (cnt_r + cnt_l) != nc_raw;
+    // this step's readback registers are consumed: request step t + 1's rows now, a whole step ahead of their use
+    if (!last_step) request(k0 + (t + 1 - t0), n_t, slot_t, rb);
+    if (env_ok && slot == 0) {
+      int* si = s_int + el * SI_N;
+      si[I_PHASE0] = phase0; si[I_T1] = t1; si[I_T2] = t2; si[I_FRAMES] = frames; si[I_MODE] = mode;
+      si[I_SEQLEN] = seq_len; si[I_TLEN] = tlen; si[I_RC] = rc; si[I_BAD] = bad; si[I_HAVEC] = (cnt_r > 0 || cnt_l > 0);
+      se[L_GR] = grf_r; se[L_GL] = grf_l; se[L_MZ] = min_z;
+    }
+    __syncthreads();
+
+    // ---- interval 2: level 1, everything without libm, as four tasks, one per wave (a3_vec_core.h)
+    {
+      Level1Ctx lc;
+      lc.m = m; lc.s_env = s_env; lc.seqs = seqs; lc.s_int = s_int; lc.s_arg = s_arg; lc.s_cls = s_cls; lc.s_lut = s_lut;
+      lc.period = period; lc.rows = rows; lc.last_step = last_step; lc.max_traj_len = p.ro.max_traj_len;
+      lc.pool = p.ro.pool; lc.pool_depth = p.ro.pool_depth; lc.row0 = row0;
+      level1_tasks(lc, wq, lane);
+    }
+    __syncthreads();
+    double r0, r1;
+    const int ee = lane & 15;
+    {  // ---- interval 3: libm round 1, regrouped by function
+      constexpr int R1_TASK[4][4] = {{0, 1, 6, 13}, {2, 3, 4, 5}, {7, 8, 9, 10}, {11, 12, 14, -1}};
+      const int task = R1_TASK[wq][lane >> 4];
+      if (task >= 0) {
+        eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
+        s_env[ee * L_ENV + L_R1 + 2 * task] = r0;
+        s_env[ee * L_ENV + L_R1 + 2 * task + 1] = r1;
+      }
+    }
+    __syncthreads();
+
+    // ---- interval 4: back on the environment's own lanes; round-2 arguments
+    const int* si_ = s_int + el * SI_N;
+    const int phase = si_[O_PHASE];
+    const int reached = si_[O_REACHED];
+    t1 = si_[O_T1];
+    t2 = si_[O_T2];
+    frames = si_[O_FRAMES];
+    const bool done = si_[O_DONE] != 0, cut = si_[O_CUT] != 0;
+    const bool need_reset = env_ok && si_[O_RESET] != 0;
+    const int new_mode = si_[O_NEWMODE], new_phase = si_[O_NEWPHASE], new_len = si_[O_NEWLEN];
+    const int len = tlen + 1;
+    const bool walking = mode != OLY_MODE_STANDING;
+    const double rq0 = se[L_RQ], rq1 = se[L_RQ + 1], rq2 = se[L_RQ + 2], rq3 = se[L_RQ + 3];
+    const double rp0 = se[L_RP], rp1 = se[L_RP + 1], rp2 = se[L_RP + 2];
+    const double lf0 = se[L_LF], lf1 = se[L_LF + 1];
+    const double rf0 = se[L_RF], rf1 = se[L_RF + 1];
+    double R[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[i][j] = se[L_ROT + 3 * i + j];
+    double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (walking) {
+      const int selA = 4 * t1, selB = 4 * t2;   // sequence[t1] / sequence[t2] after the update
+      const double s1x = sq[selA], s1y = sq[selA + 1], s1z = sq[selA + 2];
+      const double s2x = sq[selB], s2y = sq[selB + 1], s2z = sq[selB + 2];
+      const double a0 = s1x - rp0, a1 = s1y - rp1, a2 = s1z - rp2;
+      const double b0 = s2x - rp0, b1 = s2y - rp1, b2 = s2z - rp2;
+      goal[0] = R[0][0] * a0 + R[1][0] * a1 + R[2][0] * a2;
+      goal[2] = R[0][1] * a0 + R[1][1] * a1 + R[2][1] * a2;
+      goal[4] = R[0][2] * a0 + R[1][2] * a1 + R[2][2] * a2;
+      goal[1] = R[0][0] * b0 + R[1][0] * b1 + R[2][0] * b2;
+      goal[3] = R[0][1] * b0 + R[1][1] * b1 + R[2][1] * b2;
+      goal[5] = R[0][2] * b0 + R[1][2] * b1 + R[2][2] * b2;
+    }
+    // env.reset(): the rows of the next pool record (its header went through level-1 task 1); needed after round 2 only
+    double rec_seq[(OLY_MAX_SEQ + SLOTS - 1) / SLOTS][4];
+#pragma unroll
+    for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q)
+      rec_seq[q][0] = rec_seq[q][1] = rec_seq[q][2] = rec_seq[q][3] = 0.0;
+    if (need_reset) {
+      const oly_a3_reset_record* rec = p.ro.pool + (size_t)n_t * p.ro.pool_depth + (unsigned)rc % (unsigned)p.ro.pool_depth;
+#pragma unroll
+      for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
+        const int r = slot + SLOTS * q;
+        if (r < OLY_MAX_SEQ) {
+          rec_seq[q][0] = rec->seq[r][0]; rec_seq[q][1] = rec->seq[r][1];
+          rec_seq[q][2] = rec->seq[r][2]; rec_seq[q][3] = rec->seq[r][3];
+        }
+      }
+    }
+    const double root_yaw = se[L_R1 + 2 * 14];
+    {
+      int cls = F_NONE;
+      double a = 0.0, b = 0.0;
+      switch (slot) {
+        case 0:
+        case 1:
+          if (walking) {   // theta = mat2euler(R^T Rz(yaw))[2] = atan2(M10, M00)
+            const double c = se[L_R1 + 2 * slot + 1], sn = se[L_R1 + 2 * slot];
+            cls = F_ATAN2;
+            a = R[0][1] * c + R[1][1] * sn;
+            b = R[0][0] * c + R[1][0] * sn;
+          }
+          break;
+        case 2: {          // body orientation: exp(-10 (1 - <q_ref, q>^2))
+          const double tq0 = se[L_R1 + 2 * 6 + 1], tq3 = se[L_R1 + 2 * 6];
+          const double ip = tq0 * rq0 + 0.0 * rq1 + 0.0 * rq2 + tq3 * rq3;
+          cls = F_EXP;
+          a = -(10 * (1 - ip * ip));
+        } break;
+        case 3: cls = F_SINCOS; a = se[L_R1 + 2 * 11] / 2.0; break;                    // roll / 2
+        case 4: cls = F_SINCOS; a = se[L_R1 + 2 * 12] / 2.0; break;                    // pitch / 2
+        case 5: if (need_reset) { cls = F_SINCOS; a = root_yaw; } break;               // transform_sequence rotation
+        default: break;
+      }
+      if (slot < 6) {
+        s_arg[(el * SLOTS + slot) * 2] = a;
+        s_arg[(el * SLOTS + slot) * 2 + 1] = b;
+        s_cls[el * SLOTS + slot] = (uint8_t)(env_ok ? cls : F_NONE);
+      }
+    }
+    __syncthreads();
+    {  // ---- interval 5: libm round 2.  wave 0: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's
+       // clock-after-reset, slot 15, which only needed level-1 values); wave 1: atan2; wave 2: exp; wave 3: idle
+      constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
+      const int task = R2_TASK[wq][lane >> 4];
+      if (task >= 0) {
+        eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
+        const int dst = task == 15 ? L_R1 + 2 * 15 : L_R2 + 2 * task;
+        s_env[ee * L_ENV + dst] = r0;
+        s_env[ee * L_ENV + dst + 1] = r1;
+      }
+    }
+    __syncthreads();
+
+    // ---- interval 6: combination: observation rows and the next input images, rewards, flags, reset
+    float* op = s_pre + el * OBP;
+    float* oq = s_post + (nbuf * EPW + el) * OBP;
+    if (env_ok) {
+      if (walking) {
+        goal[6] = se[L_R2 + 0];
+        goal[7] = se[L_R2 + 2];
+      }
+      const double ci = se[L_R2 + 2 * 3 + 1], si = se[L_R2 + 2 * 3], cj = se[L_R2 + 2 * 4 + 1], sj = se[L_R2 + 2 * 4];
+      if (slot == 0) op[0] = (float)(ci * cj);
+      if (slot == 1) op[1] = (float)(si * cj);
+      if (slot == 2) op[2] = (float)(ci * sj);
+      if (slot == 3) op[3] = (float)(-(si * sj));
+      if (slot >= 4 && slot < 7) op[slot] = (float)se[L_AV + slot - 4];
+      if (slot < nu) {
+        const double g = gear_s;
+        op[7 + slot] = (float)(se[L_AL + slot] / g);
+        op[7 + nu + slot] = (float)(se[L_AVL + slot] / g);
+      }
+      if (slot == 7) op[7 + 2 * nu] = (float)se[L_R1 + 2 * 13];
+      if (slot == 8) op[8 + 2 * nu] = (float)se[L_R1 + 2 * 13 + 1];
+      if (slot >= 8) op[9 + 2 * nu + slot - 8] = (float)goal[slot - 8];
+    }
+    wave_lds_fence();       // the observation row of an environment is assembled and re-read by its own lanes
+    if (env_ok) {
+      float* imgA = s_img + (2 * nbuf) * IMG;
+      float* imgC = s_img + (2 * nbuf + 1) * IMG;
+      for (int c = slot; c < n_obs; c += SLOTS) {
+        float v = op[c];
+        if (need_reset) {   // get_obs of the freshly reset task: goal steps zero, clock of the drawn phase
+          if (c == 7 + 2 * nu) v = (float)se[L_R1 + 2 * 15];
+          else if (c == 8 + 2 * nu) v = (float)se[L_R1 + 2 * 15 + 1];
+          else if (c >= 9 + 2 * nu) v = 0.0f;
+        }
+        oq[c] = v;
+        // the input images of the next forward (K11's staging: normalise, k-major A-operand layout)
+        float va = v, vc = v;
+        if (p.normalize[0]) va = (v - s_norm[c]) / s_norm[MAX_IN + c];
+        if (p.normalize[1]) vc = (v - s_norm[2 * MAX_IN + c]) / s_norm[3 * MAX_IN + c];
+        const int ix = act16_index(c, el);
+        imgA[ix] = va;
+        imgC[ix] = vc;
+      }
+      // ---- rewards, flags
+      if (slot == 0) {
+        const double frc = (se[L_R1 + 2 * 2] + se[L_R1 + 2 * 3]) / 2;
+        const double vel = (se[L_R1 + 2 * 4] + se[L_R1 + 2 * 5]) / 2;
+        const double orient = se[L_R2 + 2 * 2];
+        const double height = se[L_R1 + 2 * 7];
+        const double hit = reached ? se[L_R1 + 2 * 8] : 0.0;
+        const double progress = se[L_R1 + 2 * 9];
+        const double step_r = 0.8 * hit + 0.2 * progress;
+        const double upper = se[L_R1 + 2 * 10];
+        double rew[6];
+        rew[0] = 0.150 * frc;
+        rew[1] = 0.150 * vel;
+        rew[2] = 0.050 * orient;
+        rew[3] = 0.050 * height;
+        rew[4] = 0.450 * step_r;
+        rew[5] = 0.050 * upper;
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          tot += rew[i];
+          if (p.ro.buf_rew6) p.ro.buf_rew6[(tN + n_t) * 6 + i] = (float)rew[i];
+        }
+        p.ro.buf_rewards[tN + n_t] = tot;
+        p.ro.buf_flags[tN + n_t] = (uint8_t)((cut ? OLY_FLAG_LAST : 0) | (done ? OLY_FLAG_ABSORBING : 0));
+      }
+      // bootstrap row: finish_path's last_val = (not done) * V(state) needs V of THIS observation
+      if (cut && !done) {
+        if (sc < p.ro.side_slots) {
+          const size_t srow = (size_t)n_t * p.ro.side_slots + sc;
+          for (int c = slot; c < n_obs; c += SLOTS) p.ro.side_obs[srow * n_obs + c] = op[c];
+          if (slot == 0) p.ro.side_t[srow] = t;
+        }
+        sc += 1;
+      }
+      tlen = cut ? 0 : len;
+      if (need_reset) {
+        // WalkingTask.reset (walking_task.py:321-397) + transform_sequence (:113-135)
+        const double cyw = se[L_R2 + 2 * 5 + 1], syw = se[L_R2 + 2 * 5];
+        const double mid0 = (lf0 + rf0) / 2, mid1 = (lf1 + rf1) / 2;
+#pragma unroll
+        for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
+          const int r = slot + SLOTS * q;
+          if (r >= OLY_MAX_SEQ) continue;
+          double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+          if (r < new_len) {
+            const double x = rec_seq[q][0], y = rec_seq[q][1], z = rec_seq[q][2], th = rec_seq[q][3];
+            o0 = mid0 + x * cyw - y * syw;
+            o1 = mid1 + x * syw + y * cyw;
+            o2 = z;
+            o3 = root_yaw + th;
+          }
+          sq[4 * r] = o0; sq[4 * r + 1] = o1; sq[4 * r + 2] = o2; sq[4 * r + 3] = o3;
+        }
+        phase0 = new_phase;
+        t1 = 0;
+        t2 = (new_len == 1) ? 0 : 1;        // t1 = t2 = 0, then update_target_steps
+        frames = 0;
+        reached_last = 0;
+        mode = new_mode;
+        seq_len = new_len;
+        rc += 1;
+        goal_last = 0.0;
+      } else {
+        phase0 = phase;
+        reached_last = reached;
+        if (slot < 8) goal_last = goal[slot];
+      }
+    }
+    __syncthreads();     // obs_{t+1} and its images are complete; the forward's partial tiles too
+  }
+
+  // ---------------------------------------------------------------- the rollout is over: leave the state K10 would
+  if (t0 >= T) return;
+  if (env_ok) {
+    if (slot == 0) {
+      p.st.phase[n] = phase0;
+      p.st.t1[n] = t1;
+      p.st.t2[n] = t2;
+      p.st.reached_frames[n] = frames;
+      p.st.target_reached[n] = (uint8_t)reached_last;
+      const_cast<int32_t*>(p.st.mode)[n] = mode;
+      const_cast<int32_t*>(p.st.seq_len)[n] = seq_len;
+      p.ro.traj_len[n] = tlen;
+      p.ro.pool_count[n] = rc;
+      p.ro.side_count[n] = sc;
+    }
+    if (slot < 8) p.st.goal[8 * (size_t)n + slot] = goal_last;
+    double* seq_out = const_cast<double*>(p.st.sequence) + (size_t)n * SEQW;
+#pragma unroll
+    for (int q = 0; q < SEQW / SLOTS; ++q) seq_out[slot + SLOTS * q] = sq[slot + SLOTS * q];
+  }
+  {
+    const float* fin = s_post + (it & 1) * EPW * OBP;      // the buffer the last step wrote
+    for (int e = rtid; e < rows * n_obs; e += RTH) {
+      const int r = e / n_obs, c = e - r * n_obs;
+      p.ro.state[(size_t)row0 * n_obs + e] = fin[r * OBP + c];
+    }
+  }
+  if (rtid == 0) {
+    p.ro.ctr[2 * blockIdx.x] = T;
+    p.ro.ctr[2 * blockIdx.x + 1] = k0 + (T - t0);
+  }
+}
 }  // namespace
 
 extern "C" int64_t oly_a3_rollout_scratch_bytes(int N, int n_obs) {
@@ -826,6 +1507,21 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
   }
   static const int skip = [] { const char* e = getenv("OLY_K13_SKIP"); return e ? atoi(e) : 0; }();
   a.skip = skip;
+  static const int form = [] { const char* e = getenv("OLY_K13_FORM"); return e ? atoi(e) : 0; }();
+  if (form != 1) {
+    if (!ctx->roll_split_attr_done) {
+      OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_split_kernel<3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS));
+      OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_split_kernel<4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS));
+      ctx->roll_split_attr_done = true;
+    }
+    const dim3 grid_s((N + EPW - 1) / EPW);
+    if (in_dim <= 48) hipLaunchKernelGGL(a3_rollout_split_kernel<3>, grid_s, dim3(THREADS_S), SPLIT_LDS, oly_s(stream), a);
+    else hipLaunchKernelGGL(a3_rollout_split_kernel<4>, grid_s, dim3(THREADS_S), SPLIT_LDS, oly_s(stream), a);
+    OLY_LAUNCH_CHECK(ctx, "a3_rollout_split_kernel");
+    return OLY_OK;
+  }
   const dim3 grid((N + EPW - 1) / EPW, 2);
   if (in_dim <= 48) hipLaunchKernelGGL(a3_rollout_kernel<3>, grid, dim3(THREADS), ROLL_LDS, oly_s(stream), a);
   else hipLaunchKernelGGL(a3_rollout_kernel<4>, grid, dim3(THREADS), ROLL_LDS, oly_s(stream), a);
