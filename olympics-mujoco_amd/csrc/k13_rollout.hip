@@ -49,10 +49,13 @@ using oly_mlp::f32x4;
 using oly_mlp::G1N;
 using oly_mlp::HID;
 using oly_mlp::layer_tiles16;
+using oly_mlp::layer_tiles16p;
+using oly_mlp::preload_tiles16;
 using oly_mlp::MAX_IN;
 using oly_mlp::pack_layout;
 using oly_mlp::PackLayout;
 using oly_mlp::store_relu16;
+using oly_mlp::store_relu16v;
 
 namespace {
 constexpr int THREADS = 256;            // 4 waves; two workgroups per CU
@@ -765,6 +768,7 @@ constexpr int RTH = 256;                 // threads of one role
 constexpr int OBS_PT_S = (EPW * MAX_NOBS + RTH - 1) / RTH;
 constexpr int IMG = MAX_IN * EPW;        // floats of one input image
 constexpr int PART = KSPLIT * EPW * PPITCH;
+constexpr int WD = 3;                    // weight groups in flight ahead of the MFMAs (forward waves)
 // LDS (bytes): fp64 regions first
 constexpr size_t S_ENV = 0;
 constexpr size_t S_ARG = S_ENV + sizeof(double) * EPW * L_ENV;
@@ -785,6 +789,24 @@ static_assert(S_IMG % 16 == 0 && S_HA % 16 == 0 && S_HB % 16 == 0 && S_PART % 4 
 static_assert(SPLIT_LDS <= 160 * 1024, "one workgroup per CU");
 
 template <int G1>      // groups of layer 1: 3 (inputs <= 48) or 4
+
+// Diagnostic (OLY_K13_SKIP bit 3, tools/time_k13.py --stamps): workgroup 0's first wave of each role sums, per
+// interval of the step, the s_memtime ticks it worked and the ticks it then waited at the barrier, and leaves the
+// 12 + 12 sums (plus s_memrealtime ticks of the loop) in buf_values, which is garbage afterwards.
+#define BAR()                                                          \
+  do {                                                                 \
+    if (stamping) {                                                    \
+      const unsigned long long s0_ = __builtin_amdgcn_s_memtime();     \
+      __syncthreads();                                                 \
+      const unsigned long long s1_ = __builtin_amdgcn_s_memtime();     \
+      st_work[st_i] += s0_ - st_last;                                  \
+      st_wait[st_i] += s1_ - s0_;                                      \
+      st_last = s1_;                                                   \
+      st_i = st_i == 5 ? 0 : st_i + 1;                                 \
+    } else {                                                           \
+      __syncthreads();                                                 \
+    }                                                                  \
+  } while (0)
 __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
   double* s_env = reinterpret_cast<double*>(lds8 + S_ENV);      // [EPW][L_ENV]
@@ -820,6 +842,9 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
     return;
   }
   const int skip = p.skip;
+  const bool stamping = (skip & 8) && blockIdx.x == 0 && (tid & 255) < 64;
+  unsigned long long st_work[6] = {0, 0, 0, 0, 0, 0}, st_wait[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
+  int st_i = 0;
 
   // ---------------------------------------------------------------- prologue (all 512 threads)
   for (int i = tid; i < 4 * IMG; i += THREADS_S) s_img[i] = 0.f;
@@ -862,6 +887,13 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
     const float a_scale = (a_ok && !det) ? p.ro.scale[a_col] : 0.f;
     const bool c_ok = rtid < rows;                               // critic: one value per row
     const float c_bias = PC[L.b3];
+    float bias_r[4][4];          // hidden-layer biases of this lane's columns: actor 1, 2, critic 1, 2
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = 16 * (4 * wq + q) + (lane & 15);
+      bias_r[0][q] = PA[L.b1 + col]; bias_r[1][q] = PA[L.b2 + col];
+      bias_r[2][q] = PC[L.b1 + col]; bias_r[3][q] = PC[L.b2 + col];
+    }
     float eps_next = 0.f;
     if (a_ok && !det && t0 < T) eps_next = p.ro.eps[((size_t)t0 * N + row0) * nu + rtid];
     float* partA = s_part;
@@ -875,6 +907,10 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       if (t == T - 1 && p.value_out) p.value_out[row0 + rtid] = s;
     };
     __syncthreads();
+    const unsigned long long rt0 = stamping ? __builtin_amdgcn_s_memrealtime() : 0;
+    st_last = stamping ? __builtin_amdgcn_s_memtime() : 0;
+    float4 ring[WD + 1][4];      // weight groups in flight (layers 1, 2), requested before the barrier they follow
+    float4 ring3[2][3][1];       // the same for the two output-layer chains of this wave
     int it = 0;
     for (int t = t0; t < T; ++t, ++it) {
       const size_t tN = (size_t)t * N;
@@ -894,9 +930,46 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       const float* obs_rows = s_post + buf * EPW * OBP;
       const bool run_mlp = !(skip & 1);
 
-      // ---- interval 1: the value of the step before (its partial tiles are complete since the last barrier);
-      // memory.store(state, ...) (ppo.py:186); actor layer 1
-      if (it > 0 && c_ok) critic_out(t - 1);
+      // Weight pointers of this wave's four column tiles (layers 1, 2) and two partial chains (output layer)
+      const int wqw = (skip & 4) ? 0 : wq;     // diagnostic: every wave streams wave 0's weights (wrong results)
+      const float4* const wa1[4] = {Pa4 + (L.w1n >> 2) + (size_t)(4 * wqw) * G1N * 64, Pa4 + (L.w1n >> 2) + (size_t)(4 * wqw + 1) * G1N * 64,
+                                    Pa4 + (L.w1n >> 2) + (size_t)(4 * wqw + 2) * G1N * 64, Pa4 + (L.w1n >> 2) + (size_t)(4 * wqw + 3) * G1N * 64};
+      const float4* const wa2[4] = {Pa4 + (L.w2n >> 2) + (size_t)(4 * wqw) * (HID / 16) * 64, Pa4 + (L.w2n >> 2) + (size_t)(4 * wqw + 1) * (HID / 16) * 64,
+                                    Pa4 + (L.w2n >> 2) + (size_t)(4 * wqw + 2) * (HID / 16) * 64, Pa4 + (L.w2n >> 2) + (size_t)(4 * wqw + 3) * (HID / 16) * 64};
+      const float4* const wc1[4] = {Pc4 + (L.w1n >> 2) + (size_t)(4 * wqw) * G1N * 64, Pc4 + (L.w1n >> 2) + (size_t)(4 * wqw + 1) * G1N * 64,
+                                    Pc4 + (L.w1n >> 2) + (size_t)(4 * wqw + 2) * G1N * 64, Pc4 + (L.w1n >> 2) + (size_t)(4 * wqw + 3) * G1N * 64};
+      const float4* const wc2[4] = {Pc4 + (L.w2n >> 2) + (size_t)(4 * wqw) * (HID / 16) * 64, Pc4 + (L.w2n >> 2) + (size_t)(4 * wqw + 1) * (HID / 16) * 64,
+                                    Pc4 + (L.w2n >> 2) + (size_t)(4 * wqw + 2) * (HID / 16) * 64, Pc4 + (L.w2n >> 2) + (size_t)(4 * wqw + 3) * (HID / 16) * 64};
+      const float4* const wa3[2][1] = {{Pa4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw)) * 64}, {Pa4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw + 1)) * 64}};
+      const float4* const wc3[2][1] = {{Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw)) * 64}, {Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw + 1)) * 64}};
+      const int cc = lane & 15, h2 = lane >> 4;
+      constexpr int GH = HID / 32;           // a hidden layer is cut in two halves of GH groups
+
+      // ring slots of group 0 of the four hidden layers (mlp_tiles.h: the ring is never drained inside a step)
+      constexpr int RB_A2 = G1 % (WD + 1), RB_C1 = (G1 + HID / 16) % (WD + 1), RB_C2 = (2 * G1 + HID / 16) % (WD + 1);
+      const float4* const none[4] = {nullptr, nullptr, nullptr, nullptr};
+      const float4* const none1[1] = {nullptr};
+
+      // ---- interval 1: the critic's output layer of the step BEFORE (partial tiles); actor layer 1;
+      // memory.store(state, ...) (ppo.py:186)
+      if (run_mlp) {
+        if (it == 0) {
+          preload_tiles16<4, WD, 0>(wa1, lane, G1, ring);     // (later steps: requested at the end of the step before)
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            f32x4 acc[1] = {{0}};
+            layer_tiles16p<0, 2, 2, 1, 2, 0, 0>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * (2 * wq + jj)) * 64, wc3[jj], none1, lane, acc, ring3[jj]);
+            float* part = partC + (size_t)(2 * wq + jj) * EPW * PPITCH;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + cc] = acc[0][i];
+          }
+        }
+        f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+        layer_tiles16p<0, G1, G1, 4, WD, 0, HID / 16>(reinterpret_cast<const float4*>(xA), wa1, wa2, lane, acc, ring);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[0][q], 4 * wq + q, lane, hA);
+      }
 #pragma unroll
       for (int q = 0; q < OBS_PT_S; ++q) {
         const int e = rtid + q * RTH;
@@ -904,95 +977,97 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       }
       const float eps_t = eps_next;
       if (!last_step && a_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + rtid_t];
-      if (run_mlp) {
+      BAR();
+      // ---- intervals 2, 3: actor layer 2 in two halves (the barrier between them is the environment waves'); the
+      // value of the step before
+      {
         f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-        const float4* base = Pa4 + (L.w1n >> 2) + (size_t)(4 * wq) * G1N * 64;
-        const float4* const w[4] = {base, base + G1N * 64, base + 2 * G1N * 64, base + 3 * G1N * 64};
-        layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xA), w, lane, acc);
+        if (run_mlp) layer_tiles16p<0, GH, HID / 16, 4, WD, RB_A2, G1>(reinterpret_cast<const float4*>(hA), wa2, wc1, lane, acc, ring);
+        if (it > 0 && c_ok) critic_out(t - 1);
+        BAR();
+        if (run_mlp) {
+          preload_tiles16<1, 2, 0>(wa3[0], lane, 2, ring3[0]);
+          preload_tiles16<1, 2, 0>(wa3[1], lane, 2, ring3[1]);
+          layer_tiles16p<GH, HID / 16, HID / 16, 4, WD, RB_A2, G1>(reinterpret_cast<const float4*>(hA), wa2, wc1, lane, acc, ring);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_relu16(acc[q], Pa + L.b1, 4 * wq + q, lane, hA);
+          for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[1][q], 4 * wq + q, lane, hB);
+        }
       }
-      __syncthreads();
-      if (run_mlp) {  // ---- interval 2: actor layer 2
-        f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-        const float4* base = Pa4 + (L.w2n >> 2) + (size_t)(4 * wq) * (HID / 16) * 64;
-        const float4* const w[4] = {base, base + (HID / 16) * 64, base + 2 * (HID / 16) * 64, base + 3 * (HID / 16) * 64};
-        layer_tiles16<HID / 16, 4>(reinterpret_cast<const float4*>(hA), w, lane, acc);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) store_relu16(acc[q], Pa + L.b2, 4 * wq + q, lane, hB);
-      }
-      __syncthreads();
-      if (run_mlp) {  // ---- interval 3: actor output layer as eight partial chains; wave w runs chains 2 w, 2 w + 1
-        const int c = lane & 15, h2 = lane >> 4;
+      BAR();
+      if (run_mlp) {  // ---- interval 4: actor output layer as eight partial chains (wave w: chains 2 w, 2 w + 1); critic layer 1
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          const int j = 2 * wq + jj;
           f32x4 acc[1] = {{0}};
-          const float4* const w[1] = {Pa4 + (L.w3n >> 2) + (size_t)(2 * j) * 64};
-          layer_tiles16<2, 1>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * j) * 64, w, lane, acc);
-          float* part = partA + (size_t)j * EPW * PPITCH;
+          layer_tiles16p<0, 2, 2, 1, 2, 0, 0>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * (2 * wq + jj)) * 64, wa3[jj], none1, lane, acc, ring3[jj]);
+          float* part = partA + (size_t)(2 * wq + jj) * EPW * PPITCH;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + c] = acc[0][i];
+          for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + cc] = acc[0][i];
         }
-      }
-      __syncthreads();
-      // ---- interval 4: critic layer 1, then the actor's sampling (its partial tiles are complete)
-      if (run_mlp) {
         f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-        const float4* base = Pc4 + (L.w1n >> 2) + (size_t)(4 * wq) * G1N * 64;
-        const float4* const w[4] = {base, base + G1N * 64, base + 2 * G1N * 64, base + 3 * G1N * 64};
-        layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xC), w, lane, acc);
+        layer_tiles16p<0, G1, G1, 4, WD, RB_C1, HID / 16>(reinterpret_cast<const float4*>(xC), wc1, wc2, lane, acc, ring);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_relu16(acc[q], Pc + L.b1, 4 * wq + q, lane, hA);
+        for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[2][q], 4 * wq + q, lane, hA);
       }
-      if (a_ok) {
-        float s = partA[a_row * PPITCH + a_col];
-#pragma unroll
-        for (int w = 1; w < KSPLIT; ++w) s += partA[(w * EPW + a_row) * PPITCH + a_col];
-        s += a_bias;
-        // Normal(mu, std * anneal).sample() from the pre-drawn noise (ppo.py:181), memory.store's action and the
-        // PD target the physics would receive (robot.py:88-95)
-        float a = s;
-        if (!det) {
-          const float scl = a_scale * eps_t;
-          a = s + scl;
-        }
-        p.ro.buf_actions[(tN + row0) * nu + rtid_t] = a;
-        if (last_step) {
-          p.ro.pd_target[(size_t)row0 * nu + rtid_t] = (double)a + m->motor_offset[a_col];
-          if (p.mu_out) p.mu_out[(size_t)row0 * nu + rtid_t] = s;
-        }
-      }
-      __syncthreads();
-      if (run_mlp) {  // ---- interval 5: critic layer 2
+      BAR();
+      // ---- intervals 5, 6: critic layer 2 in two halves; the actor's sampling
+      {
         f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-        const float4* base = Pc4 + (L.w2n >> 2) + (size_t)(4 * wq) * (HID / 16) * 64;
-        const float4* const w[4] = {base, base + (HID / 16) * 64, base + 2 * (HID / 16) * 64, base + 3 * (HID / 16) * 64};
-        layer_tiles16<HID / 16, 4>(reinterpret_cast<const float4*>(hA), w, lane, acc);
+        if (run_mlp) layer_tiles16p<0, GH, HID / 16, 4, WD, RB_C2, 0>(reinterpret_cast<const float4*>(hA), wc2, none, lane, acc, ring);
+        if (a_ok) {
+          float s = partA[a_row * PPITCH + a_col];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_relu16(acc[q], Pc + L.b2, 4 * wq + q, lane, hB);
-      }
-      __syncthreads();
-      if (run_mlp) {  // ---- interval 6: critic output layer
-        const int c = lane & 15, h2 = lane >> 4;
+          for (int w = 1; w < KSPLIT; ++w) s += partA[(w * EPW + a_row) * PPITCH + a_col];
+          s += a_bias;
+          // Normal(mu, std * anneal).sample() from the pre-drawn noise (ppo.py:181), memory.store's action and the
+          // PD target the physics would receive (robot.py:88-95)
+          float a = s;
+          if (!det) {
+            const float scl = a_scale * eps_t;
+            a = s + scl;
+          }
+          p.ro.buf_actions[(tN + row0) * nu + rtid_t] = a;
+          if (last_step) {
+            p.ro.pd_target[(size_t)row0 * nu + rtid_t] = (double)a + m->motor_offset[a_col];
+            if (p.mu_out) p.mu_out[(size_t)row0 * nu + rtid_t] = s;
+          }
+        }
+        BAR();
+        if (run_mlp) {
+          preload_tiles16<1, 2, 0>(wc3[0], lane, 2, ring3[0]);
+          preload_tiles16<1, 2, 0>(wc3[1], lane, 2, ring3[1]);
+          layer_tiles16p<GH, HID / 16, HID / 16, 4, WD, RB_C2, 0>(reinterpret_cast<const float4*>(hA), wc2, none, lane, acc, ring);
+          if (!last_step) preload_tiles16<4, WD, 0>(wa1, lane, G1, ring);      // the next step's first weights
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int j = 2 * wq + jj;
-          f32x4 acc[1] = {{0}};
-          const float4* const w[1] = {Pc4 + (L.w3n >> 2) + (size_t)(2 * j) * 64};
-          layer_tiles16<2, 1>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * j) * 64, w, lane, acc);
-          float* part = partC + (size_t)j * EPW * PPITCH;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + c] = acc[0][i];
+          for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[3][q], 4 * wq + q, lane, hB);
         }
       }
-      __syncthreads();     // obs_{t+1} and its images are complete (environment waves)
+      BAR();     // obs_{t+1} and its images are complete (environment waves)
     }
+    // the last step's value: the critic's output layer, a barrier (the environment waves keep it company), the sum
+    if (t0 < T && !(skip & 1)) {
+      const float4* Pc4 = reinterpret_cast<const float4*>(PC);
+      const int cc = lane & 15, h2 = lane >> 4;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const float4* const w[1] = {Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wq + jj)) * 64};
+        f32x4 acc[1] = {{0}};
+        layer_tiles16p<0, 2, 2, 1, 2, 0, 0>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * (2 * wq + jj)) * 64, w, w, lane, acc, ring3[jj]);
+        float* part = partC + (size_t)(2 * wq + jj) * EPW * PPITCH;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + cc] = acc[0][i];
+      }
+    }
+    __syncthreads();
     if (t0 < T && c_ok) critic_out(T - 1);
+    if (stamping && lane == 0) {
+      for (int i = 0; i < 6; ++i) { p.ro.buf_values[i] = (float)st_work[i]; p.ro.buf_values[6 + i] = (float)st_wait[i]; }
+      p.ro.buf_values[12] = (float)(__builtin_amdgcn_s_memrealtime() - rt0);
+    }
     return;
   }
 
   // ============================================================================================== environment waves
+  if (!(skip & 16)) __builtin_amdgcn_s_setprio(3);     // their dependent fp64 chains go ahead of the forward waves' MFMAs
   const int grp = lane >> 4, slot = lane & (SLOTS - 1);
   const int el = wq * 4 + grp;
   const int n = row0 + el;
@@ -1063,6 +1138,10 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
   request(k0, n, slot, rb);
   __syncthreads();
 
+  unsigned long long st_sub[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_sl = 0;
+#define SUB0() do { if (stamping) st_sl = __builtin_amdgcn_s_memtime(); } while (0)
+#define SUB(i) do { if (stamping) { const unsigned long long x_ = __builtin_amdgcn_s_memtime(); st_sub[i] += x_ - st_sl; st_sl = x_; } } while (0)
+  st_last = stamping ? __builtin_amdgcn_s_memtime() : 0;
   int it = 0;
   for (int t = t0; t < T; ++t, ++it) {
     const size_t tN = (size_t)t * N;
@@ -1071,10 +1150,11 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
     int n_t = n, slot_t = slot;
     asm volatile("" : "+v"(n_t), "+v"(slot_t));
     if (skip & 2) {
-      __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+      __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();  // (untimed)
       continue;
     }
     // ---- interval 1: the readback row into the scratch; K3: foot contacts
+    SUB0();
     if (env_ok) {
       se[slot] = rb.va;
       if (dst_b >= 0) se[dst_b] = rb.vb;
@@ -1083,6 +1163,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         se[L_AVL + slot] = rb.v_vel;
       }
     }
+    SUB(0);
     const int nc_raw = rb.nc_raw;
     const int nc = min(max(nc_raw, 0), C);
     int cnt_r = 0, cnt_l = 0;
@@ -1149,15 +1230,17 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
     const double grf_r = sum_r, grf_l = sum_l;
     const double min_z = have ? mz : 0.0;
     const bool bad = (cnt_r + cnt_l) != nc_raw;
+    SUB(1);
     // this step's readback registers are consumed: request step t + 1's rows now, a whole step ahead of their use
     if (!last_step) request(k0 + (t + 1 - t0), n_t, slot_t, rb);
+    SUB(2);
     if (env_ok && slot == 0) {
       int* si = s_int + el * SI_N;
       si[I_PHASE0] = phase0; si[I_T1] = t1; si[I_T2] = t2; si[I_FRAMES] = frames; si[I_MODE] = mode;
       si[I_SEQLEN] = seq_len; si[I_TLEN] = tlen; si[I_RC] = rc; si[I_BAD] = bad; si[I_HAVEC] = (cnt_r > 0 || cnt_l > 0);
       se[L_GR] = grf_r; se[L_GL] = grf_l; se[L_MZ] = min_z;
     }
-    __syncthreads();
+    BAR();
 
     // ---- interval 2: level 1, everything without libm, as four tasks, one per wave (a3_vec_core.h)
     {
@@ -1167,7 +1250,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       lc.pool = p.ro.pool; lc.pool_depth = p.ro.pool_depth; lc.row0 = row0;
       level1_tasks(lc, wq, lane);
     }
-    __syncthreads();
+    BAR();
     double r0, r1;
     const int ee = lane & 15;
     {  // ---- interval 3: libm round 1, regrouped by function
@@ -1179,7 +1262,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         s_env[ee * L_ENV + L_R1 + 2 * task + 1] = r1;
       }
     }
-    __syncthreads();
+    BAR();
 
     // ---- interval 4: back on the environment's own lanes; round-2 arguments
     const int* si_ = s_int + el * SI_N;
@@ -1263,7 +1346,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         s_cls[el * SLOTS + slot] = (uint8_t)(env_ok ? cls : F_NONE);
       }
     }
-    __syncthreads();
+    BAR();
     {  // ---- interval 5: libm round 2.  wave 0: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's
        // clock-after-reset, slot 15, which only needed level-1 values); wave 1: atan2; wave 2: exp; wave 3: idle
       constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
@@ -1275,9 +1358,10 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         s_env[ee * L_ENV + dst + 1] = r1;
       }
     }
-    __syncthreads();
+    BAR();
 
     // ---- interval 6: combination: observation rows and the next input images, rewards, flags, reset
+    SUB0();
     float* op = s_pre + el * OBP;
     float* oq = s_post + (nbuf * EPW + el) * OBP;
     if (env_ok) {
@@ -1301,6 +1385,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       if (slot >= 8) op[9 + 2 * nu + slot - 8] = (float)goal[slot - 8];
     }
     wave_lds_fence();       // the observation row of an environment is assembled and re-read by its own lanes
+    SUB(3);
     if (env_ok) {
       float* imgA = s_img + (2 * nbuf) * IMG;
       float* imgC = s_img + (2 * nbuf + 1) * IMG;
@@ -1320,6 +1405,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         imgA[ix] = va;
         imgC[ix] = vc;
       }
+      SUB(4);
       // ---- rewards, flags
       if (slot == 0) {
         const double frc = (se[L_R1 + 2 * 2] + se[L_R1 + 2 * 3]) / 2;
@@ -1346,6 +1432,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         p.ro.buf_rewards[tN + n_t] = tot;
         p.ro.buf_flags[tN + n_t] = (uint8_t)((cut ? OLY_FLAG_LAST : 0) | (done ? OLY_FLAG_ABSORBING : 0));
       }
+      SUB(5);
       // bootstrap row: finish_path's last_val = (not done) * V(state) needs V of THIS observation
       if (cut && !done) {
         if (sc < p.ro.side_slots) {
@@ -1355,6 +1442,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         }
         sc += 1;
       }
+      SUB(6);
       tlen = cut ? 0 : len;
       if (need_reset) {
         // WalkingTask.reset (walking_task.py:321-397) + transform_sequence (:113-135)
@@ -1389,8 +1477,14 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         if (slot < 8) goal_last = goal[slot];
       }
     }
-    __syncthreads();     // obs_{t+1} and its images are complete; the forward's partial tiles too
+    SUB(7);
+    BAR();     // obs_{t+1} and its images are complete
   }
+  __syncthreads();       // (the forward waves' last output layer)
+  if (stamping && lane == 0)
+    for (int i = 0; i < 6; ++i) { p.ro.buf_values[16 + i] = (float)st_work[i]; p.ro.buf_values[22 + i] = (float)st_wait[i]; }
+  if (stamping && lane == 0)
+    for (int i = 0; i < 8; ++i) p.ro.buf_values[28 + i] = (float)st_sub[i];
 
   // ---------------------------------------------------------------- the rollout is over: leave the state K10 would
   if (t0 >= T) return;
@@ -1424,6 +1518,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
     p.ro.ctr[2 * blockIdx.x + 1] = k0 + (T - t0);
   }
 }
+#undef BAR
 }  // namespace
 
 extern "C" int64_t oly_a3_rollout_scratch_bytes(int N, int n_obs) {

@@ -99,12 +99,73 @@ __device__ __forceinline__ void layer_tiles16(const float4* __restrict__ a4, con
   }
 }
 
+// The same tiles for a wave that is alone on its SIMD (K13's forward waves): nothing else hides an L2 round trip
+// (~1200 cycles), so the weight stream runs D groups ahead in a ring of D + 1 register sets that the CALLER owns and
+// that is never drained between layers: while a layer's last D groups are multiplied, the NEXT layer's first groups
+// (wn, NGN of them) are already requested (weights do not depend on the barrier between the layers).  RB is the ring
+// slot of the layer's group 0; the next layer's is (RB + GT) % (D + 1).  The call runs groups [GB, GE) of the
+// GT-group layer: a layer may be cut in two by a barrier that the wave does not itself need (accumulators and ring
+// stay in registers).  Same MFMAs in the same order as layer_tiles16.
+template <int NT, int D, int RB>
+__device__ __forceinline__ void preload_tiles16(const float4* const (&w)[NT], int lane, int groups,
+                                                float4 (&b)[D + 1][NT]) {
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < groups) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[(RB + d) % (D + 1)][t] = w[t][(size_t)d * 64 + lane];
+    }
+}
+
+template <int GB, int GE, int GT, int NT, int D, int RB, int NGN>
+__device__ __forceinline__ void layer_tiles16p(const float4* __restrict__ a4, const float4* const (&w)[NT],
+                                               const float4* const (&wn)[NT], int lane, f32x4 (&acc)[NT],
+                                               float4 (&b)[D + 1][NT]) {
+  float4 a[2];
+  a[GB & 1] = a4[GB * 64 + lane];
+#pragma unroll
+  for (int g = GB; g < GE; ++g) {
+    if (g + D < GT) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[(RB + g + D) % (D + 1)][t] = w[t][(size_t)(g + D) * 64 + lane];
+    } else if (g + D - GT < NGN) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[(RB + g + D) % (D + 1)][t] = wn[t][(size_t)(g + D - GT) * 64 + lane];
+    }
+    if (g + 1 < GE) a[(g + 1) & 1] = a4[(g + 1) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads above ahead of this group's MFMAs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float aq = q == 0 ? a[g & 1].x : q == 1 ? a[g & 1].y : q == 2 ? a[g & 1].z : a[g & 1].w;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 bb = b[(RB + g) % (D + 1)][t];
+        const float bq = q == 0 ? bb.x : q == 1 ? bb.y : q == 2 ? bb.z : bb.w;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // bias + ReLU of a 16 x 16 accumulator tile (columns 16 tile ..) into the activation image of the next layer
 __device__ __forceinline__ void store_relu16(const f32x4& acc, const float* __restrict__ bias, int tile, int lane,
                                              float* __restrict__ img) {
   const int c = lane & 15, h2 = lane >> 4;
   const float bv = bias[16 * tile + c];
   // k = 16 tile + c of the next layer: group = tile, k-step q = c >> 2, lane group c & 3
+  float* dst = img + ((tile * 4 + (c & 3)) * 16 + 4 * h2) * 4 + (c >> 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = acc[i] + bv;
+    dst[4 * i] = (v > 0.f || v != v) ? v : 0.f;     // relu, NaN kept like torch
+  }
+}
+
+// the same with the bias value of the lane's column already in a register (a wave that owns the same column tiles
+// step after step loads its biases once)
+__device__ __forceinline__ void store_relu16v(const f32x4& acc, float bv, int tile, int lane, float* __restrict__ img) {
+  const int c = lane & 15, h2 = lane >> 4;
   float* dst = img + ((tile * 4 + (c & 3)) * 16 + 4 * h2) * 4 + (c >> 2);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

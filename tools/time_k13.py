@@ -30,15 +30,32 @@ try:
     env.device_rollout(pi, vf, T, T, graph=False, persistent=True)
 except Exception as e:
     print(json.dumps({"skip": skip, "error": repr(e)[:200]})); sys.exit(0)
-print(json.dumps({"skip": skip, "us_per_step": persistent_kernel_us(env, T, reps=8) / T}))
+res = {"skip": skip, "us_per_step": persistent_kernel_us(env, T, reps=8) / T}
+if skip & 8:
+    v = env._dev_rollout.buf.values.reshape(-1)[:36].double().cpu().numpy()
+    tick_hz = v[:12].sum() / (v[12] / 1e8)          # s_memtime ticks per second (s_memrealtime runs at 100 MHz)
+    names = ["1", "2", "3", "4", "5", "6"]
+    res["s_memtime_hz"] = tick_hz
+    res["forward_wave_us_per_step"] = {"work": dict(zip(names, (v[0:6] / T / tick_hz * 1e6).round(3).tolist())),
+                                        "barrier_wait": dict(zip(names, (v[6:12] / T / tick_hz * 1e6).round(3).tolist()))}
+    res["environment_wave_us_per_step"] = {"work": dict(zip(names, (v[16:22] / T / tick_hz * 1e6).round(3).tolist())),
+                                            "barrier_wait": dict(zip(names, (v[22:28] / T / tick_hz * 1e6).round(3).tolist()))}
+    sub = ["1_stage_readback", "1_contacts", "1_request_next", "6_assemble_row", "6_post_row_and_images", "6_rewards", "6_side_row", "6_reset_and_state"]
+    res["environment_wave_parts_us_per_step"] = dict(zip(sub, (v[28:36] / T / tick_hz * 1e6).round(3).tolist()))
+print(json.dumps(res))
 ''' % (ROOT, ROOT)
 
 
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    T = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    N = int(pos[0]) if len(pos) > 0 else 4096
+    T = int(pos[1]) if len(pos) > 1 else 400
     out = {}
     variants = [(0, "everything", None), (1, "no_mfma_layers", None), (2, "no_environment_step", None), (3, "neither", None)]
+    if "--diag" in sys.argv:      # bit 2: every forward wave streams wave 0's weights (what the L2 traffic costs)
+        variants += [(6, "forward_only_one_weight_stream", None), (4, "everything_one_weight_stream", None)]
+    if "--stamps" in sys.argv:    # bit 3: per-interval work / barrier-wait times of workgroup 0 (s_memtime)
+        variants = [(8, "everything", None), (10, "no_environment_step", None), (9, "no_mfma_layers", None)]
     for skip, label, _ in variants:
         env = dict(os.environ, OLY_K13_SKIP=str(skip))
         r = subprocess.run([sys.executable, "-c", CHILD, str(N), str(T)], env=env, capture_output=True, text=True)
