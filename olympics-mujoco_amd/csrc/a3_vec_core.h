@@ -104,83 +104,96 @@ struct Level1Ctx {
 
 // An environment's 16 lanes used to run the whole level-1 block redundantly: ~1100 instructions issued by every wave
 // (3.3 us of a step).  Issue time follows the LENGTH of a wave's instruction stream, not its active lanes, so the
-// block is cut by FUNCTION across the group's four waves (as the libm rounds are), each wave taking all 16
-// environments on lanes 0..15: ~300 instructions per wave.  Same expressions on the same inputs as K10 / K2:
-// bit-identical.  Each task writes the round-1 libm arguments of the slots it owns (s_arg / s_cls) and its part of
-// the per-environment results (s_int outputs, the root rotation at L_ROT).  Call from all four waves between two
-// workgroup barriers; inputs: the staged rows of s_env, seqs, the I_* ints and L_GR / L_GL / L_MZ.
+// block is cut by FUNCTION across the group's four waves (as the libm rounds are), and inside a wave its independent
+// long operations (fp64 square roots and divisions, ~30 dependent instructions each) go to the wave's four 16-lane
+// groups, lane group s taking piece s of all 16 environments: the longest dependent chain of a wave is two such
+// operations instead of five or six.  Same expressions on the same inputs as K10 / K2: bit-identical.  Each piece
+// writes the round-1 libm arguments of the slots it owns (s_arg / s_cls) and its part of the per-environment
+// results (s_int outputs, the root rotation at L_ROT).  Call from all four waves (every lane) between two workgroup
+// barriers; inputs: the staged rows of s_env, seqs, the I_* ints and L_GR / L_GL / L_MZ.
 __device__ __forceinline__ void level1_tasks(const Level1Ctx& c, int wave, int lane) {
-if (lane < A3V_EPW) {
-  const int e = lane;
-    const double* ee_ = c.s_env + e * L_ENV;
-    const double* esq = c.seqs + e * A3V_SEQW;
-    int* si = c.s_int + e * SI_N;
-    double* arg = c.s_arg + e * A3V_SLOTS * 2;
-    uint8_t* acl = c.s_cls + e * A3V_SLOTS;
-    auto put = [&](int task, int cls, double a, double b) {
-      arg[2 * task] = a;
-      arg[2 * task + 1] = b;
-      acl[task] = (uint8_t)cls;
-    };
-    const bool live = e < c.rows;
-    // shared, cheap: done / cut / need_reset (walking_task.py:298-319, ppo.py:178,189-196)
-    const double rp2 = ee_[L_RP + 2];
-    const double foot_z = fmin(ee_[L_LF + 2], ee_[L_RF + 2]);
-    const bool bad_e = si[I_BAD] != 0;
-    const bool done = ((rp2 - foot_z) < 0.6) || bad_e;
-    const int len = si[I_TLEN] + 1;
-    const bool cut = done || len >= c.max_traj_len || c.last_step;
-    const bool need_reset = live && cut && !c.last_step;
-    const int mode_e = si[I_MODE];
-    const bool walking = mode_e != OLY_MODE_STANDING;
-    int phase = si[I_PHASE0] + 1;
-    if (phase >= c.period) phase = 0;
-    if (!live) {
+  const int e = lane & (A3V_EPW - 1), sub = lane >> 4;
+  const double* ee_ = c.s_env + e * L_ENV;
+  const double* esq = c.seqs + e * A3V_SEQW;
+  int* si = c.s_int + e * SI_N;
+  double* arg = c.s_arg + e * A3V_SLOTS * 2;
+  uint8_t* acl = c.s_cls + e * A3V_SLOTS;
+  auto put = [&](int task, int cls, double a, double b) {
+    arg[2 * task] = a;
+    arg[2 * task + 1] = b;
+    acl[task] = (uint8_t)cls;
+  };
+  const bool live = e < c.rows;
+  // shared, cheap: done / cut / need_reset (walking_task.py:298-319, ppo.py:178,189-196)
+  const double rp2 = ee_[L_RP + 2];
+  const double foot_z = fmin(ee_[L_LF + 2], ee_[L_RF + 2]);
+  const bool bad_e = si[I_BAD] != 0;
+  const bool done = ((rp2 - foot_z) < 0.6) || bad_e;
+  const int len = si[I_TLEN] + 1;
+  const bool cut = done || len >= c.max_traj_len || c.last_step;
+  const bool need_reset = live && cut && !c.last_step;
+  const int mode_e = si[I_MODE];
+  const bool walking = mode_e != OLY_MODE_STANDING;
+  int phase = si[I_PHASE0] + 1;
+  if (phase >= c.period) phase = 0;
+  if (!live) {     // rows past N: every slot of the round-1 table says "nothing to evaluate" (lane group 0 writes them)
+    if (sub == 0) {
       if (wave == 0) { put(0, F_NONE, 0, 0); put(1, F_NONE, 0, 0); put(6, F_NONE, 0, 0); put(8, F_NONE, 0, 0); put(9, F_NONE, 0, 0); }
       else if (wave == 1) { put(13, F_NONE, 0, 0); put(14, F_NONE, 0, 0); put(15, F_NONE, 0, 0); }
       else if (wave == 2) { put(7, F_NONE, 0, 0); put(10, F_NONE, 0, 0); put(11, F_NONE, 0, 0); put(12, F_NONE, 0, 0); }
       else { put(2, F_NONE, 0, 0); put(3, F_NONE, 0, 0); put(4, F_NONE, 0, 0); put(5, F_NONE, 0, 0); }
-    } else if (wave == 0) {
-      // WalkingTask.step (walking_task.py:246-293): target reached / delay / update_target_steps; then the
-      // arguments that read the selected sequence rows
-      const double rp0 = ee_[L_RP], rp1 = ee_[L_RP + 1];
-      const double lf0 = ee_[L_LF], lf1 = ee_[L_LF + 1], lf2 = ee_[L_LF + 2];
-      const double rf0 = ee_[L_RF], rf1 = ee_[L_RF + 1], rf2 = ee_[L_RF + 2];
-      int t1e = si[I_T1], t2e = si[I_T2], fr = si[I_FRAMES];
-      const int seq_len_e = si[I_SEQLEN];
-      const double tx = esq[4 * t1e], ty = esq[4 * t1e + 1], tz = esq[4 * t1e + 2];
-      const double dl = vnorm3(lf0 - tx, lf1 - ty, lf2 - tz);
-      const double dr = vnorm3(rf0 - tx, rf1 - ty, rf2 - tz);
-      int reached;
-      if (dl < c.m->target_radius || dr < c.m->target_radius) {
-        reached = 1;
-        fr += 1;
-      } else {
-        reached = 0;
-        fr = 0;
-      }
-      if (reached && fr >= c.m->delay_frames) {  // update_target_steps
-        t1e = t2e;
-        t2e += 1;
-        if (t2e == seq_len_e) t2e = seq_len_e - 1;
-        t2e = min(max(t2e, 0), OLY_MAX_SEQ - 1);
-        reached = 0;
-        fr = 0;
-      }
-      const int selA = 4 * t1e, selB = 4 * t2e;   // sequence[t1] / sequence[t2] after the update
-      const double s1x = esq[selA], s1y = esq[selA + 1], s1z = esq[selA + 2], s1w = esq[selA + 3];
-      const double s2x = esq[selB], s2y = esq[selB + 1], s2w = esq[selB + 3];
-      const double fd = fmin(vnorm3(lf0 - s1x, lf1 - s1y, lf2 - s1z), vnorm3(rf0 - s1x, rf1 - s1y, rf2 - s1z));
-      const double mpx = (s1x + s2x) / 2, mpy = (s1y + s2y) / 2;
-      const double rx = rp0 - mpx, ry = rp1 - mpy;
+    }
+    return;
+  }
+  if (wave == 0) {
+    // WalkingTask.step (walking_task.py:246-293): target reached / delay / update_target_steps; then the
+    // arguments that read the selected sequence rows.  Lane groups 0 / 1: the left / right foot's distances.
+    const double rp0 = ee_[L_RP], rp1 = ee_[L_RP + 1];
+    const int fo = (sub & 1) ? L_RF : L_LF;
+    const double f0 = ee_[fo], f1 = ee_[fo + 1], f2 = ee_[fo + 2];
+    int t1e = si[I_T1], t2e = si[I_T2], fr = si[I_FRAMES];
+    const int seq_len_e = si[I_SEQLEN];
+    const double tx = esq[4 * t1e], ty = esq[4 * t1e + 1], tz = esq[4 * t1e + 2];
+    const double d_own = vnorm3(f0 - tx, f1 - ty, f2 - tz);            // groups 0, 2: left; 1, 3: right
+    const double d_oth = __shfl_xor(d_own, 16);
+    const double dl = (sub & 1) ? d_oth : d_own, dr = (sub & 1) ? d_own : d_oth;
+    int reached;
+    if (dl < c.m->target_radius || dr < c.m->target_radius) {
+      reached = 1;
+      fr += 1;
+    } else {
+      reached = 0;
+      fr = 0;
+    }
+    if (reached && fr >= c.m->delay_frames) {  // update_target_steps
+      t1e = t2e;
+      t2e += 1;
+      if (t2e == seq_len_e) t2e = seq_len_e - 1;
+      t2e = min(max(t2e, 0), OLY_MAX_SEQ - 1);
+      reached = 0;
+      fr = 0;
+    }
+    const int selA = 4 * t1e, selB = 4 * t2e;   // sequence[t1] / sequence[t2] after the update
+    const double s1x = esq[selA], s1y = esq[selA + 1], s1z = esq[selA + 2], s1w = esq[selA + 3];
+    const double s2x = esq[selB], s2y = esq[selB + 1], s2w = esq[selB + 3];
+    const double n_own = vnorm3(f0 - s1x, f1 - s1y, f2 - s1z);
+    const double n_oth = __shfl_xor(n_own, 16);
+    if (sub == 0) {
+      const double fd = fmin(n_own, n_oth);                                        // fmin(left, right)
+      put(8, F_EXP, -fd / 0.25, 0.0);                                              // target hit
+      si[O_PHASE] = phase; si[O_T1] = t1e; si[O_T2] = t2e; si[O_FRAMES] = fr; si[O_REACHED] = reached;
+      si[O_DONE] = done; si[O_CUT] = cut; si[O_RESET] = need_reset;
+    } else if (sub == 1) {
       put(0, walking ? F_SINCOS : F_NONE, walking ? s1w : 0.0, 0.0);               // goal yaw 1: cos / sin(theta)
       put(1, walking ? F_SINCOS : F_NONE, walking ? s2w : 0.0, 0.0);
       put(6, F_SINCOS, s1w / 2.0, 0.0);                                            // euler2quat(0,0,yaw) of the target
-      put(8, F_EXP, -fd / 0.25, 0.0);                                              // target hit
+    } else if (sub == 2) {
+      const double mpx = (s1x + s2x) / 2, mpy = (s1y + s2y) / 2;
+      const double rx = rp0 - mpx, ry = rp1 - mpy;
       put(9, F_EXP, -sqrt(rx * rx + ry * ry) / 2, 0.0);                            // progress
-      si[O_PHASE] = phase; si[O_T1] = t1e; si[O_T2] = t2e; si[O_FRAMES] = fr; si[O_REACHED] = reached;
-      si[O_DONE] = done; si[O_CUT] = cut; si[O_RESET] = need_reset;
-    } else if (wave == 1) {
+    }
+  } else if (wave == 1) {
+    if (sub == 0) {
       // root rotation (goal steps, round 2) and its yaw for transform_sequence: quat2euler(root xquat)[2]
       double R[3][3];
       quat2mat(ee_[L_RQ], ee_[L_RQ + 1], ee_[L_RQ + 2], ee_[L_RQ + 3], R);
@@ -192,6 +205,7 @@ if (lane < A3V_EPW) {
       const double cyr = sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
       const bool yaw = need_reset && cyr > 4.0 * EPS;
       put(14, yaw ? F_ATAN2 : F_NONE, yaw ? R[1][0] : 0.0, yaw ? R[0][0] : 0.0);
+    } else if (sub == 1) {
       // the clock observation, and env.reset()'s record header: mode / phase / length of the next pool record
       put(13, F_SINCOS, 2 * PI * phase / (double)c.period, 0.0);                     // clock
       int new_mode = mode_e, new_phase = 0, new_len = si[I_SEQLEN];
@@ -204,47 +218,48 @@ if (lane < A3V_EPW) {
       }
       put(15, need_reset ? F_SINCOS : F_NONE, need_reset ? 2 * PI * new_phase / (double)c.period : 0.0, 0.0);   // clock after reset
       si[O_NEWMODE] = new_mode; si[O_NEWPHASE] = new_phase; si[O_NEWLEN] = new_len;
-    } else if (wave == 2) {
-      // get_obs: quat2euler(qpos[3:7]) (StickFigureA3.py:160); upper body; height
+    }
+  } else if (wave == 2) {
+    if (sub == 0) {
+      // get_obs: quat2euler(qpos[3:7]) (StickFigureA3.py:160)
       double Rb[3][3];
       quat2mat(ee_[L_BQ], ee_[L_BQ + 1], ee_[L_BQ + 2], ee_[L_BQ + 3], Rb);
       const double cyb = sqrt(Rb[0][0] * Rb[0][0] + Rb[1][0] * Rb[1][0]);
       const bool regular = cyb > 4.0 * EPS;
       const double roll_y = regular ? Rb[2][1] : -Rb[1][2];
       const double roll_x = regular ? Rb[2][2] : Rb[1][1];
+      put(11, F_ATAN2, roll_y, roll_x);                                            // roll
+      put(12, F_ATAN2, -Rb[2][0], cyb);                                            // pitch
+    } else if (sub == 1) {
       const double hx = ee_[L_HP] - ee_[L_RP], hy = ee_[L_HP + 1] - ee_[L_RP + 1];
       const double hn = sqrt(hx * hx + hy * hy);
+      put(10, F_EXP, -10 * (hn * hn), 0.0);                                        // upper body
+    } else if (sub == 2) {
       const double contact_point = si[I_HAVEC] ? ee_[L_MZ] : 0.0;
       double err = fabs((rp2 - contact_point) - c.m->goal_height_ref);
       const double deadzone = 0.01 + 0.05 * c.m->goal_speed_ref;
       if (err < deadzone) err = 0;
       put(7, F_EXP, -40 * (err * err), 0.0);                                       // height
-      put(10, F_EXP, -10 * (hn * hn), 0.0);                                        // upper body
-      put(11, F_ATAN2, roll_y, roll_x);                                            // roll
-      put(12, F_ATAN2, -Rb[2][0], cyb);                                            // pitch
-    } else {
-      // calc_reward clock terms (walking_task.py:74-110, tasks/rewards.py:65-102)
-      double c_rfrc, c_rvel, c_lfrc, c_lvel;
-      if (!walking) {
-        c_rfrc = 1.0; c_lfrc = 1.0; c_rvel = -1.0; c_lvel = -1.0;
-      } else {
-        c_rfrc = c.s_lut[0 * c.period + phase];
-        c_rvel = c.s_lut[1 * c.period + phase];
-        c_lfrc = c.s_lut[2 * c.period + phase];
-        c_lvel = c.s_lut[3 * c.period + phase];
-      }
-      const double max_frc = c.m->mass * 9.8 * 0.5;
-      double nl = fmin(ee_[L_GL], max_frc) / max_frc;
-      double nr = fmin(ee_[L_GR], max_frc) / max_frc;
-      nl *= 2; nl -= 1; nr *= 2; nr -= 1;
-      double vl = fmin(vnorm3(ee_[L_LV], ee_[L_LV + 1], ee_[L_LV + 2]), 0.2) / 0.2;
-      double vr = fmin(vnorm3(ee_[L_RV], ee_[L_RV + 1], ee_[L_RV + 2]), 0.2) / 0.2;
-      vl *= 2; vl -= 1; vr *= 2; vr -= 1;
-      put(2, F_TAN, PI / 4 * c_lfrc * nl, 0.0);                                    // foot-force clock terms
-      put(3, F_TAN, PI / 4 * c_rfrc * nr, 0.0);
-      put(4, F_TAN, PI / 4 * c_lvel * vl, 0.0);                                    // foot-velocity clock terms
-      put(5, F_TAN, PI / 4 * c_rvel * vr, 0.0);
     }
+  } else {
+    // calc_reward clock terms (walking_task.py:74-110, tasks/rewards.py:65-102): lane group 0 / 1 the left / right
+    // foot's force term, 2 / 3 the left / right foot's velocity term
+    const bool right = sub & 1, velocity = sub >= 2;
+    const int lut_row = velocity ? (right ? 1 : 3) : (right ? 0 : 2);          // r_frc 0, r_vel 1, l_frc 2, l_vel 3
+    double coef;
+    if (!walking) coef = velocity ? -1.0 : 1.0;
+    else coef = c.s_lut[lut_row * c.period + phase];
+    double x;
+    if (!velocity) {
+      const double max_frc = c.m->mass * 9.8 * 0.5;
+      x = fmin(ee_[right ? L_GR : L_GL], max_frc) / max_frc;
+    } else {
+      const int vo = right ? L_RV : L_LV;
+      x = fmin(vnorm3(ee_[vo], ee_[vo + 1], ee_[vo + 2]), 0.2) / 0.2;
+    }
+    x *= 2; x -= 1;
+    // slots: 2 left force, 3 right force, 4 left velocity, 5 right velocity
+    put(2 + sub, F_TAN, PI / 4 * coef * x, 0.0);
   }
 }
 }  // namespace oly_a3v

@@ -943,7 +943,6 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       const float4* const wa3[2][1] = {{Pa4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw)) * 64}, {Pa4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw + 1)) * 64}};
       const float4* const wc3[2][1] = {{Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw)) * 64}, {Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw + 1)) * 64}};
       const int cc = lane & 15, h2 = lane >> 4;
-      constexpr int GH = HID / 32;           // a hidden layer is cut in two halves of GH groups
 
       // ring slots of group 0 of the four hidden layers (mlp_tiles.h: the ring is never drained inside a step)
       constexpr int RB_A2 = G1 % (WD + 1), RB_C1 = (G1 + HID / 16) % (WD + 1), RB_C2 = (2 * G1 + HID / 16) % (WD + 1);
@@ -978,21 +977,20 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       const float eps_t = eps_next;
       if (!last_step && a_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + rtid_t];
       BAR();
-      // ---- intervals 2, 3: actor layer 2 in two halves (the barrier between them is the environment waves'); the
-      // value of the step before
-      {
+      // ---- interval 2: actor layer 2; the value of the step before
+      if (run_mlp) {
+        preload_tiles16<1, 2, 0>(wa3[0], lane, 2, ring3[0]);
+        preload_tiles16<1, 2, 0>(wa3[1], lane, 2, ring3[1]);
         f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-        if (run_mlp) layer_tiles16p<0, GH, HID / 16, 4, WD, RB_A2, G1>(reinterpret_cast<const float4*>(hA), wa2, wc1, lane, acc, ring);
-        if (it > 0 && c_ok) critic_out(t - 1);
-        BAR();
-        if (run_mlp) {
-          preload_tiles16<1, 2, 0>(wa3[0], lane, 2, ring3[0]);
-          preload_tiles16<1, 2, 0>(wa3[1], lane, 2, ring3[1]);
-          layer_tiles16p<GH, HID / 16, HID / 16, 4, WD, RB_A2, G1>(reinterpret_cast<const float4*>(hA), wa2, wc1, lane, acc, ring);
+        layer_tiles16p<0, HID / 16, HID / 16, 4, WD, RB_A2, G1>(reinterpret_cast<const float4*>(hA), wa2, wc1, lane, acc, ring);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[1][q], 4 * wq + q, lane, hB);
-        }
+        for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[1][q], 4 * wq + q, lane, hB);
       }
+      if (it > 0 && c_ok) critic_out(t - 1);
+      BAR();
+      // ---- interval 3: nothing.  The environment waves are in libm round 1: a dependent fp64 chain beside an MFMA
+      // stream gets one instruction in per MFMA (4.7 x slower, measured), and they, not these waves, are the longer
+      // half of the step, so the matrix work stands aside for the two libm rounds.
       BAR();
       if (run_mlp) {  // ---- interval 4: actor output layer as eight partial chains (wave w: chains 2 w, 2 w + 1); critic layer 1
 #pragma unroll
@@ -1009,37 +1007,34 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
         for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[2][q], 4 * wq + q, lane, hA);
       }
       BAR();
-      // ---- intervals 5, 6: critic layer 2 in two halves; the actor's sampling
-      {
+      // ---- interval 5 (libm round 2 of the environment waves): only the actor's sampling
+      if (a_ok) {
+        float s = partA[a_row * PPITCH + a_col];
+#pragma unroll
+        for (int w = 1; w < KSPLIT; ++w) s += partA[(w * EPW + a_row) * PPITCH + a_col];
+        s += a_bias;
+        // Normal(mu, std * anneal).sample() from the pre-drawn noise (ppo.py:181), memory.store's action and the
+        // PD target the physics would receive (robot.py:88-95)
+        float a = s;
+        if (!det) {
+          const float scl = a_scale * eps_t;
+          a = s + scl;
+        }
+        p.ro.buf_actions[(tN + row0) * nu + rtid_t] = a;
+        if (last_step) {
+          p.ro.pd_target[(size_t)row0 * nu + rtid_t] = (double)a + m->motor_offset[a_col];
+          if (p.mu_out) p.mu_out[(size_t)row0 * nu + rtid_t] = s;
+        }
+      }
+      BAR();
+      if (run_mlp) {  // ---- interval 6: critic layer 2
+        preload_tiles16<1, 2, 0>(wc3[0], lane, 2, ring3[0]);
+        preload_tiles16<1, 2, 0>(wc3[1], lane, 2, ring3[1]);
         f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-        if (run_mlp) layer_tiles16p<0, GH, HID / 16, 4, WD, RB_C2, 0>(reinterpret_cast<const float4*>(hA), wc2, none, lane, acc, ring);
-        if (a_ok) {
-          float s = partA[a_row * PPITCH + a_col];
+        layer_tiles16p<0, HID / 16, HID / 16, 4, WD, RB_C2, 0>(reinterpret_cast<const float4*>(hA), wc2, none, lane, acc, ring);
+        if (!last_step) preload_tiles16<4, WD, 0>(wa1, lane, G1, ring);      // the next step's first weights
 #pragma unroll
-          for (int w = 1; w < KSPLIT; ++w) s += partA[(w * EPW + a_row) * PPITCH + a_col];
-          s += a_bias;
-          // Normal(mu, std * anneal).sample() from the pre-drawn noise (ppo.py:181), memory.store's action and the
-          // PD target the physics would receive (robot.py:88-95)
-          float a = s;
-          if (!det) {
-            const float scl = a_scale * eps_t;
-            a = s + scl;
-          }
-          p.ro.buf_actions[(tN + row0) * nu + rtid_t] = a;
-          if (last_step) {
-            p.ro.pd_target[(size_t)row0 * nu + rtid_t] = (double)a + m->motor_offset[a_col];
-            if (p.mu_out) p.mu_out[(size_t)row0 * nu + rtid_t] = s;
-          }
-        }
-        BAR();
-        if (run_mlp) {
-          preload_tiles16<1, 2, 0>(wc3[0], lane, 2, ring3[0]);
-          preload_tiles16<1, 2, 0>(wc3[1], lane, 2, ring3[1]);
-          layer_tiles16p<GH, HID / 16, HID / 16, 4, WD, RB_C2, 0>(reinterpret_cast<const float4*>(hA), wc2, none, lane, acc, ring);
-          if (!last_step) preload_tiles16<4, WD, 0>(wa1, lane, G1, ring);      // the next step's first weights
-#pragma unroll
-          for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[3][q], 4 * wq + q, lane, hB);
-        }
+        for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[3][q], 4 * wq + q, lane, hB);
       }
       BAR();     // obs_{t+1} and its images are complete (environment waves)
     }
@@ -1098,44 +1093,69 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
   t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
   t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
   const double gear_s = slot < nu ? m->gear[slot] : 1.0;
+  const bool unit_gear = __ballot(gear_s != 1.0) == 0;     // x / 1.0 == x: no fp64 division chains in the step
   int dst_b = -1;
   if (slot < 3) dst_b = L_LV + slot;
   else if (slot < 6) dst_b = L_RV + slot - 3;
   else if (slot < 10) dst_b = L_BQ + slot - 6;
   else if (slot < 13) dst_b = L_AV + slot - 10;
-  auto request = [&](int k, int n, int slot, Readback& rb) {
+  // The readback row of step k as this lane's pieces: the element each lane loads from each array is the same every
+  // step up to the block stride, so pointer (block 0) and stride are formed ONCE (the first form recomputed ~150
+  // address instructions per step to keep forty 64-bit addresses from being hoisted and spilled: nine pointers
+  // fit easily here).
+  const double *pa = nullptr, *pb = nullptr, *pl = nullptr, *pv = nullptr, *pf = nullptr, *pz = nullptr;
+  const int32_t *pn = nullptr, *pg1 = nullptr, *pg2 = nullptr;
+  unsigned sa = 0, sb = 0;                       // strides (elements) of the two by-slot arrays
+  const unsigned s_u = (unsigned)nu * (unsigned)N, s_c = (unsigned)C * (unsigned)N;
+  if (env_ok) {
+    const size_t r3 = (size_t)n * 3, r4 = (size_t)n * 4;
+    pn = p.b.ncon + n;
+    if (slot < 4) { pa = p.b.root_quat + r4 + slot; sa = 4u * N; }
+    else if (slot < 7) { pa = p.b.root_pos + r3 + slot - 4; sa = 3u * N; }
+    else if (slot < 10) { pa = p.b.head_pos + r3 + slot - 7; sa = 3u * N; }
+    else if (slot < 13) { pa = p.b.lf_pos + r3 + slot - 10; sa = 3u * N; }
+    else { pa = p.b.rf_pos + r3 + slot - 13; sa = 3u * N; }
+    if (slot < 3) { pb = p.b.lf_vel + r3 + slot; sb = 3u * N; }
+    else if (slot < 6) { pb = p.b.rf_vel + r3 + slot - 3; sb = 3u * N; }
+    else if (slot < 10) { pb = p.b.qpos + (size_t)n * nq + 3 + slot - 6; sb = (unsigned)nq * N; }
+    else if (slot < 13) { pb = p.b.qvel + (size_t)n * nv + 3 + slot - 10; sb = (unsigned)nv * N; }
+    if (slot < nu) {
+      pl = p.b.act_len + (size_t)n * nu + slot;
+      pv = p.b.act_vel + (size_t)n * nu + slot;
+    }
+    if (slot < C) {
+      const size_t e0 = (size_t)n * C + slot;
+      pg1 = p.b.geom1 + e0;
+      pg2 = p.b.geom2 + e0;
+      pf = p.b.force6 + e0 * 6;
+      pz = p.b.cpos_z + e0;
+    }
+  }
+  auto request = [&](int k, Readback& rb) {
     rb.nc_raw = 0; rb.g1_0 = -1; rb.g2_0 = -1;
     rb.va = rb.vb = rb.v_len = rb.v_vel = rb.pz0 = 0.0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) rb.f0[q] = 0.0;
     if (!env_ok) return;
-    const size_t kN = (size_t)((unsigned)k % (unsigned)p.b.K) * N;
-    rb.nc_raw = p.b.ncon[kN + n];
-    const size_t r3 = (kN + n) * 3, r4 = (kN + n) * 4;
-    if (slot < 4) rb.va = p.b.root_quat[r4 + slot];
-    else if (slot < 7) rb.va = p.b.root_pos[r3 + slot - 4];
-    else if (slot < 10) rb.va = p.b.head_pos[r3 + slot - 7];
-    else if (slot < 13) rb.va = p.b.lf_pos[r3 + slot - 10];
-    else rb.va = p.b.rf_pos[r3 + slot - 13];
-    if (slot < 3) rb.vb = p.b.lf_vel[r3 + slot];
-    else if (slot < 6) rb.vb = p.b.rf_vel[r3 + slot - 3];
-    else if (slot < 10) rb.vb = p.b.qpos[(kN + n) * nq + 3 + slot - 6];
-    else if (slot < 13) rb.vb = p.b.qvel[(kN + n) * nv + 3 + slot - 10];
-    if (slot < nu) {
-      rb.v_len = p.b.act_len[(kN + n) * nu + slot];
-      rb.v_vel = p.b.act_vel[(kN + n) * nu + slot];
+    const size_t kk = (size_t)((unsigned)k % (unsigned)p.b.K);
+    rb.nc_raw = pn[kk * (unsigned)N];
+    rb.va = pa[kk * sa];
+    if (pb) rb.vb = pb[kk * sb];
+    if (pl) {
+      rb.v_len = pl[kk * s_u];
+      rb.v_vel = pv[kk * s_u];
     }
-    if (slot < C) {
-      const size_t e0 = (kN + n) * C + slot;
-      rb.g1_0 = p.b.geom1[e0];
-      rb.g2_0 = p.b.geom2[e0];
+    if (pf) {
+      rb.g1_0 = pg1[kk * s_c];
+      rb.g2_0 = pg2[kk * s_c];
+      const double* f = pf + kk * s_c * 6;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) rb.f0[q] = p.b.force6[e0 * 6 + q];
-      rb.pz0 = p.b.cpos_z[e0];
+      for (int q = 0; q < 6; ++q) rb.f0[q] = f[q];
+      rb.pz0 = pz[kk * s_c];
     }
   };
   Readback rb;
-  request(k0, n, slot, rb);
+  request(k0, rb);
   __syncthreads();
 
   unsigned long long st_sub[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_sl = 0;
@@ -1232,7 +1252,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
     const bool bad = (cnt_r + cnt_l) != nc_raw;
     SUB(1);
     // this step's readback registers are consumed: request step t + 1's rows now, a whole step ahead of their use
-    if (!last_step) request(k0 + (t + 1 - t0), n_t, slot_t, rb);
+    if (!last_step) request(k0 + (t + 1 - t0), rb);
     SUB(2);
     if (env_ok && slot == 0) {
       int* si = s_int + el * SI_N;
@@ -1377,8 +1397,9 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       if (slot >= 4 && slot < 7) op[slot] = (float)se[L_AV + slot - 4];
       if (slot < nu) {
         const double g = gear_s;
-        op[7 + slot] = (float)(se[L_AL + slot] / g);
-        op[7 + nu + slot] = (float)(se[L_AVL + slot] / g);
+        const double ql = se[L_AL + slot], qv = se[L_AVL + slot];
+        op[7 + slot] = (float)(unit_gear ? ql : ql / g);
+        op[7 + nu + slot] = (float)(unit_gear ? qv : qv / g);
       }
       if (slot == 7) op[7 + 2 * nu] = (float)se[L_R1 + 2 * 13];
       if (slot == 8) op[8 + 2 * nu] = (float)se[L_R1 + 2 * 13 + 1];
