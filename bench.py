@@ -520,8 +520,9 @@ def config3_block(rk, args):
                    "roofline": {"bound": "mfma", "achieved": flop / (k13_us * 1e-6) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": flop / (k13_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                                 "alg_flop_per_env_step": flop // N,
-                                "note": "a step = forward (matrix cores) THEN the latency-bound environment step on the "
-                                        "same workgroup; phase times in profiles/r03"}},
+                                "note": "a step = the forward (matrix cores, waves 0-3) beside the latency-bound environment "
+                                        "step (fp64, waves 4-7) of the same 16 environments; f32-input MFMAs hold the "
+                                        "vector ALU, so the two nearly add up: interval times in profiles/r03"}},
                "mlp_forward_kernel(K11)": {
                    "us_per_launch": k11_us,
                    "roofline": {"bound": "mfma", "achieved": flop / (k11_us * 1e-6) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,

@@ -4,34 +4,33 @@
 // The two-kernel rollout (K11 forward + K10 vec step per step) pays two dependent launches per step: ~9 us of
 // launch ramp, first-touch loads and epilogues for ~4 us of work at N = 4096.  Environments are independent and the
 // weights are read-only during a rollout, so nothing in the loop needs a grid-wide synchronisation: here a
-// workgroup OWNS 16 environments for all T steps,
+// workgroup OWNS 16 environments for all T steps, with the observation, the task state and the step sequence living
+// in LDS / registers from the first step to the last.
 //
-//     forward(obs_t)  ->  sample / store  ->  env step t (contacts, WalkingTask.step / reward / done / get_obs,
-//                                             cut rules, bootstrap row, env.reset() from the pre-drawn record)
-//                     ->  forward(obs_{t+1}) ...
+// ONE 8-wave workgroup per 16 environments (one per CU at N = 4096), the two halves of a step on DIFFERENT WAVES.
+// In the staged-readback regime the environment step of t does not read action t: the physics that consumed the
+// action has already run, its readback is what is staged (with live physics there is no persistent launch at all:
+// host batcher + K10).  So forward(obs_t) and the environment step that turns readback row t into obs_{t+1} are
+// independent: waves 0-3 ("forward") run actor and critic of obs_t as 16-row tiles on v_mfma_f32_16x16x4_f32,
+// weights streamed from L2 in the packed B-operand layout (mlp_tiles.h), while waves 4-7 ("environment") run step t
+// (contacts, WalkingTask.step / reward / done / get_obs, cut rules, bootstrap row, env.reset() from the pre-drawn
+// record), one wave of each kind per SIMD, exchanging the observation through double-buffered LDS images.
+// History (profiles/r03): v1, one 8-wave workgroup running the matrix phase and the libm phase back to back,
+// 22.7 us per step; v2, grid (N / 16, 2), a 4-wave workgroup per network, two per CU, each running the (then
+// duplicated) environment step itself, 20.4 us; this form 15.9 us: the environment step is computed ONCE per
+// tile, nothing aliases in LDS (no barrier between the phases), no snapshot launch (one workgroup reads and finally
+// overwrites its own tile's state).
+// What the two kinds of wave do NOT do is overlap much: f32-input MFMAs occupy the SIMD's vector ALU for their whole
+// 32 cycles, so beside an MFMA stream a dependent fp64 chain gets ONE instruction in per MFMA (libm 4.7 x slower,
+// measured: profiles/r03/k13_split_interval_times.json).  The step is therefore close to the SUM of the matrix time
+// and the environment time, and the forward waves stand aside (wait at the barrier) during the two libm rounds.
+// s_barrier is workgroup-wide: both kinds of wave execute the same SIX barriers per step (forward: critic output
+// layer of the step before + actor L1 | actor L2 | - | actor L3 + critic L1 | actor sampling | critic L2;
+// environment: contacts | level 1 | libm round 1 | round-2 arguments | libm round 2 | combination).
 //
-// with the observation, the task state and the step sequence living in LDS / registers from the first step to the
-// last.  The order of the reference's loop is kept (the environment step of t follows the forward that produces
-// action t, as it must when the action feeds a physics engine), so a workgroup alternates between a matrix phase and
-// a latency-bound libm phase that leaves the matrix pipes idle.  Geometry therefore: grid (N / 16, 2) = 512
-// workgroups of 4 waves at N = 4096, TWO resident per CU, each on its own environments: while one is in its
-// environment step the other's forward has the matrix cores (v1 of this kernel, one 32-environment / 8-wave
-// workgroup per CU, ran the two phases back to back: 12.8 + 9.9 us per step, profiles/r03/k13_phase_times_first.json).
-// blockIdx.y picks the NETWORK the workgroup evaluates (0: actor, 1: critic) as 16-row tiles on
-// v_mfma_f32_16x16x4_f32, weights streamed from L2 in the packed B-operand layout (mlp_tiles.h).  BOTH workgroups
-// of a 16-environment tile run the (cheap) environment step themselves instead of handing the observation across CUs:
-// a cross-CU hand-off costs 1-3 us per step (MI355X_MICROARCH.md price list), the replayed step needs no
-// synchronisation at all.  Only one workgroup of a pair stores any given array: the actor one the actions, rewards,
-// flags, bootstrap rows and the final task state, the critic one the stored observations and the values.
-// The two workgroups of a tile are NOT guaranteed to run at the same time (a grid larger than the chip holds, e.g.
-// 20007 environments, dispatches the critic workgroups after actor workgroups have finished), and the actor one ends by
-// overwriting the task state both started from.  So the inputs a step loop starts from (task state, step sequences,
-// cursors, the first observation, the counters) are copied by a small launch into caller-provided scratch first, and
-// both workgroups read THAT: nothing a workgroup reads is written by anyone during the launch.
-//
-// Per step the only global traffic on the critical path is the weight stream (L2 hits).  Readback rows and the
-// noise row of step t + 1 are requested right after step t's own rows were consumed, i.e. a whole libm phase and a
-// forward before they are needed; stores are fire-and-forget.
+// Per step the only global traffic on the critical path is the weight stream (L2 hits), kept D groups ahead in a
+// register ring that is not drained between layers.  Readback rows and the noise row of step t + 1 are requested a
+// whole step before they are needed; stores are fire-and-forget.
 //
 // Numerics: the forward is K11's arithmetic (exact f32 fma chains, k ascending; the output layer's eight partial
 // chains over k in [32 j, 32 j + 32) added in order j, bias last) on the 16-row instruction, the environment step
@@ -48,19 +47,16 @@ using oly_mlp::act16_index;
 using oly_mlp::f32x4;
 using oly_mlp::G1N;
 using oly_mlp::HID;
-using oly_mlp::layer_tiles16;
 using oly_mlp::layer_tiles16p;
-using oly_mlp::preload_tiles16;
 using oly_mlp::MAX_IN;
 using oly_mlp::pack_layout;
 using oly_mlp::PackLayout;
-using oly_mlp::store_relu16;
+using oly_mlp::preload_tiles16;
 using oly_mlp::store_relu16v;
 
 namespace {
-constexpr int THREADS = 256;            // 4 waves; two workgroups per CU
 constexpr int SLOTS = A3V_SLOTS;        // lanes per environment
-constexpr int EPW = THREADS / SLOTS;    // environments per workgroup = rows of the MFMA tile
+constexpr int EPW = A3V_EPW;            // environments per workgroup = rows of the MFMA tile
 static_assert(EPW == 16, "a workgroup's environments are one 16-row MFMA tile");
 constexpr int KSPLIT = 8;               // output layer: partial chains over k in [32 j, 32 j + 32), as K11's eight waves
 constexpr int PPITCH = 17;              // pitch of the output layer's partial tiles [chain][row][col]
@@ -68,58 +64,7 @@ constexpr int MAX_NU = 16;
 constexpr int MAX_NOBS = 7 + 2 * MAX_NU + 10;
 constexpr int OBP = MAX_NOBS + 1;       // pitch of the observation rows in LDS
 constexpr int SEQW = A3V_SEQW;          // doubles of one environment's step sequence
-constexpr int OBS_PT = (EPW * MAX_NOBS + THREADS - 1) / THREADS;
-
-// Device copy of everything the rollout kernel reads AND (at its end) overwrites.  Laid out in the caller's scratch
-// buffer (oly_a3_rollout_scratch_bytes): SoA, 8-byte-aligned segments.
-struct Snapshot {
-  const int32_t *phase, *t1, *t2, *frames, *mode, *seq_len, *traj_len, *pool_count, *side_count, *ctr;
-  const uint8_t* target_reached;
-  const double *goal, *sequence;
-  const float* state;
-};
-
-__host__ __device__ inline size_t snap_align(size_t x) { return (x + 15) & ~(size_t)15; }
-struct SnapLayout {
-  size_t ints, ctr, reached, goal, sequence, state, total;      // byte offsets
-};
-__host__ __device__ inline SnapLayout snap_layout(int N, int n_obs) {
-  SnapLayout L;
-  L.ints = 0;                                                  // 9 arrays of N int32
-  L.ctr = snap_align(L.ints + sizeof(int32_t) * 9 * (size_t)N);
-  L.reached = snap_align(L.ctr + sizeof(int32_t) * (2 * (((size_t)N + 15) / 16) + 2));
-  L.goal = snap_align(L.reached + (size_t)N);
-  L.sequence = snap_align(L.goal + sizeof(double) * 8 * (size_t)N);
-  L.state = snap_align(L.sequence + sizeof(double) * SEQW * (size_t)N);
-  L.total = snap_align(L.state + sizeof(float) * (size_t)n_obs * N);
-  return L;
-}
-
-struct SnapArgs {
-  int N, n_obs;
-  oly_a3_state st;
-  oly_a3_rollout ro;
-  unsigned char* scratch;
-};
-
-__global__ __launch_bounds__(256) void a3_rollout_snapshot_kernel(SnapArgs a) {
-  const SnapLayout L = snap_layout(a.N, a.n_obs);
-  const long stride = (long)gridDim.x * blockDim.x, gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int32_t* ints = reinterpret_cast<int32_t*>(a.scratch + L.ints);
-  const int32_t* src[9] = {a.st.phase, a.st.t1, a.st.t2, a.st.reached_frames, a.st.mode, a.st.seq_len, a.ro.traj_len,
-                           a.ro.pool_count, a.ro.side_count};
-  for (long i = gid; i < (long)a.N; i += stride) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) ints[(size_t)k * a.N + i] = src[k][i];
-    (a.scratch + L.reached)[i] = a.st.target_reached[i];
-  }
-  const long nctr = 2 * (((long)a.N + 15) / 16) + 2;
-  for (long i = gid; i < nctr; i += stride) reinterpret_cast<int32_t*>(a.scratch + L.ctr)[i] = a.ro.ctr[i];
-  for (long i = gid; i < 8L * a.N; i += stride) reinterpret_cast<double*>(a.scratch + L.goal)[i] = a.st.goal[i];
-  for (long i = gid; i < (long)SEQW * a.N; i += stride)
-    reinterpret_cast<double*>(a.scratch + L.sequence)[i] = a.st.sequence[i];
-  for (long i = gid; i < (long)a.n_obs * a.N; i += stride) reinterpret_cast<float*>(a.scratch + L.state)[i] = a.ro.state[i];
-}
+constexpr int GEOM_LDS = 1024;          // geom -> body table kept in LDS up to this many geoms
 
 struct RollArgs {
   const A3Dev* md;
@@ -132,22 +77,9 @@ struct RollArgs {
   int out_dim[2], normalize[2];
   float* mu_out;       // [N,nu] mean of the LAST forward (what ro.mu holds after the two-kernel loop), or NULL
   float* value_out;    // [N]    value of the last forward, or NULL
-  Snapshot in;         // the launch's inputs (see a3_rollout_snapshot_kernel): read here, never written
-  int skip;            // diagnostic (OLY_K13_SKIP, tools/time_k13.py): bit 0 no MFMA layers, bit 1 no environment step
+  int skip;            // diagnostic (OLY_K13_SKIP, tools/time_k13.py): bit 0 no MFMA layers, bit 1 no environment step,
+                       // bit 3 interval stamps
 };
-
-// LDS: input image | layer-1 image | layer-2 image (the environment scratch and the output layer's partial tiles
-// alias the two hidden images) | step sequences | observation rows before / after a reset
-constexpr int GEOM_LDS = 1024;          // geom -> body table kept in LDS up to this many geoms
-constexpr size_t ROLL_LDS = sizeof(float) * (MAX_IN + 2 * HID) * EPW + sizeof(double) * EPW * SEQW +
-                            sizeof(float) * 2 * EPW * OBP + sizeof(double) * 4 * OLY_MAX_PERIOD + sizeof(int) * GEOM_LDS;
-static_assert((sizeof(float) * 2 * EPW * OBP) % 8 == 0, "the clock table must stay 8-byte aligned");
-static_assert(sizeof(double) * (EPW * L_ENV + EPW * SLOTS * 2) + EPW * SLOTS + sizeof(int) * EPW * SI_N <=
-                  sizeof(float) * 2 * HID * EPW,
-              "the environment scratch must fit in the activation images it aliases");
-static_assert(sizeof(float) * KSPLIT * EPW * PPITCH <= sizeof(float) * HID * EPW, "partial tiles alias the layer-1 image");
-static_assert((sizeof(float) * MAX_IN * EPW) % 16 == 0 && (sizeof(float) * (MAX_IN + 2 * HID) * EPW) % 8 == 0,
-              "image / fp64 regions must stay aligned");
 
 // An environment's 16 lanes sit in ONE wave, and a wave's LDS operations complete in order: rows that only the
 // environment's own lanes write and read need a compiler / memory-model fence, not a workgroup barrier.
@@ -163,606 +95,6 @@ struct Readback {
   double va, vb, v_len, v_vel, f0[6], pz0;
 };
 
-template <int G1>      // groups of layer 1: 3 (inputs <= 48) or 4
-__global__ __launch_bounds__(THREADS, 2) void a3_rollout_kernel(RollArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xT = lds;                                              // [MAX_IN x EPW]  forward input image
-  float* hA = xT + MAX_IN * EPW;                                // [HID x EPW]     layer-1 image / output-layer partials
-  float* hB = hA + HID * EPW;                                   // [HID x EPW]     layer-2 image
-  double* s_env = reinterpret_cast<double*>(hA);                // [EPW][L_ENV]    (environment phase)
-  double* s_arg = s_env + EPW * L_ENV;                          // [EPW][SLOTS][2]
-  uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_arg + EPW * SLOTS * 2);   // [EPW][SLOTS]
-  int* s_int = reinterpret_cast<int*>(s_cls + EPW * SLOTS);               // [EPW][SI_N]
-  double* seqs = reinterpret_cast<double*>(hB + HID * EPW);     // [EPW][SEQW]     step sequences, whole rollout
-  float* s_pre = reinterpret_cast<float*>(seqs + EPW * SEQW);   // [EPW][OBP]      observation before a reset
-  float* s_post = s_pre + EPW * OBP;                            // [EPW][OBP]      observation the policy sees next
-  // Model tables the environment step indexes per lane.  From global memory they would be VECTOR loads, and vector
-  // memory operations complete in order: a clock-table load issued behind the request for step t + 1's readback rows
-  // (or behind the forward's stores) waits for all of those first - 3 us per step in the first version of this kernel.
-  double* s_lut = reinterpret_cast<double*>(s_post + EPW * OBP);   // [4][period]  clock LUT
-  int* s_gb = reinterpret_cast<int*>(s_lut + 4 * OLY_MAX_PERIOD);  // [ngeom]      geom -> body
-
-  const A3Dev* __restrict__ m = p.md;
-  const int nu = m->nu, n_obs = m->n_obs, period = m->period, nq = m->nq, nv = m->nv;
-  const int N = p.N, T = p.ro.T;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = lane >> 4, slot = lane & (SLOTS - 1);
-  const int el = wave * 4 + grp;
-  const int row0 = blockIdx.x * EPW;
-  const int n = row0 + el;
-  const bool env_ok = n < N;
-  const int rows = min(EPW, N - row0);
-  const int net = blockIdx.y;
-  const bool actor = net == 0;
-  const int out_dim = p.out_dim[net];
-  const bool det = p.ro.deterministic != 0;
-  const PackLayout L = pack_layout(p.in_dim, out_dim);
-  const float* __restrict__ Pbase = p.packed[net];
-  // K10's private (t, k) pair of this 16-environment group
-  const int t0 = p.in.ctr[2 * blockIdx.x];
-  const int k0 = p.in.ctr[2 * blockIdx.x + 1];
-  if (t0 < 0 || t0 > T) {     // counters the caller never rewound: K10's rule (no write, sticky mark behind the counters)
-    if (threadIdx.x == 0) p.ro.ctr[2 * ((N + 15) / 16)] = 1;
-    return;
-  }
-  const int C = p.b.C;
-  const int passes = (C + SLOTS - 1) / SLOTS;
-  double* se = s_env + el * L_ENV;
-  double* sq = seqs + el * SEQW;
-
-  // ---------------------------------------------------------------- task state: registers for the whole rollout
-  int phase0 = 0, t1 = 0, t2 = 0, frames = 0, mode = OLY_MODE_STANDING, seq_len = 1, tlen = 0, rc = 0, sc = 0;
-  int reached_last = 0;
-  double goal_last = 0.0;
-  if (env_ok) {
-    phase0 = p.in.phase[n];
-    t1 = p.in.t1[n];
-    t2 = p.in.t2[n];
-    frames = p.in.frames[n];
-    reached_last = p.in.target_reached[n];
-    mode = p.in.mode[n];
-    seq_len = p.in.seq_len[n];
-    tlen = p.in.traj_len[n];
-    rc = p.in.pool_count[n];
-    sc = p.in.side_count[n];
-    if (slot < 8) goal_last = p.in.goal[8 * (size_t)n + slot];
-#pragma unroll
-    for (int q = 0; q < SEQW / SLOTS; ++q) sq[slot + SLOTS * q] = p.in.sequence[(size_t)n * SEQW + slot + SLOTS * q];
-  }
-  t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
-  t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
-  for (int i = tid; i < 4 * period; i += THREADS) s_lut[i] = m->clock_lut[i];
-  const bool gb_lds = p.cd.ngeom <= GEOM_LDS;
-  if (gb_lds)
-    for (int i = tid; i < p.cd.ngeom; i += THREADS) s_gb[i] = p.cd.geom_bodyid[i];
-  const double gear_s = slot < nu ? m->gear[slot] : 1.0;
-  for (int e = tid; e < rows * n_obs; e += THREADS) {
-    const int r = e / n_obs, c = e - r * n_obs;
-    s_post[r * OBP + c] = p.in.state[(size_t)row0 * n_obs + e];
-  }
-
-  // per-thread constants of the dense sweeps (the element a thread owns does not change from step to step)
-  int ob_src[OBS_PT];                    // LDS offset of observation element tid + q THREADS of the tile
-#pragma unroll
-  for (int q = 0; q < OBS_PT; ++q) {
-    const int e = tid + q * THREADS, r = e / n_obs;
-    ob_src[q] = r * OBP + (e - r * n_obs);
-  }
-  const int xk = tid & (MAX_IN - 1);     // input column this thread stages (THREADS % MAX_IN == 0)
-  float x_mean = 0.f, x_std = 1.f;
-  if (p.normalize[net] && xk < p.in_dim) {
-    x_mean = Pbase[L.mean + xk];
-    x_std = Pbase[L.std + xk];
-  }
-  const int o_row = tid / out_dim, o_col = tid - o_row * out_dim;      // output element this thread finishes
-  const bool o_ok = tid < rows * out_dim;
-  const float o_bias = o_ok ? Pbase[L.b3 + o_col] : 0.f;
-  const float o_scale = (actor && o_ok && !det) ? p.ro.scale[o_col] : 0.f;
-
-  // readback row kk of the staged blocks, one piece per lane (K10's load plan)
-  int dst_b = -1;
-  if (slot < 3) dst_b = L_LV + slot;
-  else if (slot < 6) dst_b = L_RV + slot - 3;
-  else if (slot < 10) dst_b = L_BQ + slot - 6;
-  else if (slot < 13) dst_b = L_AV + slot - 10;
-  auto request = [&](int k, int n, int slot, Readback& rb) {
-    rb.nc_raw = 0; rb.g1_0 = -1; rb.g2_0 = -1;
-    rb.va = rb.vb = rb.v_len = rb.v_vel = rb.pz0 = 0.0;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) rb.f0[q] = 0.0;
-    if (!env_ok) return;
-    const size_t kN = (size_t)((unsigned)k % (unsigned)p.b.K) * N;
-    rb.nc_raw = p.b.ncon[kN + n];
-    const size_t r3 = (kN + n) * 3, r4 = (kN + n) * 4;
-    if (slot < 4) rb.va = p.b.root_quat[r4 + slot];
-    else if (slot < 7) rb.va = p.b.root_pos[r3 + slot - 4];
-    else if (slot < 10) rb.va = p.b.head_pos[r3 + slot - 7];
-    else if (slot < 13) rb.va = p.b.lf_pos[r3 + slot - 10];
-    else rb.va = p.b.rf_pos[r3 + slot - 13];
-    if (slot < 3) rb.vb = p.b.lf_vel[r3 + slot];
-    else if (slot < 6) rb.vb = p.b.rf_vel[r3 + slot - 3];
-    else if (slot < 10) rb.vb = p.b.qpos[(kN + n) * nq + 3 + slot - 6];
-    else if (slot < 13) rb.vb = p.b.qvel[(kN + n) * nv + 3 + slot - 10];
-    if (slot < nu) {
-      rb.v_len = p.b.act_len[(kN + n) * nu + slot];
-      rb.v_vel = p.b.act_vel[(kN + n) * nu + slot];
-    }
-    if (slot < C) {
-      const size_t e0 = (kN + n) * C + slot;
-      rb.g1_0 = p.b.geom1[e0];
-      rb.g2_0 = p.b.geom2[e0];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) rb.f0[q] = p.b.force6[e0 * 6 + q];
-      rb.pz0 = p.b.cpos_z[e0];
-    }
-  };
-  Readback rb;
-  request(k0, n, slot, rb);
-  float eps_next = 0.f;                                      // the noise of the action element this thread samples
-  if (actor && o_ok && !det && t0 < T) eps_next = p.ro.eps[((size_t)t0 * N + row0) * nu + tid];
-  __syncthreads();
-
-  const int skip = p.skip;
-  for (int t = t0; t < T; ++t) {
-    const size_t tN = (size_t)t * N;
-    const bool last_step = t == T - 1;
-    // the weight stream is the same every step: an opaque zero offset keeps the compiler from hoisting its
-    // (loop-invariant) loads out of the step loop and spilling them
-    int opaque0 = 0;
-    asm volatile("" : "+s"(opaque0));
-    const float* P = Pbase + opaque0;
-    const float4* P4 = reinterpret_cast<const float4*>(P);
-    // likewise the per-lane global addresses of some forty arrays: derived from opaque copies of the lane's
-    // environment / element index they are recomputed where used (a multiply-add) instead of being hoisted out
-    // of the loop as 64-bit registers and spilled
-    int n_t = n, tid_t = tid, slot_t = slot;
-    asm volatile("" : "+v"(n_t), "+v"(tid_t), "+v"(slot_t));
-
-    // ================================================================ forward of obs_t (K11's arithmetic, 16-row tiles)
-    for (int e = tid; e < MAX_IN * EPW; e += THREADS) {
-      const int mrow = e / MAX_IN;
-      float v = 0.f;
-      if (mrow < rows && xk < p.in_dim) {
-        v = s_post[mrow * OBP + xk];
-        if (p.normalize[net]) v = (v - x_mean) / x_std;
-      }
-      xT[act16_index(xk, mrow)] = v;
-    }
-    if (!actor) {       // memory.store(state, ...): the observation the policy saw (ppo.py:186)
-#pragma unroll
-      for (int q = 0; q < OBS_PT; ++q) {
-        const int e = tid + q * THREADS;
-        if (e < rows * n_obs) p.ro.buf_states[(tN + row0) * n_obs + tid_t + q * THREADS] = s_post[ob_src[q]];
-      }
-    }
-    const float eps_t = eps_next;
-    __syncthreads();
-    const bool run_mlp = !(skip & 1);
-    if (run_mlp) {  // ---- layer 1: [16, in <= 64] x [64, 256]; wave w owns columns [64 w, 64 w + 64) = 4 tiles
-      f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-      const float4* base = P4 + (L.w1n >> 2) + (size_t)(4 * wave) * G1N * 64;
-      const float4* const w[4] = {base, base + G1N * 64, base + 2 * G1N * 64, base + 3 * G1N * 64};
-      layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xT), w, lane, acc);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) store_relu16(acc[t], P + L.b1, 4 * wave + t, lane, hA);
-    }
-    __syncthreads();
-    if (run_mlp) {  // ---- layer 2: [16, 256] x [256, 256]
-      f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-      const float4* base = P4 + (L.w2n >> 2) + (size_t)(4 * wave) * (HID / 16) * 64;
-      const float4* const w[4] = {base, base + (HID / 16) * 64, base + 2 * (HID / 16) * 64, base + 3 * (HID / 16) * 64};
-      layer_tiles16<HID / 16, 4>(reinterpret_cast<const float4*>(hA), w, lane, acc);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) store_relu16(acc[t], P + L.b2, 4 * wave + t, lane, hB);
-    }
-    __syncthreads();
-    if (run_mlp) {  // ---- layer 3: [16, 256] x [256, out <= 16] as eight partial chains; wave w runs chains 2 w, 2 w + 1
-      const int c = lane & 15, h2 = lane >> 4;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * wave + jj;
-        f32x4 acc[1] = {{0}};
-        const float4* const w[1] = {P4 + (L.w3n >> 2) + (size_t)(2 * j) * 64};
-        layer_tiles16<2, 1>(reinterpret_cast<const float4*>(hB) + (size_t)(2 * j) * 64, w, lane, acc);
-        float* part = hA + (size_t)j * EPW * PPITCH;       // [row][col] partial of chain j
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PPITCH + c] = acc[0][i];
-      }
-    }
-    __syncthreads();
-    if (o_ok) {
-      float s = hA[o_row * PPITCH + o_col];
-#pragma unroll
-      for (int w = 1; w < KSPLIT; ++w) s += hA[(w * EPW + o_row) * PPITCH + o_col];
-      s += o_bias;
-      if (actor) {
-        // Normal(mu, std * anneal).sample() from the pre-drawn noise (ppo.py:181), memory.store's action and the
-        // PD target the physics would receive (robot.py:88-95)
-        float a = s;
-        if (!det) {
-          const float scl = o_scale * eps_t;
-          a = s + scl;
-        }
-        p.ro.buf_actions[(tN + row0) * nu + tid_t] = a;
-        if (last_step) {
-          p.ro.pd_target[(size_t)row0 * nu + tid_t] = (double)a + m->motor_offset[o_col];
-          if (p.mu_out) p.mu_out[(size_t)row0 * nu + tid_t] = s;
-        }
-      } else {
-        p.ro.buf_values[tN + row0 + tid_t] = s;
-        if (last_step && p.value_out) p.value_out[row0 + tid_t] = s;
-      }
-    }
-    __syncthreads();     // the activation images are dead: the environment scratch takes their place
-
-    // ================================================================ environment step t (K10's step)
-    if (skip & 2) continue;
-    if (env_ok) {
-      se[slot] = rb.va;
-      if (dst_b >= 0) se[dst_b] = rb.vb;
-      if (slot < nu) {
-        se[L_AL + slot] = rb.v_len;
-        se[L_AVL + slot] = rb.v_vel;
-      }
-    }
-    // ---- K3: foot contacts of the readback row
-    const int nc_raw = rb.nc_raw;
-    const int nc = min(max(nc_raw, 0), C);
-    int cnt_r = 0, cnt_l = 0;
-    double sum_r = 0.0, sum_l = 0.0, mz = 0.0;
-    bool have = false;
-    for (int ps = 0; ps < passes; ++ps) {
-      const int i = ps * SLOTS + slot;
-      bool is_r = false, is_l = false;
-      double nrm = 0.0, pz = 0.0;
-      if (env_ok && i < nc) {
-        int g1 = rb.g1_0, g2 = rb.g2_0;
-        double f[6] = {rb.f0[0], rb.f0[1], rb.f0[2], rb.f0[3], rb.f0[4], rb.f0[5]};
-        pz = rb.pz0;
-        if (ps > 0) {            // more than 16 contact slots: the later passes load on demand
-          const size_t kN = (size_t)((unsigned)(k0 + (t - t0)) % (unsigned)p.b.K) * N;
-          const size_t e = (kN + n_t) * C + i;
-          g1 = p.b.geom1[e];
-          g2 = p.b.geom2[e];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) f[q] = p.b.force6[e * 6 + q];
-          pz = p.b.cpos_z[e];
-        }
-        if (g1 >= 0 && g1 < p.cd.ngeom && g2 >= 0 && g2 < p.cd.ngeom) {
-          const int b1 = gb_lds ? s_gb[g1] : p.cd.geom_bodyid[g1], b2 = gb_lds ? s_gb[g2] : p.cd.geom_bodyid[g2];
-          is_r = (b1 == p.cd.floor_body) && (b2 == p.cd.rfoot_body);
-          is_l = (b1 == p.cd.floor_body) && (b2 == p.cd.lfoot_body);
-        }
-        if (is_r || is_l) {
-          double s = 0.0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) s += f[q] * f[q];
-          nrm = sqrt(s);
-        } else {
-          pz = 0.0;
-        }
-      }
-      const unsigned long long br = __ballot(is_r), bl = __ballot(is_l);
-      const unsigned mr = (unsigned)((br >> (grp * SLOTS)) & 0xffffu);
-      const unsigned ml = (unsigned)((bl >> (grp * SLOTS)) & 0xffffu);
-      cnt_r += __popc(mr);
-      cnt_l += __popc(ml);
-      // In-order chain over the matching slots (contact order), as contact_kernel / K10: ((0 + n_a) + n_b) + ...
-      // K10 walks the set bits with two 64-bit shuffles per contact (~400 cycles each round); here every lane parks its
-      // norm / height in the environment's scratch row (same wave: LDS operations of a wave complete in order, no
-      // barrier needed) and each lane runs the chain over the 16 slots from LDS broadcasts.
-      double* cn = se + L_R1;            // [16] norms, [16] heights: the libm result rows, unused until round 1
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (a later pass overwrites what this one read)
-      cn[slot] = nrm;
-      cn[SLOTS + slot] = pz;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const unsigned any = mr | ml;
-#pragma unroll
-      for (int q = 0; q < SLOTS; ++q) {     // (measured: this form 2.3 us, branch-free selects 2.7, a loop to the highest
-        const double vk = cn[q], zk = cn[SLOTS + q];    // matching slot 2.9, K10's shuffle walk 3.2)
-        if ((any >> q) & 1u) {
-          if ((mr >> q) & 1u) sum_r += vk;
-          if ((ml >> q) & 1u) sum_l += vk;
-          if (!have || zk < mz) mz = zk;
-          have = true;
-        }
-      }
-    }
-    const double grf_r = sum_r, grf_l = sum_l;
-    const double min_z = have ? mz : 0.0;
-    const bool bad = (cnt_r + cnt_l) != nc_raw;
-    // this step's readback registers are consumed: request step t + 1's rows and noise now, a whole libm phase
-    // and a forward ahead of their use
-    if (!last_step) {
-      request(k0 + (t + 1 - t0), n_t, slot_t, rb);
-      if (actor && o_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + tid_t];
-    }
-    // what the level-1 tasks need from this environment's lanes
-    if (env_ok && slot == 0) {
-      int* si = s_int + el * SI_N;
-      si[I_PHASE0] = phase0; si[I_T1] = t1; si[I_T2] = t2; si[I_FRAMES] = frames; si[I_MODE] = mode;
-      si[I_SEQLEN] = seq_len; si[I_TLEN] = tlen; si[I_RC] = rc; si[I_BAD] = bad; si[I_HAVEC] = (cnt_r > 0 || cnt_l > 0);
-      se[L_GR] = grf_r; se[L_GL] = grf_l; se[L_MZ] = min_z;
-    }
-    __syncthreads();
-
-    // ---- level 1: everything without libm, as four tasks, one per wave, one LANE per environment (a3_vec_core.h)
-    {
-      Level1Ctx lc;
-      lc.m = m; lc.s_env = s_env; lc.seqs = seqs; lc.s_int = s_int; lc.s_arg = s_arg; lc.s_cls = s_cls; lc.s_lut = s_lut;
-      lc.period = period; lc.rows = rows; lc.last_step = last_step; lc.max_traj_len = p.ro.max_traj_len;
-      lc.pool = p.ro.pool; lc.pool_depth = p.ro.pool_depth; lc.row0 = row0;
-      level1_tasks(lc, wave, lane);
-    }
-    __syncthreads();
-    double r0, r1;
-    const int ee = lane & 15;
-    {
-      constexpr int R1_TASK[4][4] = {{0, 1, 6, 13}, {2, 3, 4, 5}, {7, 8, 9, 10}, {11, 12, 14, -1}};
-      const int task = R1_TASK[wave][lane >> 4];
-      if (task >= 0) {
-        eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
-        s_env[ee * L_ENV + L_R1 + 2 * task] = r0;
-        s_env[ee * L_ENV + L_R1 + 2 * task + 1] = r1;
-      }
-    }
-    __syncthreads();
-
-    // ---- back on the environment's own lanes: what the level-1 tasks decided, and the few values the rest of the
-    // step needs from them (the goal steps are formed here: they need task 0's step indices and task 1's rotation)
-    const int* si_ = s_int + el * SI_N;
-    const int phase = si_[O_PHASE];
-    const int reached = si_[O_REACHED];
-    t1 = si_[O_T1];
-    t2 = si_[O_T2];
-    frames = si_[O_FRAMES];
-    const bool done = si_[O_DONE] != 0, cut = si_[O_CUT] != 0;
-    const bool need_reset = env_ok && si_[O_RESET] != 0;
-    const int new_mode = si_[O_NEWMODE], new_phase = si_[O_NEWPHASE], new_len = si_[O_NEWLEN];
-    const int len = tlen + 1;
-    const bool walking = mode != OLY_MODE_STANDING;
-    const double rq0 = se[L_RQ], rq1 = se[L_RQ + 1], rq2 = se[L_RQ + 2], rq3 = se[L_RQ + 3];
-    const double rp0 = se[L_RP], rp1 = se[L_RP + 1], rp2 = se[L_RP + 2];
-    const double lf0 = se[L_LF], lf1 = se[L_LF + 1];
-    const double rf0 = se[L_RF], rf1 = se[L_RF + 1];
-    double R[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) R[i][j] = se[L_ROT + 3 * i + j];
-    double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (walking) {
-      const int selA = 4 * t1, selB = 4 * t2;   // sequence[t1] / sequence[t2] after the update
-      const double s1x = sq[selA], s1y = sq[selA + 1], s1z = sq[selA + 2];
-      const double s2x = sq[selB], s2y = sq[selB + 1], s2z = sq[selB + 2];
-      const double a0 = s1x - rp0, a1 = s1y - rp1, a2 = s1z - rp2;
-      const double b0 = s2x - rp0, b1 = s2y - rp1, b2 = s2z - rp2;
-      goal[0] = R[0][0] * a0 + R[1][0] * a1 + R[2][0] * a2;
-      goal[2] = R[0][1] * a0 + R[1][1] * a1 + R[2][1] * a2;
-      goal[4] = R[0][2] * a0 + R[1][2] * a1 + R[2][2] * a2;
-      goal[1] = R[0][0] * b0 + R[1][0] * b1 + R[2][0] * b2;
-      goal[3] = R[0][1] * b0 + R[1][1] * b1 + R[2][1] * b2;
-      goal[5] = R[0][2] * b0 + R[1][2] * b1 + R[2][2] * b2;
-    }
-    // env.reset(): the rows of the next pool record (its header went through task 3); needed after round 2 only
-    double rec_seq[(OLY_MAX_SEQ + SLOTS - 1) / SLOTS][4];
-#pragma unroll
-    for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q)
-      rec_seq[q][0] = rec_seq[q][1] = rec_seq[q][2] = rec_seq[q][3] = 0.0;
-    if (need_reset) {
-      const oly_a3_reset_record* rec = p.ro.pool + (size_t)n_t * p.ro.pool_depth + (unsigned)rc % (unsigned)p.ro.pool_depth;
-#pragma unroll
-      for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
-        const int r = slot + SLOTS * q;
-        if (r < OLY_MAX_SEQ) {
-          rec_seq[q][0] = rec->seq[r][0]; rec_seq[q][1] = rec->seq[r][1];
-          rec_seq[q][2] = rec->seq[r][2]; rec_seq[q][3] = rec->seq[r][3];
-        }
-      }
-    }
-
-    // ---- round 2
-    const double root_yaw = se[L_R1 + 2 * 14];
-    int cls = F_NONE;
-    double a = 0.0, b = 0.0;
-    switch (slot) {
-      case 0:
-      case 1:
-        if (walking) {   // theta = mat2euler(R^T Rz(yaw))[2] = atan2(M10, M00)
-          const double c = se[L_R1 + 2 * slot + 1], sn = se[L_R1 + 2 * slot];
-          cls = F_ATAN2;
-          a = R[0][1] * c + R[1][1] * sn;
-          b = R[0][0] * c + R[1][0] * sn;
-        }
-        break;
-      case 2: {          // body orientation: exp(-10 (1 - <q_ref, q>^2))
-        const double tq0 = se[L_R1 + 2 * 6 + 1], tq3 = se[L_R1 + 2 * 6];
-        const double ip = tq0 * rq0 + 0.0 * rq1 + 0.0 * rq2 + tq3 * rq3;
-        cls = F_EXP;
-        a = -(10 * (1 - ip * ip));
-      } break;
-      case 3: cls = F_SINCOS; a = se[L_R1 + 2 * 11] / 2.0; break;                    // roll / 2
-      case 4: cls = F_SINCOS; a = se[L_R1 + 2 * 12] / 2.0; break;                    // pitch / 2
-      case 5: if (need_reset) { cls = F_SINCOS; a = root_yaw; } break;               // transform_sequence rotation
-      default: break;
-    }
-    if (slot < 6) {
-      s_arg[(el * SLOTS + slot) * 2] = a;
-      s_arg[(el * SLOTS + slot) * 2 + 1] = b;
-      s_cls[el * SLOTS + slot] = (uint8_t)(env_ok ? cls : F_NONE);
-    }
-    __syncthreads();
-    {
-      // wave 0: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's clock-after-reset, slot 15, which only
-      // needed level-1 values); wave 1: atan2 (the two goal yaws); wave 2: exp (orientation); wave 3: idle
-      constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
-      const int task = R2_TASK[wave][lane >> 4];
-      if (task >= 0) {
-        eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
-        const int dst = task == 15 ? L_R1 + 2 * 15 : L_R2 + 2 * task;
-        s_env[ee * L_ENV + dst] = r0;
-        s_env[ee * L_ENV + dst + 1] = r1;
-      }
-    }
-    __syncthreads();
-
-    // ---- combine, observation rows
-    float* op = s_pre + el * OBP;
-    float* oq = s_post + el * OBP;
-    if (env_ok) {
-      if (walking) {
-        goal[6] = se[L_R2 + 0];
-        goal[7] = se[L_R2 + 2];
-      }
-      const double ci = se[L_R2 + 2 * 3 + 1], si = se[L_R2 + 2 * 3], cj = se[L_R2 + 2 * 4 + 1], sj = se[L_R2 + 2 * 4];
-      if (slot == 0) op[0] = (float)(ci * cj);
-      if (slot == 1) op[1] = (float)(si * cj);
-      if (slot == 2) op[2] = (float)(ci * sj);
-      if (slot == 3) op[3] = (float)(-(si * sj));
-      if (slot >= 4 && slot < 7) op[slot] = (float)se[L_AV + slot - 4];
-      if (slot < nu) {
-        const double g = gear_s;
-        op[7 + slot] = (float)(se[L_AL + slot] / g);
-        op[7 + nu + slot] = (float)(se[L_AVL + slot] / g);
-      }
-      if (slot == 7) op[7 + 2 * nu] = (float)se[L_R1 + 2 * 13];
-      if (slot == 8) op[8 + 2 * nu] = (float)se[L_R1 + 2 * 13 + 1];
-      if (slot >= 8) op[9 + 2 * nu + slot - 8] = (float)goal[slot - 8];
-    }
-    wave_lds_fence();       // the observation row of an environment is assembled and re-read by its own lanes
-    if (env_ok) {
-      for (int c = slot; c < n_obs; c += SLOTS) {
-        float v = op[c];
-        if (need_reset) {   // get_obs of the freshly reset task: goal steps zero, clock of the drawn phase
-          if (c == 7 + 2 * nu) v = (float)se[L_R1 + 2 * 15];
-          else if (c == 8 + 2 * nu) v = (float)se[L_R1 + 2 * 15 + 1];
-          else if (c >= 9 + 2 * nu) v = 0.0f;
-        }
-        oq[c] = v;
-      }
-
-      // ---- rewards, flags (stored by the actor workgroup only)
-      if (actor && slot == 0) {
-        const double frc = (se[L_R1 + 2 * 2] + se[L_R1 + 2 * 3]) / 2;
-        const double vel = (se[L_R1 + 2 * 4] + se[L_R1 + 2 * 5]) / 2;
-        const double orient = se[L_R2 + 2 * 2];
-        const double height = se[L_R1 + 2 * 7];
-        const double hit = reached ? se[L_R1 + 2 * 8] : 0.0;
-        const double progress = se[L_R1 + 2 * 9];
-        const double step_r = 0.8 * hit + 0.2 * progress;
-        const double upper = se[L_R1 + 2 * 10];
-        double rew[6];
-        rew[0] = 0.150 * frc;
-        rew[1] = 0.150 * vel;
-        rew[2] = 0.050 * orient;
-        rew[3] = 0.050 * height;
-        rew[4] = 0.450 * step_r;
-        rew[5] = 0.050 * upper;
-        double tot = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          tot += rew[i];
-          if (p.ro.buf_rew6) p.ro.buf_rew6[(tN + n_t) * 6 + i] = (float)rew[i];
-        }
-        p.ro.buf_rewards[tN + n_t] = tot;
-        p.ro.buf_flags[tN + n_t] = (uint8_t)((cut ? OLY_FLAG_LAST : 0) | (done ? OLY_FLAG_ABSORBING : 0));
-      }
-      // bootstrap row: finish_path's last_val = (not done) * V(state) needs V of THIS observation
-      if (cut && !done) {
-        if (actor && sc < p.ro.side_slots) {
-          const size_t srow = (size_t)n_t * p.ro.side_slots + sc;
-          for (int c = slot; c < n_obs; c += SLOTS) p.ro.side_obs[srow * n_obs + c] = op[c];
-          if (slot == 0) p.ro.side_t[srow] = t;
-        }
-        sc += 1;
-      }
-      tlen = cut ? 0 : len;
-      if (need_reset) {
-        // WalkingTask.reset (walking_task.py:321-397) + transform_sequence (:113-135)
-        const double cyw = se[L_R2 + 2 * 5 + 1], syw = se[L_R2 + 2 * 5];
-        const double mid0 = (lf0 + rf0) / 2, mid1 = (lf1 + rf1) / 2;
-#pragma unroll
-        for (int q = 0; q < (OLY_MAX_SEQ + SLOTS - 1) / SLOTS; ++q) {
-          const int r = slot + SLOTS * q;
-          if (r >= OLY_MAX_SEQ) continue;
-          double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
-          if (r < new_len) {
-            const double x = rec_seq[q][0], y = rec_seq[q][1], z = rec_seq[q][2], th = rec_seq[q][3];
-            o0 = mid0 + x * cyw - y * syw;
-            o1 = mid1 + x * syw + y * cyw;
-            o2 = z;
-            o3 = root_yaw + th;
-          }
-          sq[4 * r] = o0; sq[4 * r + 1] = o1; sq[4 * r + 2] = o2; sq[4 * r + 3] = o3;
-        }
-        phase0 = new_phase;
-        t1 = 0;
-        t2 = (new_len == 1) ? 0 : 1;        // t1 = t2 = 0, then update_target_steps
-        frames = 0;
-        reached_last = 0;
-        mode = new_mode;
-        seq_len = new_len;
-        rc += 1;
-        goal_last = 0.0;
-      } else {
-        phase0 = phase;
-        reached_last = reached;
-        if (slot < 8) goal_last = goal[slot];
-      }
-    }
-    __syncthreads();     // s_post is complete (the next forward stages it); the scratch may be overwritten
-  }
-
-  // ---------------------------------------------------------------- the rollout is over: leave the state K10 would
-  if (t0 >= T) return;
-  if (actor) {
-    if (env_ok) {
-      if (slot == 0) {
-        p.st.phase[n] = phase0;
-        p.st.t1[n] = t1;
-        p.st.t2[n] = t2;
-        p.st.reached_frames[n] = frames;
-        p.st.target_reached[n] = (uint8_t)reached_last;
-        const_cast<int32_t*>(p.st.mode)[n] = mode;
-        const_cast<int32_t*>(p.st.seq_len)[n] = seq_len;
-        p.ro.traj_len[n] = tlen;
-        p.ro.pool_count[n] = rc;
-        p.ro.side_count[n] = sc;
-      }
-      if (slot < 8) p.st.goal[8 * (size_t)n + slot] = goal_last;
-      double* seq_out = const_cast<double*>(p.st.sequence) + (size_t)n * SEQW;
-#pragma unroll
-      for (int q = 0; q < SEQW / SLOTS; ++q) seq_out[slot + SLOTS * q] = sq[slot + SLOTS * q];
-    }
-    for (int e = tid; e < rows * n_obs; e += THREADS) {
-      const int r = e / n_obs, c = e - r * n_obs;
-      p.ro.state[(size_t)row0 * n_obs + e] = s_post[r * OBP + c];
-    }
-    if (tid == 0) {
-      p.ro.ctr[2 * blockIdx.x] = T;
-      p.ro.ctr[2 * blockIdx.x + 1] = k0 + (T - t0);
-    }
-  }
-}
-
-// ===============================================================================================================
-// The shipped form: ONE 8-wave workgroup per 16 environments, the two halves of the step on DIFFERENT WAVES.
-//
-// In the staged-readback regime the environment step of t does not read action t: the physics that consumed the
-// action has already run, its readback is what is staged (with live physics there is no persistent launch at all:
-// host batcher + K10).  So forward(obs_t) and the environment step that turns readback row t into obs_{t+1} are
-// independent, and the first form's alternation of a matrix phase and a libm phase is not needed: here waves 0-3
-// ("forward") run actor and critic of obs_t while waves 4-7 ("environment") run step t, side by side on the same
-// SIMDs (one wave of each kind per SIMD), meeting once per step.  What that buys over the first form (grid (N / 16, 2),
-// two 4-wave workgroups per tile): the environment step is computed ONCE per tile instead of once per network,
-// the matrix pipes always have a wave with MFMAs to issue, nothing aliases in LDS (no barrier between the phases),
-// no snapshot launch (one workgroup reads and finally overwrites its own tile's state).  s_barrier is workgroup-wide,
-// so both kinds of wave execute the same SIX barriers per step; each role's intervals are placed against the
-// other's (forward: actor L1 | L2 | L3 | critic L1 + actor sampling | L2 | L3; environment: contacts | level 1 |
-// libm round 1 | round-2 arguments | libm round 2 | combination).
-// Arithmetic, stores and final state: exactly the first form's (the tests compare with the two-kernel loop).
 constexpr int THREADS_S = 512;
 constexpr int RTH = 256;                 // threads of one role
 constexpr int OBS_PT_S = (EPW * MAX_NOBS + RTH - 1) / RTH;
@@ -807,7 +139,7 @@ template <int G1>      // groups of layer 1: 3 (inputs <= 48) or 4
       __syncthreads();                                                 \
     }                                                                  \
   } while (0)
-__global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs p) {
+__global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
   double* s_env = reinterpret_cast<double*>(lds8 + S_ENV);      // [EPW][L_ENV]
   double* s_arg = reinterpret_cast<double*>(lds8 + S_ARG);      // [EPW][SLOTS][2]
@@ -916,7 +248,8 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       const size_t tN = (size_t)t * N;
       const bool last_step = t == T - 1;
       const int buf = it & 1;
-      // (see the first form: opaque copies keep loop-invariant weight loads and addresses from being hoisted and spilled)
+      // opaque copies keep the (loop-invariant) weight loads and store addresses from being hoisted out of the step
+      // loop and spilled
       int opaque0 = 0;
       asm volatile("" : "+s"(opaque0));
       const float* Pa = PA + opaque0;
@@ -931,17 +264,16 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
       const bool run_mlp = !(skip & 1);
 
       // Weight pointers of this wave's four column tiles (layers 1, 2) and two partial chains (output layer)
-      const int wqw = (skip & 4) ? 0 : wq;     // diagnostic: every wave streams wave 0's weights (wrong results)
-      const float4* const wa1[4] = {Pa4 + (L.w1n >> 2) + (size_t)(4 * wqw) * G1N * 64, Pa4 + (L.w1n >> 2) + (size_t)(4 * wqw + 1) * G1N * 64,
-                                    Pa4 + (L.w1n >> 2) + (size_t)(4 * wqw + 2) * G1N * 64, Pa4 + (L.w1n >> 2) + (size_t)(4 * wqw + 3) * G1N * 64};
-      const float4* const wa2[4] = {Pa4 + (L.w2n >> 2) + (size_t)(4 * wqw) * (HID / 16) * 64, Pa4 + (L.w2n >> 2) + (size_t)(4 * wqw + 1) * (HID / 16) * 64,
-                                    Pa4 + (L.w2n >> 2) + (size_t)(4 * wqw + 2) * (HID / 16) * 64, Pa4 + (L.w2n >> 2) + (size_t)(4 * wqw + 3) * (HID / 16) * 64};
-      const float4* const wc1[4] = {Pc4 + (L.w1n >> 2) + (size_t)(4 * wqw) * G1N * 64, Pc4 + (L.w1n >> 2) + (size_t)(4 * wqw + 1) * G1N * 64,
-                                    Pc4 + (L.w1n >> 2) + (size_t)(4 * wqw + 2) * G1N * 64, Pc4 + (L.w1n >> 2) + (size_t)(4 * wqw + 3) * G1N * 64};
-      const float4* const wc2[4] = {Pc4 + (L.w2n >> 2) + (size_t)(4 * wqw) * (HID / 16) * 64, Pc4 + (L.w2n >> 2) + (size_t)(4 * wqw + 1) * (HID / 16) * 64,
-                                    Pc4 + (L.w2n >> 2) + (size_t)(4 * wqw + 2) * (HID / 16) * 64, Pc4 + (L.w2n >> 2) + (size_t)(4 * wqw + 3) * (HID / 16) * 64};
-      const float4* const wa3[2][1] = {{Pa4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw)) * 64}, {Pa4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw + 1)) * 64}};
-      const float4* const wc3[2][1] = {{Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw)) * 64}, {Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wqw + 1)) * 64}};
+      const float4* const wa1[4] = {Pa4 + (L.w1n >> 2) + (size_t)(4 * wq) * G1N * 64, Pa4 + (L.w1n >> 2) + (size_t)(4 * wq + 1) * G1N * 64,
+                                    Pa4 + (L.w1n >> 2) + (size_t)(4 * wq + 2) * G1N * 64, Pa4 + (L.w1n >> 2) + (size_t)(4 * wq + 3) * G1N * 64};
+      const float4* const wa2[4] = {Pa4 + (L.w2n >> 2) + (size_t)(4 * wq) * (HID / 16) * 64, Pa4 + (L.w2n >> 2) + (size_t)(4 * wq + 1) * (HID / 16) * 64,
+                                    Pa4 + (L.w2n >> 2) + (size_t)(4 * wq + 2) * (HID / 16) * 64, Pa4 + (L.w2n >> 2) + (size_t)(4 * wq + 3) * (HID / 16) * 64};
+      const float4* const wc1[4] = {Pc4 + (L.w1n >> 2) + (size_t)(4 * wq) * G1N * 64, Pc4 + (L.w1n >> 2) + (size_t)(4 * wq + 1) * G1N * 64,
+                                    Pc4 + (L.w1n >> 2) + (size_t)(4 * wq + 2) * G1N * 64, Pc4 + (L.w1n >> 2) + (size_t)(4 * wq + 3) * G1N * 64};
+      const float4* const wc2[4] = {Pc4 + (L.w2n >> 2) + (size_t)(4 * wq) * (HID / 16) * 64, Pc4 + (L.w2n >> 2) + (size_t)(4 * wq + 1) * (HID / 16) * 64,
+                                    Pc4 + (L.w2n >> 2) + (size_t)(4 * wq + 2) * (HID / 16) * 64, Pc4 + (L.w2n >> 2) + (size_t)(4 * wq + 3) * (HID / 16) * 64};
+      const float4* const wa3[2][1] = {{Pa4 + (L.w3n >> 2) + (size_t)(2 * (2 * wq)) * 64}, {Pa4 + (L.w3n >> 2) + (size_t)(2 * (2 * wq + 1)) * 64}};
+      const float4* const wc3[2][1] = {{Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wq)) * 64}, {Pc4 + (L.w3n >> 2) + (size_t)(2 * (2 * wq + 1)) * 64}};
       const int cc = lane & 15, h2 = lane >> 4;
 
       // ring slots of group 0 of the four hidden layers (mlp_tiles.h: the ring is never drained inside a step)
@@ -1062,7 +394,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
   }
 
   // ============================================================================================== environment waves
-  if (!(skip & 16)) __builtin_amdgcn_s_setprio(3);     // their dependent fp64 chains go ahead of the forward waves' MFMAs
+  __builtin_amdgcn_s_setprio(3);     // their dependent fp64 chains go ahead of the forward waves' MFMAs
   const int grp = lane >> 4, slot = lane & (SLOTS - 1);
   const int el = wq * 4 + grp;
   const int n = row0 + el;
@@ -1540,18 +872,14 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_split_kernel(RollArgs
   }
 }
 #undef BAR
+#undef SUB0
+#undef SUB
 }  // namespace
-
-extern "C" int64_t oly_a3_rollout_scratch_bytes(int N, int n_obs) {
-  if (N <= 0 || n_obs <= 0) return 0;
-  return (int64_t)snap_layout(N, n_obs).total;
-}
 
 extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_blocks* blocks, const oly_a3_state* st,
                                          const oly_a3_rollout* ro, int in_dim, const float* packed_actor,
                                          int normalize_actor, const float* packed_critic, int normalize_critic,
-                                         float* mu_out, float* value_out, void* scratch, int64_t scratch_bytes,
-                                         oly_stream stream) {
+                                         float* mu_out, float* value_out, oly_stream stream) {
   if (!ctx) return OLY_EINVAL;
   if (!ctx->a3_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_rollout_persistent before oly_a3_configure");
   if (!ctx->contact_ok) OLY_FAIL(ctx, OLY_ENOTCONF, "oly_a3_rollout_persistent before oly_contact_configure");
@@ -1577,17 +905,6 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
              ctx->a3_host.n_obs);
   if (((reinterpret_cast<uintptr_t>(packed_actor) | reinterpret_cast<uintptr_t>(packed_critic)) & 15) != 0)
     OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: packed weights must be 16-byte aligned");
-  const SnapLayout SL = snap_layout(N, in_dim);
-  if (!scratch || scratch_bytes < (int64_t)SL.total || (reinterpret_cast<uintptr_t>(scratch) & 15) != 0)
-    OLY_FAIL(ctx, OLY_EINVAL, "oly_a3_rollout_persistent: scratch must be 16-byte aligned and hold %zu bytes "
-             "(oly_a3_rollout_scratch_bytes)", SL.total);
-  if (!ctx->roll_attr_done) {
-    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel<3>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROLL_LDS));
-    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel<4>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROLL_LDS));
-    ctx->roll_attr_done = true;
-  }
   RollArgs a;
   a.md = ctx->a3_dev;
   a.cd = ctx->contact;
@@ -1604,43 +921,18 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
   a.normalize[1] = normalize_critic;
   a.mu_out = mu_out;
   a.value_out = value_out;
-  {  // the inputs the step loops start from, copied aside: both workgroups of a tile read these, whenever they run
-    SnapArgs sa{N, in_dim, *st, *ro, static_cast<unsigned char*>(scratch)};
-    long nb = ((long)N * SEQW + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(a3_rollout_snapshot_kernel, dim3((unsigned)nb), dim3(256), 0, oly_s(stream), sa);
-    unsigned char* sc8 = static_cast<unsigned char*>(scratch);
-    const int32_t* ints = reinterpret_cast<const int32_t*>(sc8 + SL.ints);
-    a.in.phase = ints;                     a.in.t1 = ints + (size_t)N;          a.in.t2 = ints + 2 * (size_t)N;
-    a.in.frames = ints + 3 * (size_t)N;    a.in.mode = ints + 4 * (size_t)N;    a.in.seq_len = ints + 5 * (size_t)N;
-    a.in.traj_len = ints + 6 * (size_t)N;  a.in.pool_count = ints + 7 * (size_t)N;
-    a.in.side_count = ints + 8 * (size_t)N;
-    a.in.ctr = reinterpret_cast<const int32_t*>(sc8 + SL.ctr);
-    a.in.target_reached = sc8 + SL.reached;
-    a.in.goal = reinterpret_cast<const double*>(sc8 + SL.goal);
-    a.in.sequence = reinterpret_cast<const double*>(sc8 + SL.sequence);
-    a.in.state = reinterpret_cast<const float*>(sc8 + SL.state);
-  }
   static const int skip = [] { const char* e = getenv("OLY_K13_SKIP"); return e ? atoi(e) : 0; }();
   a.skip = skip;
-  static const int form = [] { const char* e = getenv("OLY_K13_FORM"); return e ? atoi(e) : 0; }();
-  if (form != 1) {
-    if (!ctx->roll_split_attr_done) {
-      OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_split_kernel<3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS));
-      OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_split_kernel<4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS));
-      ctx->roll_split_attr_done = true;
-    }
-    const dim3 grid_s((N + EPW - 1) / EPW);
-    if (in_dim <= 48) hipLaunchKernelGGL(a3_rollout_split_kernel<3>, grid_s, dim3(THREADS_S), SPLIT_LDS, oly_s(stream), a);
-    else hipLaunchKernelGGL(a3_rollout_split_kernel<4>, grid_s, dim3(THREADS_S), SPLIT_LDS, oly_s(stream), a);
-    OLY_LAUNCH_CHECK(ctx, "a3_rollout_split_kernel");
-    return OLY_OK;
+  if (!ctx->roll_attr_done) {
+    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel<3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS));
+    OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel<4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS));
+    ctx->roll_attr_done = true;
   }
-  const dim3 grid((N + EPW - 1) / EPW, 2);
-  if (in_dim <= 48) hipLaunchKernelGGL(a3_rollout_kernel<3>, grid, dim3(THREADS), ROLL_LDS, oly_s(stream), a);
-  else hipLaunchKernelGGL(a3_rollout_kernel<4>, grid, dim3(THREADS), ROLL_LDS, oly_s(stream), a);
+  const dim3 grid_s((N + EPW - 1) / EPW);
+  if (in_dim <= 48) hipLaunchKernelGGL(a3_rollout_kernel<3>, grid_s, dim3(THREADS_S), SPLIT_LDS, oly_s(stream), a);
+  else hipLaunchKernelGGL(a3_rollout_kernel<4>, grid_s, dim3(THREADS_S), SPLIT_LDS, oly_s(stream), a);
   OLY_LAUNCH_CHECK(ctx, "a3_rollout_kernel");
   return OLY_OK;
 }

@@ -72,7 +72,6 @@ struct oly_ctx {
   bool mlp_attr_done = false;   // dynamic-LDS limit of the fused MLP kernel raised on this device
   bool disc_attr_done = false;  // same for the fused discriminator kernel (K12)
   bool roll_attr_done = false;  // same for the persistent rollout kernel (K13)
-  bool roll_split_attr_done = false;
   unsigned scan_attr_done = 0;  // dynamic-LDS limit of the pipelined scan kernels raised on this device
   int num_cu;
 };

@@ -168,8 +168,7 @@ SIGNATURES = {
     "oly_mlp_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "oly_mlp_pack": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "oly_a3_rollout_persistent": (C.c_int, [vp, C.c_int, C.POINTER(A3Blocks), C.POINTER(A3State), C.POINTER(A3Rollout), C.c_int,
-                                            vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int64, vp]),
-    "oly_a3_rollout_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
+                                            vp, C.c_int, vp, C.c_int, vp, vp, vp]),
     "oly_mlp_forward2": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]),
     "oly_return_scan": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                   vp, vp, vp, vp, vp, vp, vp]),

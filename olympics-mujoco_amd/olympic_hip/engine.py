@@ -374,8 +374,6 @@ class Engine:
                 check(h, rc, "oly_a3_vec_step")
             return keep
         pfn = lib().oly_a3_rollout_persistent
-        nscr = int(lib().oly_a3_rollout_scratch_bytes(N, nobs))
-        scratch = []                 # allocated by the first persistent launch, kept with the closure
 
         def persistent(packed_actor, norm_actor, packed_critic, norm_critic, mu_out=None, value_out=None):
             """The remaining steps of the rollout (device counter t .. T - 1) in ONE launch (K13): per step the
@@ -386,11 +384,8 @@ class Engine:
                 _req(mu_out, "mu_out", (N, nu), f32, dv)
             if value_out is not None:
                 _req(value_out, "value_out", (N,), f32, dv)
-            if not scratch:
-                scratch.append(torch.empty(nscr, dtype=torch.uint8, device=dv))
             rc = pfn(h, N, C.byref(cb), C.byref(cst), C.byref(cr), nobs, ptr(packed_actor), int(bool(norm_actor)),
-                     ptr(packed_critic), int(bool(norm_critic)), ptr(mu_out), ptr(value_out), ptr(scratch[0]),
-                     C.c_int64(nscr), self._s())
+                     ptr(packed_critic), int(bool(norm_critic)), ptr(mu_out), ptr(value_out), self._s())
             if rc:
                 check(h, rc, "oly_a3_rollout_persistent")
             return keep

@@ -555,8 +555,8 @@ def test_vec_step_and_mlp_argument_errors(eng, golden):
     pk = eng.mlp_pack(z(256, 41), z(256), z(256, 256), z(256), z(12, 256), z(12))
     with pytest.raises(OlyError, match="packed_a"):
         eng.mlp_forward2(z(8, 41), pk[:-4].clone(), 12, z(8, 12))                        # not a whole packed stream
-    # the persistent rollout (K13) at the C boundary: scratch too small / missing / misaligned, weights missing, a
-    # network that does not read the observation
+    # the persistent rollout (K13) at the C boundary: weights missing / misaligned, a network that does not read the
+    # observation
     import ctypes as C
     from olympic_hip import _ffi
     L, h = _ffi.lib(), eng.ctx.handle
@@ -564,18 +564,14 @@ def test_vec_step_and_mlp_argument_errors(eng, golden):
     pc = eng.mlp_pack(z(256, 41), z(256), z(256, 256), z(256), z(1, 256), z(1))
     with pytest.raises(OlyError, match="packed_critic"):
         launch.persistent(pk, True, pc[:-4].clone(), False)                              # not a whole packed stream
-    need = int(L.oly_a3_rollout_scratch_bytes(40, 41))
-    assert need > 40 * (9 * 4 + 88 * 8 + 41 * 4) and L.oly_a3_rollout_scratch_bytes(0, 41) == 0
     cb, cst, cr = launch.structs
-    scratch = torch.zeros(need + 16, dtype=torch.uint8, device="cuda")
     P = _ffi.ptr
 
-    def call(in_dim=41, pa=pk, pcr=pc, scr=scratch, nbytes=need):
+    def call(in_dim=41, pa=pk, pcr=pc):
         return L.oly_a3_rollout_persistent(h, 40, C.byref(cb), C.byref(cst), C.byref(cr), in_dim, P(pa), 1, P(pcr), 0, None,
-                                           None, P(scr), C.c_int64(nbytes), eng._s())
-    assert call(nbytes=need - 1) == _abi.OLY_EINVAL and b"scratch" in L.oly_last_error(h)
-    assert call(scr=None) == _abi.OLY_EINVAL
-    assert call(scr=scratch[8:]) == _abi.OLY_EINVAL                                      # not 16-byte aligned
+                                           None, eng._s())
+    off = torch.zeros(pk.numel() + 4, dtype=torch.float32, device="cuda")
+    assert call(pa=off[1:]) == _abi.OLY_EINVAL and b"aligned" in L.oly_last_error(h)    # not 16-byte aligned
     assert call(pcr=None) == _abi.OLY_EINVAL and b"NULL" in L.oly_last_error(h)
     assert call(in_dim=40) == _abi.OLY_EINVAL and b"observation" in L.oly_last_error(h)
     assert call() == _abi.OLY_OK

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Where a step of the persistent rollout kernel (K13) spends its time: HIP-event time of the launch at
 N = 4096, T = 400 with phases switched off (OLY_K13_SKIP: bit 0 = no MFMA layers, bit 1 = no environment step:
-outputs are garbage).  One process per variant (the knob is read once)."""
+outputs are garbage).  One process per variant (the knob is read once).
+--stamps: bit 3 as well: the first forward wave and the first environment wave of workgroup 0 sum, per interval of the
+step (the six barriers), the s_memtime ticks they worked and the ticks they then waited at the barrier, and the
+environment wave the parts of its two longest intervals (buf.values is garbage afterwards)."""
 import json
 import os
 import subprocess
@@ -52,8 +55,6 @@ def main():
     T = int(pos[1]) if len(pos) > 1 else 400
     out = {}
     variants = [(0, "everything", None), (1, "no_mfma_layers", None), (2, "no_environment_step", None), (3, "neither", None)]
-    if "--diag" in sys.argv:      # bit 2: every forward wave streams wave 0's weights (what the L2 traffic costs)
-        variants += [(6, "forward_only_one_weight_stream", None), (4, "everything_one_weight_stream", None)]
     if "--stamps" in sys.argv:    # bit 3: per-interval work / barrier-wait times of workgroup 0 (s_memtime)
         variants = [(8, "everything", None), (10, "no_environment_step", None), (9, "no_mfma_layers", None)]
     for skip, label, _ in variants:
