@@ -98,6 +98,7 @@ struct Readback {
 constexpr int THREADS_S = 512;
 constexpr int RTH = 256;                 // threads of one role
 constexpr int OBS_PT_S = (EPW * MAX_NOBS + RTH - 1) / RTH;
+constexpr int OBS_PL = (MAX_NOBS + SLOTS - 1) / SLOTS;     // observation columns per lane of an environment
 constexpr int IMG = MAX_IN * EPW;        // floats of one input image
 constexpr int PART = KSPLIT * EPW * PPITCH;
 constexpr int WD = 3;                    // weight groups in flight ahead of the MFMAs (forward waves)
@@ -281,8 +282,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
       const float4* const none[4] = {nullptr, nullptr, nullptr, nullptr};
       const float4* const none1[1] = {nullptr};
 
-      // ---- interval 1: the critic's output layer of the step BEFORE (partial tiles); actor layer 1;
-      // memory.store(state, ...) (ppo.py:186)
+      // ---- interval 1: the critic's output layer of the step BEFORE (partial tiles); actor layer 1
       if (run_mlp) {
         if (it == 0) {
           preload_tiles16<4, WD, 0>(wa1, lane, G1, ring);     // (later steps: requested at the end of the step before)
@@ -301,6 +301,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[0][q], 4 * wq + q, lane, hA);
       }
+      // memory.store(state, ...) (ppo.py:186); the noise row of the next step
 #pragma unroll
       for (int q = 0; q < OBS_PT_S; ++q) {
         const int e = rtid + q * RTH;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
       const float eps_t = eps_next;
       if (!last_step && a_ok && !det) eps_next = p.ro.eps[((size_t)(t + 1) * N + row0) * nu + rtid_t];
       BAR();
-      // ---- interval 2: actor layer 2; the value of the step before
+      // ---- interval 2: actor layer 2
       if (run_mlp) {
         preload_tiles16<1, 2, 0>(wa3[0], lane, 2, ring3[0]);
         preload_tiles16<1, 2, 0>(wa3[1], lane, 2, ring3[1]);
@@ -318,11 +319,13 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) store_relu16v(acc[q], bias_r[1][q], 4 * wq + q, lane, hB);
       }
-      if (it > 0 && c_ok) critic_out(t - 1);
+      if (it > 0 && c_ok) critic_out(t - 1);      // the value of the step before (partial tiles complete since barrier 1)
       BAR();
-      // ---- interval 3: nothing.  The environment waves are in libm round 1: a dependent fp64 chain beside an MFMA
+      // ---- interval 3: no matrix work.  The environment waves are in libm round 1: a dependent fp64 chain beside an MFMA
       // stream gets one instruction in per MFMA (4.7 x slower, measured), and they, not these waves, are the longer
       // half of the step, so the matrix work stands aside for the two libm rounds.
+      // (The step's bookkeeping stores stay in intervals 1 and 2, where the environment waves are the longer half
+      // anyway: here they made this interval 0.8 us.)
       BAR();
       if (run_mlp) {  // ---- interval 4: actor output layer as eight partial chains (wave w: chains 2 w, 2 w + 1); critic layer 1
 #pragma unroll
@@ -424,6 +427,9 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
   }
   t1 = min(max(t1, 0), OLY_MAX_SEQ - 1);
   t2 = min(max(t2, 0), OLY_MAX_SEQ - 1);
+  int img_ix[OBS_PL];                     // where this lane's observation columns sit in an input image
+#pragma unroll
+  for (int j = 0; j < OBS_PL; ++j) img_ix[j] = act16_index(min(slot + SLOTS * j, MAX_IN - 1), el);
   const double gear_s = slot < nu ? m->gear[slot] : 1.0;
   const bool unit_gear = __ballot(gear_s != 1.0) == 0;     // x / 1.0 == x: no fp64 division chains in the step
   int dst_b = -1;
@@ -519,7 +525,9 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
     const int nc_raw = rb.nc_raw;
     const int nc = min(max(nc_raw, 0), C);
     int cnt_r = 0, cnt_l = 0;
-    double sum_r = 0.0, sum_l = 0.0, mz = 0.0;
+    // the three in-order chains of the reduction, one per LANE of the environment: slot 0 the right foot's force sum,
+    // slot 1 the left foot's, slot 2 (and the idle rest) the lowest contact height
+    double chain = 0.0;
     bool have = false;
     for (int ps = 0; ps < passes; ++ps) {
       const int i = ps * SLOTS + slot;
@@ -557,9 +565,11 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
       const unsigned ml = (unsigned)((bl >> (grp * SLOTS)) & 0xffffu);
       cnt_r += __popc(mr);
       cnt_l += __popc(ml);
-      // In-order chain over the matching slots (contact order), as contact_kernel / K10: ((0 + n_a) + n_b) + ...
+      // In-order chains over the matching slots (contact order), as contact_kernel / K10: ((0 + n_a) + n_b) + ...
       // Every lane parks its norm / height in the environment's scratch row (same wave: LDS operations of a wave
-      // complete in order, no barrier needed) and each lane runs the chain over the 16 slots from LDS broadcasts.
+      // complete in order, no barrier needed); a chain lane then walks the 16 slots of ITS row: one add or one
+      // compare-and-select per slot instead of all three chains on every lane (~290 -> ~190 vector instructions, and
+      // an instruction of these waves costs an MFMA slot of the forward waves').
       double* cn = se + L_R1;            // [16] norms, [16] heights: the libm result rows, unused until round 1
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (a later pass overwrites what this one read)
       cn[slot] = nrm;
@@ -567,20 +577,20 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const unsigned any = mr | ml;
+      const bool lowest = slot >= 2;
+      const unsigned msel = slot == 0 ? mr : slot == 1 ? ml : (mr | ml);
+      const double* src = cn + (lowest ? SLOTS : 0);
 #pragma unroll
       for (int q = 0; q < SLOTS; ++q) {
-        const double vk = cn[q], zk = cn[SLOTS + q];
-        if ((any >> q) & 1u) {
-          if ((mr >> q) & 1u) sum_r += vk;
-          if ((ml >> q) & 1u) sum_l += vk;
-          if (!have || zk < mz) mz = zk;
+        const double v = src[q];
+        const double added = chain + v;
+        const double lower = (!have || v < chain) ? v : chain;
+        if ((msel >> q) & 1u) {
+          chain = lowest ? lower : added;
           have = true;
         }
       }
     }
-    const double grf_r = sum_r, grf_l = sum_l;
-    const double min_z = have ? mz : 0.0;
     const bool bad = (cnt_r + cnt_l) != nc_raw;
     SUB(1);
     // this step's readback registers are consumed: request step t + 1's rows now, a whole step ahead of their use
@@ -590,8 +600,8 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
       int* si = s_int + el * SI_N;
       si[I_PHASE0] = phase0; si[I_T1] = t1; si[I_T2] = t2; si[I_FRAMES] = frames; si[I_MODE] = mode;
       si[I_SEQLEN] = seq_len; si[I_TLEN] = tlen; si[I_RC] = rc; si[I_BAD] = bad; si[I_HAVEC] = (cnt_r > 0 || cnt_l > 0);
-      se[L_GR] = grf_r; se[L_GL] = grf_l; se[L_MZ] = min_z;
     }
+    if (env_ok && slot < 3) se[slot == 0 ? L_GR : slot == 1 ? L_GL : L_MZ] = (slot < 2 || have) ? chain : 0.0;
     BAR();
 
     // ---- interval 2: level 1, everything without libm, as four tasks, one per wave (a3_vec_core.h)
@@ -721,20 +731,21 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
         goal[6] = se[L_R2 + 0];
         goal[7] = se[L_R2 + 2];
       }
+      // every LDS value a lane needs is read up front, unconditionally (a read inside each `if (slot == k)` is a
+      // serialised LDS round trip per branch)
       const double ci = se[L_R2 + 2 * 3 + 1], si = se[L_R2 + 2 * 3], cj = se[L_R2 + 2 * 4 + 1], sj = se[L_R2 + 2 * 4];
-      if (slot == 0) op[0] = (float)(ci * cj);
-      if (slot == 1) op[1] = (float)(si * cj);
-      if (slot == 2) op[2] = (float)(ci * sj);
-      if (slot == 3) op[3] = (float)(-(si * sj));
-      if (slot >= 4 && slot < 7) op[slot] = (float)se[L_AV + slot - 4];
+      const int xi = slot < 7 ? L_AV + max(slot, 4) - 4 : L_R1 + 2 * 13 + min(slot, 8) - 7;   // slots 4..6: qvel[3:6]; 7, 8: clock
+      const double xv = se[xi];
+      const int mi = min(slot, nu - 1);
+      const double ql = se[L_AL + mi], qv = se[L_AVL + mi];
+      const double lo = slot == 0 ? ci * cj : slot == 1 ? si * cj : slot == 2 ? ci * sj : slot == 3 ? -(si * sj) : xv;
+      if (slot < 7) op[slot] = (float)lo;
       if (slot < nu) {
         const double g = gear_s;
-        const double ql = se[L_AL + slot], qv = se[L_AVL + slot];
         op[7 + slot] = (float)(unit_gear ? ql : ql / g);
         op[7 + nu + slot] = (float)(unit_gear ? qv : qv / g);
       }
-      if (slot == 7) op[7 + 2 * nu] = (float)se[L_R1 + 2 * 13];
-      if (slot == 8) op[8 + 2 * nu] = (float)se[L_R1 + 2 * 13 + 1];
+      if (slot == 7 || slot == 8) op[2 * nu + slot] = (float)xv;
       if (slot >= 8) op[9 + 2 * nu + slot - 8] = (float)goal[slot - 8];
     }
     wave_lds_fence();       // the observation row of an environment is assembled and re-read by its own lanes
@@ -742,8 +753,14 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
     if (env_ok) {
       float* imgA = s_img + (2 * nbuf) * IMG;
       float* imgC = s_img + (2 * nbuf + 1) * IMG;
-      for (int c = slot; c < n_obs; c += SLOTS) {
-        float v = op[c];
+      float vrow[OBS_PL];
+#pragma unroll
+      for (int j = 0; j < OBS_PL; ++j) vrow[j] = op[min(slot + SLOTS * j, n_obs - 1)];     // (all reads first)
+#pragma unroll
+      for (int j = 0; j < OBS_PL; ++j) {
+        const int c = slot + SLOTS * j;
+        if (c >= n_obs) continue;
+        float v = vrow[j];
         if (need_reset) {   // get_obs of the freshly reset task: goal steps zero, clock of the drawn phase
           if (c == 7 + 2 * nu) v = (float)se[L_R1 + 2 * 15];
           else if (c == 8 + 2 * nu) v = (float)se[L_R1 + 2 * 15 + 1];
@@ -754,9 +771,8 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
         float va = v, vc = v;
         if (p.normalize[0]) va = (v - s_norm[c]) / s_norm[MAX_IN + c];
         if (p.normalize[1]) vc = (v - s_norm[2 * MAX_IN + c]) / s_norm[3 * MAX_IN + c];
-        const int ix = act16_index(c, el);
-        imgA[ix] = va;
-        imgC[ix] = vc;
+        imgA[img_ix[j]] = va;
+        imgC[img_ix[j]] = vc;
       }
       SUB(4);
       // ---- rewards, flags
