@@ -214,6 +214,16 @@ __device__ __forceinline__ void store_relu(const f32x16& acc, const float* __res
   }
 }
 
+__device__ __forceinline__ void store_relu_v(const f32x16& acc, float b, int col0, int lane, float* __restrict__ hT) {
+  const int col = col0 + (lane & 31), h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+    const float v = acc[i] + b;
+    hT[(size_t)col * LDP + row] = (v > 0.f || v != v) ? v : 0.f;     // relu, NaN kept like torch
+  }
+}
+
 // G1: groups of layer 1 (4: in <= 32, 8: in <= 64).  XPT = 8 G1 * 32 / 256 input elements per thread.
 template <int G1>
 __global__ __launch_bounds__(THREADS, 2) void disc_forward_kernel(DiscArgs p) {
@@ -227,7 +237,8 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward_kernel(DiscArgs p) {
   double* st = reinterpret_cast<double*>(wd + ZD + 4);   // [2][MAX_IN]  mean, std of the standardiser
   const DiscLayout L = disc_layout(p.D);
   const float* Pbase = p.packed;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // uniform: the weight streams get scalar bases
   const int r = lane & 31, h = lane >> 5;
 
   if (tid < ZD + 4) wd[tid] = Pbase[L.wd + tid];
@@ -273,6 +284,12 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward_kernel(DiscArgs p) {
     }
   };
 
+  // this wave's bias values (its columns do not change from tile to tile): a global load in front of every
+  // accumulator write-back otherwise
+  const float bias0a = Pbase[L.b0 + 64 * wave + r], bias0b = Pbase[L.b0 + 64 * wave + 32 + r];
+  const float bias1 = Pbase[L.b1 + 32 * wave + r];
+  const float bias_mu = Pbase[L.bmu + 32 * wave + r], bias_lv = Pbase[L.blv + 32 * wave + r];
+
   long tile = blockIdx.x;
   if (tile < p.ntiles) {
     load_x(tile);
@@ -294,15 +311,15 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward_kernel(DiscArgs p) {
       const float4* const w[2] = {P4 + (L.w0 >> 2) + (size_t)(2 * wave) * G1 * 64,
                                   P4 + (L.w0 >> 2) + (size_t)(2 * wave + 1) * G1 * 64};
       layer_tiles<G1, 2>(xT, w, lane, acc);
-      store_relu(acc[0], P + L.b0, 64 * wave, lane, hA);
-      store_relu(acc[1], P + L.b0, 64 * wave + 32, lane, hA);
+      store_relu_v(acc[0], bias0a, 64 * wave, lane, hA);
+      store_relu_v(acc[1], bias0b, 64 * wave + 32, lane, hA);
     }
     __syncthreads();
     {  // ---- layer 2: [32, 256] x [256, 128]; wave w owns columns [32 w, 32 w + 32), one chain over all k
       f32x16 acc[1] = {{0}};
       const float4* const w[1] = {P4 + (L.w1 >> 2) + (size_t)wave * (H1 / 8) * 64};
       layer_tiles<H1 / 8, 1>(hA, w, lane, acc);
-      store_relu(acc[0], P + L.b1, 32 * wave, lane, hB);
+      store_relu_v(acc[0], bias1, 32 * wave, lane, hB);
     }
     if (next < p.ntiles) load_x(next);       // in flight behind layer 3
     // the reparameterisation noise of this wave's columns, in flight behind layer 3
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward_kernel(DiscArgs p) {
       const float4* const w[2] = {P4 + (L.wmu >> 2) + (size_t)wave * (H2 / 8) * 64,
                                   P4 + (L.wlv >> 2) + (size_t)wave * (H2 / 8) * 64};
       layer_tiles<H2 / 8, 2>(hB, w, lane, acc);
-      const float bmu = P[L.bmu + col], blv = P[L.blv + col];
+      const float bmu = bias_mu, blv = bias_lv;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
