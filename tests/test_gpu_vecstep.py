@@ -266,15 +266,18 @@ def test_device_rollout_graph_replay_equals_eager_loop(deterministic):
 @pytest.mark.parametrize("N,T,max_len,det,K,C", [(512, 27, 10, False, 7, 16), (500, 13, 4, True, 5, 16),
                                                  (37, 40, 100, False, 3, 16), (4096, 24, 8, False, 32, 16),
                                                  (1, 9, 3, False, 4, 16), (300, 11, 5, False, 4, 20),
-                                                 (100, 9, 4, False, 3, 5), (20007, 6, 3, False, 4, 16)])
+                                                 (100, 9, 4, False, 3, 5), (20007, 6, 3, False, 4, 16),
+                                                 (4096, 400, 400, False, 32, 16),      # BASELINE config 3, whole
+                                                 (4096, 400, 150, True, 32, 16)])
 def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K, C):
-    """K13 (oly_a3_rollout_persistent: ONE launch for the whole rollout, a workgroup owns 32 environments through all
-    T steps, observations / task state never leave the CU) against T rounds of K11 + K10 from the same start: every
+    """K13 (oly_a3_rollout_persistent: ONE launch for the whole rollout, an 8-wave workgroup owns 16 environments through
+    all T steps - four waves the forward, four the environment step - observations / task state never leave the CU)
+    against T rounds of K11 + K10 from the same start: every
     buffer, the bootstrap side list, the final task state, the next observation, the PD targets, the pool cursors and
     the device counters are BIT-identical (integer, float32 and float64 alike), for full and ragged tiles, with the
     actor's input normalisation on, two rollouts in a row (the second continues the replay row and the pools), and for
     20 contact slots (a second, on-demand pass over the slots) and 5 (fewer slots than lanes), and for more workgroups
-    than the chip holds at once (20007 environments = 2502 workgroups: nothing in the kernel needs them co-resident)."""
+    than the chip holds at once (20007 environments = 1251 workgroups), and at BASELINE config 3's own size."""
     from olympic_hip.ppo import MLPCritic, MLPGaussianActor
     torch.manual_seed(5)
     pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
