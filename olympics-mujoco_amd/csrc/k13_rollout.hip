@@ -710,8 +710,10 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
     }
     BAR();
     {  // ---- interval 5: libm round 2.  wave 0: sin/cos (roll / 2, pitch / 2, root yaw, and round 1's
-       // clock-after-reset, slot 15, which only needed level-1 values); wave 1: atan2; wave 2: exp; wave 3: idle
-      constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {2, -1, -1, -1}, {-1, -1, -1, -1}};
+       // clock-after-reset, slot 15, which only needed level-1 values); wave 1: atan2; wave 3: exp (orientation) and,
+       // on the same 16 lanes (one per environment), the step's reward terms and flags, which need nothing else of
+       // this round: every wave used to run them for its own 4 environments in the combination
+      constexpr int R2_TASK[4][4] = {{3, 4, 5, 15}, {0, 1, -1, -1}, {-1, -1, -1, -1}, {2, -1, -1, -1}};
       const int task = R2_TASK[wq][lane >> 4];
       if (task >= 0) {
         eval_task(s_cls[ee * SLOTS + task], s_arg[(ee * SLOTS + task) * 2], s_arg[(ee * SLOTS + task) * 2 + 1], r0, r1);
@@ -719,10 +721,38 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
         s_env[ee * L_ENV + dst] = r0;
         s_env[ee * L_ENV + dst + 1] = r1;
       }
+      if (wq == 3 && lane < rows) {       // lane = environment of the tile
+        const double* sv = s_env + lane * L_ENV;
+        const int* sj = s_int + lane * SI_N;
+        const double frc = (sv[L_R1 + 2 * 2] + sv[L_R1 + 2 * 3]) / 2;
+        const double vel = (sv[L_R1 + 2 * 4] + sv[L_R1 + 2 * 5]) / 2;
+        const double orient = r0;
+        const double height = sv[L_R1 + 2 * 7];
+        const double hit = sj[O_REACHED] ? sv[L_R1 + 2 * 8] : 0.0;
+        const double progress = sv[L_R1 + 2 * 9];
+        const double step_r = 0.8 * hit + 0.2 * progress;
+        const double upper = sv[L_R1 + 2 * 10];
+        double rew[6];
+        rew[0] = 0.150 * frc;
+        rew[1] = 0.150 * vel;
+        rew[2] = 0.050 * orient;
+        rew[3] = 0.050 * height;
+        rew[4] = 0.450 * step_r;
+        rew[5] = 0.050 * upper;
+        const size_t row = tN + row0 + lane;
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          tot += rew[i];
+          if (p.ro.buf_rew6) p.ro.buf_rew6[row * 6 + i] = (float)rew[i];
+        }
+        p.ro.buf_rewards[row] = tot;
+        p.ro.buf_flags[row] = (uint8_t)((sj[O_CUT] ? OLY_FLAG_LAST : 0) | (sj[O_DONE] ? OLY_FLAG_ABSORBING : 0));
+      }
     }
     BAR();
 
-    // ---- interval 6: combination: observation rows and the next input images, rewards, flags, reset
+    // ---- interval 6: combination: observation rows and the next input images, bootstrap rows, reset
     SUB0();
     float* op = s_pre + el * OBP;
     float* oq = s_post + (nbuf * EPW + el) * OBP;
@@ -775,32 +805,6 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
         imgC[img_ix[j]] = vc;
       }
       SUB(4);
-      // ---- rewards, flags
-      if (slot == 0) {
-        const double frc = (se[L_R1 + 2 * 2] + se[L_R1 + 2 * 3]) / 2;
-        const double vel = (se[L_R1 + 2 * 4] + se[L_R1 + 2 * 5]) / 2;
-        const double orient = se[L_R2 + 2 * 2];
-        const double height = se[L_R1 + 2 * 7];
-        const double hit = reached ? se[L_R1 + 2 * 8] : 0.0;
-        const double progress = se[L_R1 + 2 * 9];
-        const double step_r = 0.8 * hit + 0.2 * progress;
-        const double upper = se[L_R1 + 2 * 10];
-        double rew[6];
-        rew[0] = 0.150 * frc;
-        rew[1] = 0.150 * vel;
-        rew[2] = 0.050 * orient;
-        rew[3] = 0.050 * height;
-        rew[4] = 0.450 * step_r;
-        rew[5] = 0.050 * upper;
-        double tot = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          tot += rew[i];
-          if (p.ro.buf_rew6) p.ro.buf_rew6[(tN + n_t) * 6 + i] = (float)rew[i];
-        }
-        p.ro.buf_rewards[tN + n_t] = tot;
-        p.ro.buf_flags[tN + n_t] = (uint8_t)((cut ? OLY_FLAG_LAST : 0) | (done ? OLY_FLAG_ABSORBING : 0));
-      }
       SUB(5);
       // bootstrap row: finish_path's last_val = (not done) * V(state) needs V of THIS observation
       if (cut && !done) {
