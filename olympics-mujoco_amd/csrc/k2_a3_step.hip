@@ -408,19 +408,22 @@ __global__ __launch_bounds__(256) void a3_step16_kernel(A3Args p) {
       goal[7] = se[L_R2 + 2];
     }
     obs_t* op = s_obs + el * (MAXOBS + 1);
+    // every LDS value a lane needs is read up front, unconditionally (a read inside each `if (slot == k)` is a
+    // serialised LDS round trip per branch)
     const double ci = se[L_R2 + 2 * 3 + 1], si = se[L_R2 + 2 * 3], cj = se[L_R2 + 2 * 4 + 1], sj = se[L_R2 + 2 * 4];
-    if (slot == 0) op[0] = (obs_t)(ci * cj);
-    if (slot == 1) op[1] = (obs_t)(si * cj);
-    if (slot == 2) op[2] = (obs_t)(ci * sj);
-    if (slot == 3) op[3] = (obs_t)(-(si * sj));
-    if (slot >= 4 && slot < 7) op[slot] = (obs_t)se[L_AV + slot - 4];
+    const int xi = slot < 7 ? L_AV + max(slot, 4) - 4 : L_R1 + 2 * 13 + min(slot, 8) - 7;   // slots 4..6: qvel[3:6]; 7, 8: clock
+    const double xv = se[xi];
+    const int mi = min(slot, nu - 1);
+    const double ql = se[L_AL + mi], qv = se[L_AVL + mi];
+    const double lo = slot == 0 ? ci * cj : slot == 1 ? si * cj : slot == 2 ? ci * sj : slot == 3 ? -(si * sj) : xv;
+    if (slot < 7) op[slot] = (obs_t)lo;
     if (slot < nu) {
       const double g = m->gear[slot];
-      op[7 + slot] = (obs_t)(se[L_AL + slot] / g);
-      op[7 + nu + slot] = (obs_t)(se[L_AVL + slot] / g);
+      const bool unit = __ballot(g != 1.0) == 0;     // x / 1.0 == x: no fp64 division chain when every gear is 1
+      op[7 + slot] = (obs_t)(unit ? ql : ql / g);
+      op[7 + nu + slot] = (obs_t)(unit ? qv : qv / g);
     }
-    if (slot == 7) op[7 + 2 * nu] = (obs_t)se[L_R1 + 2 * 13];
-    if (slot == 8) op[8 + 2 * nu] = (obs_t)se[L_R1 + 2 * 13 + 1];
+    if (slot == 7 || slot == 8) op[2 * nu + slot] = (obs_t)xv;
     if (slot >= 8) op[9 + 2 * nu + slot - 8] = (obs_t)goal[slot - 8];
     if (slot < 8) p.st.goal[8 * (size_t)n + slot] = goal[slot];
     if (slot == 0) {
