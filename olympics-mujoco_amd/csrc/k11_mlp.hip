@@ -15,6 +15,8 @@
 // and adds the eight partial chains in wave order, then the bias.  Deterministic, and restated
 // bit for bit by the oracle (oly_mlp_forward_cpu); against torch's own fp32 Linear the difference is
 // summation order only (<= 1e-5 relative on these layers).
+#include <cstdlib>
+
 #include "oly_common.h"
 #include "mlp_tiles.h"
 
@@ -152,6 +154,110 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(MlpArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same forward for SMALL batches, 16 rows per workgroup on v_mfma_f32_16x16x4_f32 (the tiles K13 runs inside
+// its step loop, mlp_tiles.h).  4096 rows x 2 networks are 256 of the 32-row tiles: one 8-wave workgroup per CU, a
+// chain of 176 dependent 64-cycle MFMAs per wave with nothing beside it to hide the input load, the barriers and
+// the epilogue.  As 512 four-wave workgroups of 16 rows, two per CU, a tile's chain is half as long (320 MFMAs of
+// 32 cycles on four independent accumulators) and one workgroup's staging overlaps the other's layers.  Same
+// arithmetic value for value: k-ascending fma chains, the output layer as the same eight partial chains over
+// k in [32 j, 32 j + 32) added in order j, bias last (wave w runs chains 2 w and 2 w + 1).
+constexpr int RT16 = 16, THREADS16 = 256, PP16 = MAX_OUT + 1;
+static_assert(KSPLIT * RT16 * PP16 <= (MAX_IN + HID) * RT16, "the output layer's partial tiles alias the input and layer-1 images");
+
+template <int G1>      // groups of 16 inputs in layer 1
+__global__ __launch_bounds__(THREADS16, 2) void mlp_forward16_kernel(MlpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xT = lds;                     // [MAX_IN x 16]  input image (act16 layout); with hA later the partial tiles
+  float* hA = xT + MAX_IN * RT16;      // [HID x 16]     layer-1 image
+  float* hB = hA + HID * RT16;         // [HID x 16]     layer-2 image
+  const MlpNet net = p.net[blockIdx.y];
+  const PackLayout L = pack_layout(p.in_dim, net.out_dim);
+  const float* __restrict__ P = net.packed;
+  const float4* P4 = reinterpret_cast<const float4*>(P);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * RT16;
+  const int rows = min(RT16, p.N - row0);
+  const int in_dim = p.in_dim;
+
+  // ---- stage the input rows, normalised, zero-padded, as the A-operand image
+  for (int e = tid; e < MAX_IN * RT16; e += THREADS16) {
+    const int m = e / MAX_IN, k = e - m * MAX_IN;      // consecutive threads: consecutive k of one row
+    float v = 0.f;
+    if (m < rows && k < in_dim) {
+      v = p.x[(size_t)(row0 + m) * in_dim + k];
+      if (net.normalize) v = (v - P[L.mean + k]) / P[L.std + k];
+    }
+    xT[act16_index(k, m)] = v;
+  }
+  // this wave's hidden-layer biases, requested before the first barrier
+  float bias1[4], bias2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    bias1[t] = P[L.b1 + 16 * (4 * wave + t) + (lane & 15)];
+    bias2[t] = P[L.b2 + 16 * (4 * wave + t) + (lane & 15)];
+  }
+  __syncthreads();
+  {  // ---- layer 1: [16, in <= 64] x [in, 256]; wave w owns column tiles 4 w .. 4 w + 3
+    f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+    const float4* base = P4 + (L.w1n >> 2) + (size_t)(4 * wave) * G1N * 64;
+    const float4* const w[4] = {base, base + G1N * 64, base + 2 * G1N * 64, base + 3 * G1N * 64};
+    layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xT), w, lane, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) store_relu16v(acc[t], bias1[t], 4 * wave + t, lane, hA);
+  }
+  __syncthreads();
+  {  // ---- layer 2: [16, 256] x [256, 256]
+    f32x4 acc[4] = {{0}, {0}, {0}, {0}};
+    const float4* base = P4 + (L.w2n >> 2) + (size_t)(4 * wave) * (HID / 16) * 64;
+    const float4* const w[4] = {base, base + (HID / 16) * 64, base + 2 * (HID / 16) * 64, base + 3 * (HID / 16) * 64};
+    layer_tiles16<HID / 16, 4>(reinterpret_cast<const float4*>(hA), w, lane, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) store_relu16v(acc[t], bias2[t], 4 * wave + t, lane, hB);
+  }
+  __syncthreads();
+  {  // ---- output layer: [16, 256] x [256, out <= 32] as eight partial chains; wave w runs chains 2 w, 2 w + 1
+    const int c = lane & 15, h2 = lane >> 4;
+    const bool two = net.out_dim > 16;           // a second 16-column tile
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * wave + jj;
+      const float4* a4 = reinterpret_cast<const float4*>(hB) + (size_t)(2 * j) * 64;
+      float* part = xT + (size_t)j * RT16 * PP16;                 // [row][col] partial of chain j
+      if (two) {
+        f32x4 acc[2] = {{0}, {0}};
+        const float4* const w[2] = {P4 + (L.w3n >> 2) + (size_t)(2 * j) * 64,
+                                    P4 + (L.w3n >> 2) + (size_t)(HID / 16 + 2 * j) * 64};
+        layer_tiles16<2, 2>(a4, w, lane, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          part[(4 * h2 + i) * PP16 + c] = acc[0][i];
+          part[(4 * h2 + i) * PP16 + 16 + c] = acc[1][i];
+        }
+      } else {
+        f32x4 acc[1] = {{0}};
+        const float4* const w[1] = {P4 + (L.w3n >> 2) + (size_t)(2 * j) * 64};
+        layer_tiles16<2, 1>(a4, w, lane, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(4 * h2 + i) * PP16 + c] = acc[0][i];
+      }
+    }
+  }
+  __syncthreads();
+  const int out_dim = net.out_dim;
+  for (int e = tid; e < rows * out_dim; e += THREADS16) {
+    const int m = e / out_dim, c = e - m * out_dim;
+    float s = xT[m * PP16 + c];
+#pragma unroll
+    for (int w = 1; w < KSPLIT; ++w) s += xT[(w * RT16 + m) * PP16 + c];
+    s += P[L.b3 + c];
+    net.y[(size_t)(row0 + m) * out_dim + c] = s;
+  }
+}
+
+constexpr size_t MLP16_LDS = sizeof(float) * (MAX_IN + 2 * HID) * RT16;
 constexpr size_t MLP_LDS = sizeof(float) * (MAX_IN + 2 * HID) * LDP;
 }  // namespace
 
@@ -195,7 +301,23 @@ extern "C" int oly_mlp_forward2(oly_ctx* ctx, int N, int in_dim, const float* x,
   a.x = x;
   a.net[0] = MlpNet{packed_a, y_a, out_a, normalize_a};
   a.net[1] = MlpNet{packed_b, y_b, out_b, normalize_b};
-  dim3 grid((N + RT - 1) / RT, packed_b ? 2 : 1);
+  // 16-row tiles while the 32-row tiles would leave CUs without a second workgroup (OLY_K11_ROWS = 16 / 32 forces one)
+  static const int force_rows = [] { const char* e = getenv("OLY_K11_ROWS"); return e ? atoi(e) : 0; }();
+  const int nets = packed_b ? 2 : 1;
+  const long slots = 2L * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+  const bool rows16 = force_rows == 16 || (force_rows != 32 && (long)((N + RT - 1) / RT) * nets < slots);
+  if (rows16) {
+    dim3 grid16((N + RT16 - 1) / RT16, nets);
+    switch ((in_dim + 15) / 16) {
+      case 1: hipLaunchKernelGGL(mlp_forward16_kernel<1>, grid16, dim3(THREADS16), MLP16_LDS, oly_s(stream), a); break;
+      case 2: hipLaunchKernelGGL(mlp_forward16_kernel<2>, grid16, dim3(THREADS16), MLP16_LDS, oly_s(stream), a); break;
+      case 3: hipLaunchKernelGGL(mlp_forward16_kernel<3>, grid16, dim3(THREADS16), MLP16_LDS, oly_s(stream), a); break;
+      default: hipLaunchKernelGGL(mlp_forward16_kernel<4>, grid16, dim3(THREADS16), MLP16_LDS, oly_s(stream), a); break;
+    }
+    OLY_LAUNCH_CHECK(ctx, "mlp_forward16_kernel");
+    return OLY_OK;
+  }
+  dim3 grid((N + RT - 1) / RT, nets);
   hipLaunchKernelGGL(mlp_forward_kernel, grid, dim3(THREADS), MLP_LDS, oly_s(stream), a);
   OLY_LAUNCH_CHECK(ctx, "mlp_forward_kernel");
   return OLY_OK;

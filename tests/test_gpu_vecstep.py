@@ -675,6 +675,21 @@ def test_persistent_rollout_random_configurations(seed):
     assert out[0][1] == out[1][1], what
 
 
+@pytest.mark.parametrize("rows", [16, 32])
+def test_fused_mlp_both_tile_heights_on_every_case(rows):
+    """oly_mlp_forward2 picks 16-row tiles (v_mfma_f32_16x16x4_f32, 512 four-wave workgroups for 4096 rows x 2 networks)
+    for small batches and 32-row tiles (v_mfma_f32_32x32x2_f32) for large ones; OLY_K11_ROWS forces one kernel onto
+    every fused-MLP test and the persistent-rollout comparison of this file (the knob is read once per process, hence
+    the child): both are bit-exact against the same oracle."""
+    import subprocess
+    import sys
+    env = dict(os.environ, OLY_K11_ROWS=str(rows))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "(fused_mlp and not both_tile_heights) or persistent_rollout_equals", "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("in_dim,out_a,out_b,N", [(1, 1, 1, 5), (7, 32, 1, 33), (40, 5, 32, 64), (64, 12, 1, 97),
                                                   (63, 31, 2, 200), (33, 1, 17, 31)])
 def test_fused_mlp_other_dimensions_vs_oracle(eng, oracle, in_dim, out_a, out_b, N):
