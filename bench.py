@@ -409,7 +409,7 @@ def config3_sampling(N, dev, T=400, reps=3):
     res["eager_launches"]["launches_per_step"] = res["graph_replay"]["launches_per_step"] = 2
     res["persistent"]["launches_per_rollout"] = 1
     info = env._dev_rollout.last_info
-    res.update({"N": N, "T": T, "kernels": "a3_rollout_kernel (K13) | mlp_forward_kernel (K11) + a3_vec_kernel (K10)",
+    res.update({"N": N, "T": T, "kernels": "a3_rollout_kernel (K13) | mlp_forward16_kernel (K11, 16-row tiles at this batch) + a3_vec_kernel (K10)",
                 "timing": "wall clock of whole rollouts (reset launch, bootstrap pass, reset-pool refill included) / T",
                 "resets_per_rollout": info.get("resets"), "bootstrap_rows": info.get("side_rows"),
                 "round1_host_loop_us_per_vec_step": 360.0, "round2_graph_replay_us_per_vec_step": 33.9})
@@ -523,7 +523,7 @@ def config3_block(rk, args):
                                 "note": "a step = the forward (matrix cores, waves 0-3) beside the latency-bound environment "
                                         "step (fp64, waves 4-7) of the same 16 environments; f32-input MFMAs hold the "
                                         "vector ALU, so the two nearly add up: interval times in profiles/r03"}},
-               "mlp_forward_kernel(K11)": {
+               "mlp_forward16_kernel(K11)": {
                    "us_per_launch": k11_us,
                    "roofline": {"bound": "mfma", "achieved": flop / (k11_us * 1e-6) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": flop / (k11_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
