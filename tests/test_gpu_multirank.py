@@ -127,7 +127,7 @@ def test_bench_default_line_carries_every_baseline_config():
     assert not any("error" in v for v in c.values()), c
     c3 = c["config3_a3_ppo_sampling"]
     assert c3["sampling"]["persistent"]["us_per_vec_step"] < c3["sampling"]["graph_replay"]["us_per_vec_step"]
-    for k, bound in (("a3_rollout_kernel(K13)", "mfma"), ("mlp_forward_kernel(K11)", "mfma"), ("a3_vec_kernel(K10)", "hbm")):
+    for k, bound in (("a3_rollout_kernel(K13)", "mfma"), ("mlp_forward16_kernel(K11)", "mfma"), ("a3_vec_kernel(K10)", "hbm")):
         r = c3["kernels"][k]["roofline"]
         assert r["bound"] == bound and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c4 = c["config4_vail_reward"]
