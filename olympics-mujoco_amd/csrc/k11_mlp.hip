@@ -64,6 +64,16 @@ __global__ void mlp_pack_kernel(PackLayout L, const float* __restrict__ W1, cons
     } else if (e < L.w1n) {
       const int k = (int)(e - L.std);
       v = (std && k < L.in_dim) ? std[k] : 1.f;
+    } else if (e >= L.w2t) {
+      // the transposed-role streams of K14: PT[tile][group][lane][q] = W[n = 16 group + 4 q + (lane >> 4)][k = 16 tile + (lane & 15)]
+      const bool l2 = e < L.w3t;
+      const size_t r = e - (l2 ? L.w2t : L.w3t);
+      const int groups = l2 ? HID / 16 : T3N;
+      const int q = r & 3, lane = (r >> 2) & 63;
+      const int g = (int)((r >> 8) % groups), tile = (int)((r >> 8) / groups);
+      const int n = 16 * g + 4 * q + (lane >> 4), k = 16 * tile + (lane & 15);
+      if (l2) v = W2[(size_t)n * HID + k];
+      else v = n < L.out_dim ? W3[(size_t)n * HID + k] : 0.f;
     } else {
       // the 16-column-tile streams: P16[tile][group][lane][q] = W[16 tile + (lane & 15)][16 group + 4 q + (lane >> 4)]
       const bool l1 = e < L.w2n, l2 = !l1 && e < L.w3n;

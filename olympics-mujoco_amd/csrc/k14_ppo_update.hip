@@ -1,0 +1,721 @@
+// K14: the gradients of ONE PPO minibatch update (PPO.update_policy + the two backward() calls of PPO.train,
+// rl/algos/ppo.py:232-282,396-410) in one launch on the f32 matrix cores: actor and critic forward, the loss terms
+// of K9 (clipped surrogate, value loss, mirror-symmetry loss), and the backward pass down to the parameter
+// gradients torch's autograd would hand to the optimiser.
+//
+// Why: at the config-3 batch (4096 environments x 400 steps, minibatches of 65536 rows) the update phase is 93 % of
+// an iteration, and as library GEMMs + ~40 small torch launches per minibatch it runs at ~20 % of the f32 MFMA peak
+// (hipBLASLt picks 32 x 64 macro tiles for the [256, B] x [B, 256] weight-gradient shapes).  Here a 512-thread
+// workgroup owns 16-row tiles of ONE network and carries a tile through
+//   forward   X -> H1 -> H2 -> out          (the tiles of K11 / K13: mlp_tiles.h, same numerics, so mu / value equal K11's)
+//   loss      d out                         (one wave; K9's arithmetic per row)
+//   backward  dH2 = dZ3 W3, dZ2 = dH2 [H2 > 0], dH1 = dZ2 W2, dZ1 = dH1 [H1 > 0]
+//             dW3 += dZ3^T H2, dW2 += dZ2^T H1, dW1 += dZ1^T X, db += column sums
+// with every activation in LDS and the WEIGHT GRADIENTS IN REGISTERS for the whole launch: wave w owns the 32 rows
+// {32 w .. 32 w + 31} of dW2 / dW1 (128 + 8 KT1 accumulator registers) and 32 columns of dW3.  The matrix cores' k
+// index of a weight-gradient product is the ROW of the tile, and both of its operands are accumulator tiles of
+// earlier products in the C/D register layout (lane l: column l & 15, rows 4 (l >> 4) + i), so dZ is used straight
+// from registers and H from a float4-per-lane LDS image: no transposes.  A workgroup ("part") walks tiles part,
+// part + parts, ...; at the end it stores its partial gradients in parameter order and a finishing launch adds the
+// parts in order (fp64).  256 workgroups = one per CU, split between the networks by their work.
+//
+// Mirror-symmetry loss (ppo.py:261-268): an actor tile runs three sub-passes: forward of the mirrored rows (keeps
+// policy(mirror_obs) only), forward + loss + backward of the rows themselves (d mirror / d det joins d mu), forward
+// again + backward of the mirrored rows with d mirror / d mir.  The mirrored observations are an input array (the
+// env's own mirror_clock_observation, rl/envs/wrappers.py:59-72, evaluated once per iteration); mirror_action is
+// its (index, sign) table.
+//
+// Numerics (restated bit for bit by the oracle twin, oly_ppo_update_cpu): forward as K11; dH chains run over
+// the layer's output index ascending; a weight-gradient element is ONE f32 fma chain over the part's rows in
+// tile order, inside a tile in the order 0,4,8,12,1,5,9,13,...; bias gradients are per-(column, row-group) f32
+// sums combined as (s0 + s1) + (s2 + s3); exp is K12's exp32; log(std) is an input.  Against torch autograd the
+// difference is summation order (tolerance in tests/test_gpu_update.py).
+#include <cstdlib>
+
+#include "oly_common.h"
+#include "mlp_tiles.h"
+
+using namespace oly_mlp;
+namespace {
+
+constexpr int UT = 512;          // 8 waves, two per SIMD
+constexpr int UR = 16;           // rows per tile
+constexpr int PP = 17;           // pitch of the output layer's partial tiles
+constexpr int XI = MAX_IN * UR;  // floats of one input image
+constexpr int HI = HID * UR;     // floats of one hidden image
+constexpr float LOG_SQRT_2PI = 0.9189385332046727f;
+
+// element (row, col) of a [16 rows] x [16 T cols] block in the C/D register layout of v_mfma_f32_16x16x4_f32:
+// image4[tile * 64 + lane] = { value[row = 4 (lane >> 4) + i][col = 16 tile + (lane & 15)] : i = 0..3 }
+__device__ __forceinline__ int c16_index(int col, int row) {
+  return (((col >> 4) * 4 + (row >> 2)) * 16 + (col & 15)) * 4 + (row & 3);
+}
+
+__device__ __forceinline__ float pow2i(int e) { return __int_as_float((e + 127) << 23); }
+// K12's exp32 (k12_disc_forward.hip): f32 fma / rint / exponent arithmetic only, the oracle's copy returns the same bits
+__device__ __forceinline__ float exp32(float x) {
+  if (x != x) return x;
+  if (x > 88.72283935546875f) return __int_as_float(0x7f800000);
+  if (x < -103.97208404541016f) return 0.f;
+  const float n = rintf(x * 1.4426950408889634f);
+  float r = fmaf(n, -0.693145751953125f, x);
+  r = fmaf(n, -1.428606765330187045e-06f, r);
+  float u = 0.000198527617612853646278381f;
+  u = fmaf(u, r, 0.00139304355252534151077271f);
+  u = fmaf(u, r, 0.00833336077630519866943359f);
+  u = fmaf(u, r, 0.0416664853692054748535156f);
+  u = fmaf(u, r, 0.166666671633720397949219f);
+  u = fmaf(u, r, 0.5f);
+  u = 1.0f + fmaf(r * r, u, r);
+  const int q = (int)n, q1 = q >> 1;
+  return (u * pow2i(q1)) * pow2i(q - q1);
+}
+
+struct UpdNet {
+  const float* packed;
+  float* partials;        // [parts][grad_floats]
+  int out_dim, normalize, parts, grad_floats;
+};
+struct UpdArgs {
+  int B, in_dim, act_dim, ntiles;
+  const float *obs, *mir_obs, *action, *adv, *ret, *old_mu;
+  const int* idx;
+  UpdNet net[2];          // actor, critic
+  const float *sd, *log_sd, *old_sd, *old_log_sd;
+  float clip, vf_coeff, mirror_coeff, mirror_gscale, inv_b;
+  const int* act_src;
+  const float* act_sign;
+  double* stat_partials;  // [parts_actor + parts_critic][NSTAT]
+#ifdef OLY_K14_DUMP
+  float* dbg;
+#endif
+};
+constexpr int NSTAT = 6;   // surrogate, kl, clipped, mirror, critic, rows
+
+__device__ __forceinline__ float relu_keep_nan(float v) { return (v > 0.f || v != v) ? v : 0.f; }
+
+// store a C/D-layout value tile (columns 16 tile ..) as the A-operand image of the next product (mlp_tiles.h: act16)
+__device__ __forceinline__ void store_act16(const f32x4& v, int tile, int lane, float* __restrict__ img) {
+  const int c = lane & 15, h2 = lane >> 4;
+  float* dst = img + ((tile * 4 + (c & 3)) * 16 + 4 * h2) * 4 + (c >> 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[4 * i] = v[i];
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// mlp_tiles.h's layer_tiles16 with the weight stream read by buffer loads: ONE per-lane offset register (16 lane) for
+// every stream of the kernel and a wave-uniform byte offset per (tile, group) in SGPRs / the instruction's immediate.
+// (As 64-bit global addresses hipcc keeps a VGPR pair per four groups of every stream alive across the whole item
+// loop, ~60 registers that then spill.)  Same MFMAs in the same order: NT 16-column tiles that share the A operand,
+// G groups of 16 k, weights two groups ahead, activations one group ahead.
+#ifdef OLY_K14_GLOBAL     // diagnostic build: the same loads as plain global loads
+__device__ const char* g_k14_base;
+#define OLY_K14_LOAD(rs, voff, so) (*reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(pbase) + (voff) + (so)))
+#else
+#define OLY_K14_LOAD(rs, voff, so) __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so, 0)
+#endif
+template <int G, int NT>
+__device__ __forceinline__ void layer_tiles16b(const float4* __restrict__ a4, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                               const unsigned (&soff)[NT], int lane, f32x4 (&acc)[NT],
+                                               const float* pbase = nullptr) {
+  u32x4 b[3][NT];
+  float4 a[2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    b[0][t] = OLY_K14_LOAD(rs, voff, soff[t]);
+    if (G > 1) b[1][t] = OLY_K14_LOAD(rs, voff, soff[t] + 1024u);
+  }
+  a[0] = a4[lane];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (g + 2 < G) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[(g + 2) % 3][t] = OLY_K14_LOAD(rs, voff, soff[t] + (unsigned)(g + 2) * 1024u);
+    }
+    if (g + 1 < G) a[(g + 1) & 1] = a4[(g + 1) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads above ahead of this group's MFMAs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float aq = q == 0 ? a[g & 1].x : q == 1 ? a[g & 1].y : q == 2 ? a[g & 1].z : a[g & 1].w;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const u32x4 bb = b[g % 3][t];
+        const float bq = __uint_as_float(q == 0 ? bb.x : q == 1 ? bb.y : q == 2 ? bb.z : bb.w);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int KT1>      // groups of 16 inputs
+__global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xA = lds;                 // [2][XI]   input rows as the A operand of layer 1 (double-buffered over work items)
+  float* xC = xA + 2 * XI;         // [2][XI]   the same rows in the C/D layout: B operand of dW1
+  float* h1A = xC + 2 * XI;        // [HI]      layer-1 activations, A operand of layer 2
+  float* h1C = h1A + HI;           // [HI]      the same in the C/D layout: B operand of dW2, ReLU mask of dH1
+  float* h2A = h1C + HI;           // [HI]      layer-2 activations, A operand of the output layer
+  float* dz2A = h2A;               //           dZ2, A operand of dH1 (the output layer has read h2A two barriers earlier)
+  float* part = h2A + HI;          // [8][16][PP] output layer: the eight partial chains
+  float* mirL = part + 8 * UR * PP;  // [16][16] policy(mirror_obs) of the tile
+  float* dmirL = mirL + UR * 16;   // [16][16]  d loss / d policy(mirror_obs)
+  float* dz3A = dmirL + UR * 16;   // [256]     d loss / d out as an A operand (one group of 16)
+  float* dz3C = dz3A + 256;        // [256]     the same in the C/D layout: A operand of dW3
+  float* cstL = dz3C + 256;        // [8][16]   per-column constants of the loss (wave 0 reads them per tile)
+  double* stL = reinterpret_cast<double*>(cstL + 128);   // [NSTAT][64] wave 0's per-lane statistics
+  float4* dW1L = reinterpret_cast<float4*>(stL + NSTAT * 64);   // [16][KT1][64] dW1 in the C/D layout: the accumulators
+                                   //           of a tile are read, run through its four MFMAs and written back
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, j = lane >> 4;
+  const bool critic = (int)blockIdx.x >= p.net[0].parts;
+  const UpdNet net = p.net[critic ? 1 : 0];
+  const int part_id = (int)blockIdx.x - (critic ? p.net[0].parts : 0);
+  const int parts = net.parts, out_dim = net.out_dim, in_dim = p.in_dim, B = p.B;
+  const PackLayout L = pack_layout(in_dim, out_dim);
+  const float* __restrict__ P = net.packed;
+  const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, (int)(L.total * sizeof(float)), 0x00020000);
+  const unsigned voff = 16u * (unsigned)lane;
+  const bool mirror = !critic && p.mir_obs != nullptr;
+  const int ta = 2 * wave;       // this wave's hidden column tiles: ta, ta + 1
+
+  f32x4 dW2[2][16], dW3[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dW2[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KT1; ++k) dW1L[((ta + t) * KT1 + k) * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dW3[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float db2[2] = {0.f, 0.f}, db1[2] = {0.f, 0.f}, db3 = 0.f;
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < NSTAT; ++q) stL[q * 64 + lane] = 0.0;
+  }
+
+  float bias1[2], bias2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    bias1[t] = P[L.b1 + 16 * (ta + t) + c];
+    bias2[t] = P[L.b2 + 16 * (ta + t) + c];
+  }
+  // staging role of this thread: input column k of rows m0 and m0 + 8
+  const int sk = tid & 63, sm = tid >> 6;
+  float nmean = 0.f, nstd = 1.f;
+  if (net.normalize && sk < in_dim) { nmean = P[L.mean + sk]; nstd = P[L.std + sk]; }
+  // per-column constants of the loss: cstL[f][col], f = bias, sd^2, 2 sd^2, 2 old_sd^2, log sd, log old_sd, mirror sign, mirror index
+  if (tid < 16) {
+    const int col = tid;
+    const bool on = col < out_dim;
+    float v[8] = {on ? P[L.b3 + col] : 0.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+    if (!critic && on) {
+      const float s = p.sd[col], os = p.old_sd[col];
+      v[1] = s * s;
+      v[2] = 2.0f * (s * s);
+      v[3] = 2.0f * (os * os);
+      v[4] = p.log_sd[col];
+      v[5] = p.old_log_sd[col];
+      if (mirror) { v[6] = p.act_sign[col]; v[7] = __int_as_float(p.act_src[col]); }
+    }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) cstL[f * 16 + col] = v[f];
+  }
+  const float lo = 1.0f - p.clip, hi = 1.0f + p.clip;
+
+  const int my_tiles = (p.ntiles - part_id + parts - 1) / parts;
+  const int per_tile = mirror ? 3 : 1;
+  const int n_items = my_tiles * per_tile;
+
+  // the input rows of work item `it` (tile, sub-pass): thread's two elements, normalised, zero-padded
+  auto load_x = [&](int it, float (&v)[2]) {
+    const int tile = part_id + (it / per_tile) * parts;
+    const int sp = mirror ? it % 3 : 1;
+    const float* __restrict__ src = (sp == 1) ? p.obs : p.mir_obs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = tile * UR + sm + 8 * i;
+      float x = 0.f;
+      if (row < B && sk < in_dim) {
+        const long r = p.idx ? (long)p.idx[row] : (long)row;
+        x = src[r * in_dim + sk];
+        if (net.normalize) x = (x - nmean) / nstd;
+      }
+      v[i] = x;
+    }
+  };
+  auto store_x = [&](int buf, const float (&v)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = sm + 8 * i;
+      xA[buf * XI + act16_index(sk, m)] = v[i];
+      xC[buf * XI + c16_index(sk, m)] = v[i];
+    }
+  };
+
+  float xn[2];
+  if (n_items > 0) {
+    load_x(0, xn);
+    store_x(0, xn);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < n_items; ++it) {
+    const int tile = part_id + (it / per_tile) * parts;
+    const int sp = mirror ? it % 3 : 1;     // 0: mirrored rows, forward only; 1: the rows; 2: mirrored rows, forward + backward
+    const int pb = it & 1;
+    const bool more = it + 1 < n_items;
+    if (more) load_x(it + 1, xn);           // in flight behind this item's layers
+    const int grow = tile * UR + c;
+    const bool valid = grow < B;
+    const float4* xA4 = reinterpret_cast<const float4*>(xA + pb * XI);
+    const float4* xC4 = reinterpret_cast<const float4*>(xC + pb * XI);
+    float4* h1C4 = reinterpret_cast<float4*>(h1C);
+
+    {  // ---- layer 1
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const unsigned s0 = (unsigned)(L.w1n * 4) + (unsigned)ta * (G1N * 1024u);
+      const unsigned so[2] = {s0, s0 + G1N * 1024u};
+      layer_tiles16b<KT1, 2>(xA4, rsP, voff, so, lane, acc, P);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[t][i] + bias1[t]);
+        store_act16(v, ta + t, lane, h1A);
+        h1C4[(ta + t) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();
+    f32x4 h2own[2];
+    {  // ---- layer 2
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const unsigned s0 = (unsigned)(L.w2n * 4) + (unsigned)ta * (HID / 16 * 1024u);
+      const unsigned so[2] = {s0, s0 + HID / 16 * 1024u};
+      layer_tiles16b<HID / 16, 2>(reinterpret_cast<const float4*>(h1A), rsP, voff, so, lane, acc, P);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h2own[t][i] = relu_keep_nan(acc[t][i] + bias2[t]);
+        store_act16(h2own[t], ta + t, lane, h2A);
+      }
+    }
+    __syncthreads();
+    // wave 0: the loss inputs of this tile (lane: row c, columns 4 j ..), requested behind the output layer
+    float act[4] = {0.f, 0.f, 0.f, 0.f}, omu[4] = {0.f, 0.f, 0.f, 0.f}, advv = 0.f, retv = 0.f;
+    if (wave == 0 && sp == 1 && valid) {
+      const long r = p.idx ? (long)p.idx[grow] : (long)grow;
+      if (critic) {
+        retv = p.ret[r];
+      } else {
+        advv = p.adv[r];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int col = 4 * j + cc;
+          if (col < out_dim) { act[cc] = p.action[r * out_dim + col]; omu[cc] = p.old_mu[r * out_dim + col]; }
+        }
+      }
+    }
+    {  // ---- output layer: chain `wave` of the eight partial chains (k in [32 wave, 32 wave + 32))
+      f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+      const unsigned so[1] = {(unsigned)(L.w3n * 4) + (unsigned)(2 * wave) * 1024u};
+      layer_tiles16b<2, 1>(reinterpret_cast<const float4*>(h2A) + (size_t)(2 * wave) * 64, rsP, voff, so, lane, acc, P);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[(wave * UR + 4 * j + i) * PP + c] = acc[0][i];
+    }
+    __syncthreads();
+    if (wave == 0) {  // ---- out = partial chains in order + bias; loss terms; d loss / d out   (lane: row c, columns 4 j ..)
+      float o[4], g[4] = {0.f, 0.f, 0.f, 0.f};
+      const float4* cst4 = reinterpret_cast<const float4*>(cstL);
+      const float4 b3q = cst4[j];
+      const float b3v[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int col = 4 * j + cc;
+        float s = part[c * PP + col];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) s += part[(w * UR + c) * PP + col];
+        o[cc] = s + b3v[cc];
+      }
+#ifdef OLY_K14_DUMP
+      if (it == 0) {
+        float* dd = p.dbg + blockIdx.x * 8192;
+        for (int cc = 0; cc < 4; ++cc) dd[c * 16 + 4 * j + cc] = o[cc];
+        for (int e = lane; e < 1024; e += 64) dd[256 + e] = xA[pb * XI + e];
+        for (int e = lane; e < 4096; e += 64) dd[256 + 1024 + e] = h1A[e];
+      }
+#endif
+      if (sp == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) mirL[c * 16 + 4 * j + cc] = o[cc];
+      } else if (sp == 2) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) g[cc] = (4 * j + cc < out_dim) ? dmirL[c * 16 + 4 * j + cc] : 0.f;
+      } else if (critic) {
+        // critic_loss = vf_coeff * mse(ret, value)   (ppo.py:256)
+        const float v = o[0];
+        if (j == 0 && valid) {
+          const float dv = retv - v;
+          stL[4 * 64 + lane] += (double)(dv * dv);
+          g[0] = p.vf_coeff * 2.0f * (v - retv) * p.inv_b;
+        }
+      } else {
+        float t[4], lt[4], olt[4];
+        const float4 q1 = cst4[4 + j], q2 = cst4[8 + j], q3 = cst4[12 + j], q4 = cst4[16 + j], q5 = cst4[20 + j],
+                     q6 = cst4[24 + j], q7 = cst4[28 + j];
+        const float sd2[4] = {q1.x, q1.y, q1.z, q1.w}, sdv2[4] = {q2.x, q2.y, q2.z, q2.w}, osdv2[4] = {q3.x, q3.y, q3.z, q3.w};
+        const float lsd[4] = {q4.x, q4.y, q4.z, q4.w}, olsd[4] = {q5.x, q5.y, q5.z, q5.w}, msg[4] = {q6.x, q6.y, q6.z, q6.w};
+        const int msrc[4] = {__float_as_int(q7.x), __float_as_int(q7.y), __float_as_int(q7.z), __float_as_int(q7.w)};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const bool on = 4 * j + cc < out_dim;
+          t[cc] = act[cc] - o[cc];
+          const float ot = act[cc] - omu[cc];
+          // Normal.log_prob: -((v - loc)**2) / (2*var) - log(scale) - log(sqrt(2 pi))
+          lt[cc] = on ? -(t[cc] * t[cc]) / sdv2[cc] - lsd[cc] - LOG_SQRT_2PI : 0.f;
+          olt[cc] = on ? -(ot * ot) / osdv2[cc] - olsd[cc] - LOG_SQRT_2PI : 0.f;
+        }
+        float lp = 0.f, olp = 0.f;      // sums over the action dimension in order, as torch's .sum(-1) of 12 terms does
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          if (jj < out_dim) {
+            lp += __shfl(lt[jj & 3], c + 16 * (jj >> 2), 64);
+            olp += __shfl(olt[jj & 3], c + 16 * (jj >> 2), 64);
+          }
+        }
+        const float log_ratio = lp - olp;
+        const float ratio = exp32(log_ratio);
+        const float cpi = ratio * advv;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float cl = rc * advv;
+        if (j == 0 && valid) {
+          stL[0 * 64 + lane] += (double)fminf(cpi, cl);
+          stL[1 * 64 + lane] += (double)((ratio - 1.0f) - log_ratio);
+          stL[2 * 64 + lane] += (fabsf(ratio - 1.0f) > p.clip) ? 1.0 : 0.0;
+          stL[5 * 64 + lane] += 1.0;
+        }
+        // torch.min splits the gradient on ties; clamp passes it inside [lo, hi] (inclusive)
+        const float inr = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+        const float wgt = cpi < cl ? 1.0f : (cpi == cl ? 0.5f + 0.5f * inr : inr);
+        const float g_lp = -p.inv_b * advv * wgt * ratio;
+        double mir_sq = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int col = 4 * j + cc;
+          if (col < out_dim && valid) {
+            float gm = g_lp * t[cc] / sd2[cc];
+            if (mirror) {
+              // (det - mirror_action(policy(mirror_obs)))^2 mean   (ppo.py:261-268); det = mu
+              const float d = o[cc] - msg[cc] * mirL[c * 16 + msrc[cc]];
+              mir_sq += (double)(d * d);
+              const float gg = p.mirror_gscale * d;
+              gm = gm + p.mirror_coeff * gg;
+              dmirL[c * 16 + msrc[cc]] = p.mirror_coeff * (-msg[cc] * gg);
+            }
+            g[cc] = gm;
+          } else if (mirror && col < out_dim) {
+            dmirL[c * 16 + msrc[cc]] = 0.f;
+          }
+        }
+        if (mirror) stL[3 * 64 + lane] += mir_sq;
+      }
+      if (sp != 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int col = 4 * j + cc;
+          dz3A[act16_index(col, c)] = g[cc];
+          dz3C[c16_index(col, c)] = g[cc];
+        }
+      }
+    }
+    if (sp != 0) {
+      __syncthreads();
+      // ---- dH2 (own tiles) = dZ3 W3; dZ2 = dH2 [H2 > 0]; dW3 (own columns) += dZ3^T H2; dW2 (own rows) += dZ2^T H1
+      f32x4 dz2[2];
+      {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const unsigned s0 = (unsigned)(L.w3t * 4) + (unsigned)ta * (T3N * 1024u);
+        const unsigned so[2] = {s0, s0 + T3N * 1024u};
+        layer_tiles16b<1, 2>(reinterpret_cast<const float4*>(dz3A), rsP, voff, so, lane, acc, P);
+        const float4 z3 = reinterpret_cast<const float4*>(dz3C)[lane];
+        if (wave == 0) {
+          db3 += z3.x;
+          db3 += z3.y;
+          db3 += z3.z;
+          db3 += z3.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dz2[t][i] = h2own[t][i] > 0.f ? acc[t][i] : 0.f;
+            db2[t] += dz2[t][i];
+          }
+          store_act16(dz2[t], ta + t, lane, dz2A);
+          dW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(z3.x, h2own[t][0], dW3[t], 0, 0, 0);
+          dW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(z3.y, h2own[t][1], dW3[t], 0, 0, 0);
+          dW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(z3.z, h2own[t][2], dW3[t], 0, 0, 0);
+          dW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(z3.w, h2own[t][3], dW3[t], 0, 0, 0);
+        }
+      }
+      {
+        float4 hb[2];
+        hb[0] = h1C4[lane];
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+          if (kt + 1 < 16) hb[(kt + 1) & 1] = h1C4[(kt + 1) * 64 + lane];
+          const float4 b = hb[kt & 1];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            dW2[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[t][0], b.x, dW2[t][kt], 0, 0, 0);
+            dW2[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[t][1], b.y, dW2[t][kt], 0, 0, 0);
+            dW2[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[t][2], b.z, dW2[t][kt], 0, 0, 0);
+            dW2[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[t][3], b.w, dW2[t][kt], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      {  // ---- dH1 (own tiles) = dZ2 W2; dZ1 = dH1 [H1 > 0]; dW1 (own rows) += dZ1^T X
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const unsigned s0 = (unsigned)(L.w2t * 4) + (unsigned)ta * (HID / 16 * 1024u);
+        const unsigned so[2] = {s0, s0 + HID / 16 * 1024u};
+        layer_tiles16b<HID / 16, 2>(reinterpret_cast<const float4*>(dz2A), rsP, voff, so, lane, acc, P);
+        f32x4 dz1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float4 h = h1C4[(ta + t) * 64 + lane];
+          dz1[t][0] = h.x > 0.f ? acc[t][0] : 0.f;
+          dz1[t][1] = h.y > 0.f ? acc[t][1] : 0.f;
+          dz1[t][2] = h.z > 0.f ? acc[t][2] : 0.f;
+          dz1[t][3] = h.w > 0.f ? acc[t][3] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) db1[t] += dz1[t][i];
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) {
+          const float4 b = xC4[kt * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            float4* slot = dW1L + ((ta + t) * KT1 + kt) * 64 + lane;
+            const float4 a0 = *slot;
+            f32x4 a = {a0.x, a0.y, a0.z, a0.w};
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][0], b.x, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][1], b.y, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][2], b.z, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][3], b.w, a, 0, 0, 0);
+            *slot = make_float4(a[0], a[1], a[2], a[3]);
+          }
+        }
+      }
+    }
+    if (more) store_x(pb ^ 1, xn);
+    __syncthreads();
+  }
+
+  // ---- this part's partial gradients, in parameter order: W1 [256, in] | b1 | W2 [256, 256] | b2 | W3 [out, 256] | b3
+  float* __restrict__ G = net.partials + (size_t)part_id * net.grad_floats;
+  const size_t oW1 = 0, ob1 = (size_t)HID * in_dim, oW2 = ob1 + HID, ob2 = oW2 + (size_t)HID * HID, oW3 = ob2 + HID,
+               ob3 = oW3 + (size_t)out_dim * HID;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n0 = 16 * (ta + t) + 4 * j;        // rows n0 + i of dW2 / dW1
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) G[oW2 + (size_t)(n0 + i) * HID + 16 * kt + c] = dW2[t][kt][i];
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt) {
+      const int k = 16 * kt + c;
+      if (k < in_dim) {
+        const float4 a = dW1L[((ta + t) * KT1 + kt) * 64 + lane];
+        G[oW1 + (size_t)(n0 + 0) * in_dim + k] = a.x;
+        G[oW1 + (size_t)(n0 + 1) * in_dim + k] = a.y;
+        G[oW1 + (size_t)(n0 + 2) * in_dim + k] = a.z;
+        G[oW1 + (size_t)(n0 + 3) * in_dim + k] = a.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (4 * j + i < out_dim) G[oW3 + (size_t)(4 * j + i) * HID + 16 * (ta + t) + c] = dW3[t][i];
+    }
+    // bias gradients: (s0 + s1) + (s2 + s3) over the four row groups
+    float s2 = db2[t], s1 = db1[t];
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    if (j == 0) {
+      G[ob2 + 16 * (ta + t) + c] = s2;
+      G[ob1 + 16 * (ta + t) + c] = s1;
+    }
+  }
+  if (wave == 0) {
+    float s3 = db3;
+    s3 += __shfl_xor(s3, 16, 64);
+    s3 += __shfl_xor(s3, 32, 64);
+    if (j == 0 && c < out_dim) G[ob3 + c] = s3;
+    double* S = p.stat_partials + (size_t)blockIdx.x * NSTAT;
+#pragma unroll
+    for (int q = 0; q < NSTAT; ++q) {
+      const double s = wave_sum(stL[q * 64 + lane]);
+      if (lane == 0) S[q] = s;
+    }
+  }
+}
+
+struct FinArgs {
+  UpdNet net[2];
+  float* grad[2];
+  const double* stat_partials;
+  double* scal_out;
+  const float* log_sd;
+  int B, act_dim, mirror;
+  float vf_coeff;
+};
+
+// grad[e] = sum over the parts in order (fp64), rounded once; block 0 also finishes the six scalars
+__global__ __launch_bounds__(256) void ppo_update_finish_kernel(FinArgs f) {
+  const long na = f.net[0].grad_floats, nc = f.net[1].grad_floats;
+  const long stride = (long)gridDim.x * 256;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < na + nc; e += stride) {
+    const int n = e >= na;
+    const long ee = n ? e - na : e;
+    const float* __restrict__ src = f.net[n].partials + ee;
+    const long gf = f.net[n].grad_floats;
+    double s = 0.0;
+    for (int q = 0; q < f.net[n].parts; ++q) s += (double)src[(size_t)q * gf];
+    f.grad[n][ee] = (float)s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < NSTAT) {
+    const int q = threadIdx.x;
+    double s = 0.0;
+    const int total = f.net[0].parts + f.net[1].parts;
+    for (int b = 0; b < total; ++b) s += f.stat_partials[(size_t)b * NSTAT + q];
+    const double invB = 1.0 / (double)f.B;
+    // scal_out: actor, entropy_penalty, critic, approx_kl, mirror, clip_fraction
+    if (q == 0) f.scal_out[0] = -s * invB;
+    if (q == 1) f.scal_out[3] = s * invB;
+    if (q == 2) f.scal_out[5] = s * invB;
+    if (q == 3) f.scal_out[4] = f.mirror ? s / ((double)f.B * f.act_dim) : 0.0;
+    if (q == 4) f.scal_out[2] = (double)f.vf_coeff * s * invB;
+    if (q == 5) {
+      // entropy of a fixed-std Gaussian: the same f32 row value for every row (Normal.entropy: 0.5 + 0.5 log(2 pi) + log(std))
+      float ent = 0.f;
+      for (int a = 0; a < f.act_dim; ++a) ent += (0.5f + LOG_SQRT_2PI) + f.log_sd[a];
+      f.scal_out[1] = -(s * (double)ent) / ((double)f.B * f.act_dim);
+    }
+  }
+}
+
+// input images 4 XI, hidden images 3 HI, partial tiles, mirror rows, dZ3 images, constants, statistics; + dW1: 16 KT1 KB
+constexpr size_t UPD_LDS_BASE = sizeof(float) * (4 * XI + 3 * HI + 8 * UR * PP + 2 * UR * 16 + 512 + 128) + sizeof(double) * NSTAT * 64;
+constexpr size_t upd_lds(int kt1) { return UPD_LDS_BASE + (size_t)16 * kt1 * 64 * sizeof(float4); }
+
+inline int grad_floats(int in_dim, int out_dim) { return HID * in_dim + HID + HID * HID + HID + out_dim * HID + out_dim; }
+
+void choose_parts(const oly_ctx* ctx, int B, int mirror, int* pa, int* pc) {
+  const int ntiles = (B + UR - 1) / UR;
+  const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+  // MFMAs per tile: forward 336, backward 576 per wave-quartet; the mirror loss adds two forwards and a backward to the actor
+  const double wa = mirror ? 3.0 * 336 + 2.0 * 576 : 912.0, wc = 912.0;
+  int a = (int)(cus * wa / (wa + wc) + 0.5);
+  a = a < 1 ? 1 : (a > cus - 1 ? cus - 1 : a);
+  int cpart = cus - a;
+  *pa = ntiles < a ? ntiles : a;
+  *pc = ntiles < cpart ? ntiles : cpart;
+}
+
+}  // namespace
+
+extern "C" int oly_ppo_update_grad_floats(int in_dim, int hidden, int out_dim) {
+  if (hidden != HID || in_dim <= 0 || in_dim > MAX_IN || out_dim <= 0 || out_dim > 16) return -1;
+  return grad_floats(in_dim, out_dim);
+}
+
+extern "C" int64_t oly_ppo_update_ws_floats(oly_ctx* ctx, int B, int in_dim, int act_dim, int mirror, int32_t* parts_actor,
+                                            int32_t* parts_critic) {
+  if (!ctx || B <= 0 || in_dim <= 0 || in_dim > MAX_IN || act_dim <= 0 || act_dim > 16) return -1;
+  int pa, pc;
+  choose_parts(ctx, B, mirror, &pa, &pc);
+  if (parts_actor) *parts_actor = pa;
+  if (parts_critic) *parts_critic = pc;
+  // partial gradients of both networks, then the statistics (NSTAT doubles per part)
+  return (int64_t)pa * grad_floats(in_dim, act_dim) + (int64_t)pc * grad_floats(in_dim, 1) + 2 * (int64_t)NSTAT * (pa + pc) + 4;
+}
+
+extern "C" int oly_ppo_update_grads(oly_ctx* ctx, const oly_ppo_update* u, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!u) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: NULL argument block");
+  if (u->B <= 0 || u->in_dim <= 0 || u->in_dim > MAX_IN || u->act_dim <= 0 || u->act_dim > 16)
+    OLY_FAIL(ctx, OLY_ERANGE, "oly_ppo_update_grads: supported shape is in <= %d -> 256 -> 256 -> act <= 16, B > 0 (got B=%d in=%d act=%d)",
+             MAX_IN, u->B, u->in_dim, u->act_dim);
+  if (!u->obs || !u->action || !u->adv || !u->ret || !u->old_mu || !u->packed_actor || !u->packed_critic || !u->sd ||
+      !u->log_sd || !u->old_sd || !u->old_log_sd || !u->grad_actor || !u->grad_critic || !u->scal_out || !u->ws)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: NULL pointer");
+  const int mirror = u->mir_obs != nullptr;
+  if (mirror && (!u->act_src || !u->act_sign)) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: mir_obs without the action mirror table");
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!al16(u->packed_actor) || !al16(u->packed_critic) || !al16(u->ws))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: packed streams and workspace must be 16-byte aligned");
+  int pa = u->parts_actor, pc = u->parts_critic;
+  const int ntiles = (u->B + UR - 1) / UR;
+  if (pa <= 0 || pc <= 0) choose_parts(ctx, u->B, mirror, &pa, &pc);
+  if (pa > ntiles || pc > ntiles) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: more parts (%d, %d) than 16-row tiles (%d)", pa, pc, ntiles);
+  const int gfa = grad_floats(u->in_dim, u->act_dim), gfc = grad_floats(u->in_dim, 1);
+  const int64_t need = (int64_t)pa * gfa + (int64_t)pc * gfc + 2 * (int64_t)NSTAT * (pa + pc) + 4;
+  if (u->ws_floats < need) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: workspace of %lld floats, %lld needed", (long long)u->ws_floats, (long long)need);
+  UpdArgs a;
+  a.B = u->B; a.in_dim = u->in_dim; a.act_dim = u->act_dim; a.ntiles = ntiles;
+  a.obs = u->obs; a.mir_obs = u->mir_obs; a.action = u->action; a.adv = u->adv; a.ret = u->ret; a.old_mu = u->old_mu;
+  a.idx = u->idx;
+  float* ws = u->ws;
+  a.net[0] = UpdNet{u->packed_actor, ws, u->act_dim, u->normalize_actor, pa, gfa};
+  a.net[1] = UpdNet{u->packed_critic, ws + (size_t)pa * gfa, 1, u->normalize_critic, pc, gfc};
+  size_t off = (size_t)pa * gfa + (size_t)pc * gfc;
+  off = (off + 3) & ~(size_t)3;                    // doubles: 8-byte aligned (ws is 16-byte aligned)
+  a.stat_partials = reinterpret_cast<double*>(ws + off);
+  a.sd = u->sd; a.log_sd = u->log_sd; a.old_sd = u->old_sd; a.old_log_sd = u->old_log_sd;
+  a.clip = u->clip; a.vf_coeff = u->vf_coeff; a.mirror_coeff = u->mirror_coeff;
+  a.mirror_gscale = (float)(2.0 / ((double)u->B * u->act_dim));
+  a.inv_b = 1.0f / (float)u->B;
+  a.act_src = u->act_src; a.act_sign = u->act_sign;
+#ifdef OLY_K14_DUMP
+  a.dbg = u->ws + u->ws_floats - 2 * 8192;
+#endif
+  const int kt1 = (u->in_dim + 15) / 16;
+  const dim3 grid(pa + pc), block(UT);
+#define OLY_UPD_LAUNCH(K)                                                                                              \
+  do {                                                                                                                 \
+    if (!(ctx->upd_attr_done & (1u << K))) {                                                                           \
+      OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_kernel<K>),                            \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds(K)));                     \
+      ctx->upd_attr_done |= 1u << K;                                                                                   \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(ppo_update_kernel<K>, grid, block, upd_lds(K), oly_s(stream), a);                                  \
+  } while (0)
+  switch (kt1) {
+    case 1: OLY_UPD_LAUNCH(1); break;
+    case 2: OLY_UPD_LAUNCH(2); break;
+    case 3: OLY_UPD_LAUNCH(3); break;
+    default: OLY_UPD_LAUNCH(4); break;
+  }
+#undef OLY_UPD_LAUNCH
+  OLY_LAUNCH_CHECK(ctx, "ppo_update_kernel");
+  FinArgs f;
+  f.net[0] = a.net[0]; f.net[1] = a.net[1];
+  f.grad[0] = u->grad_actor; f.grad[1] = u->grad_critic;
+  f.stat_partials = a.stat_partials;
+  f.scal_out = u->scal_out;
+  f.log_sd = u->log_sd;
+  f.B = u->B; f.act_dim = u->act_dim; f.mirror = mirror;
+  f.vf_coeff = u->vf_coeff;
+  const long total = (long)gfa + gfc;
+  const int fb = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(ppo_update_finish_kernel, dim3(fb), dim3(256), 0, oly_s(stream), f);
+  OLY_LAUNCH_CHECK(ctx, "ppo_update_finish_kernel");
+  return OLY_OK;
+}

@@ -25,6 +25,7 @@ struct PackLayout {
   int in_dim, out_dim, g1;      // g1: groups of four k-steps in layer 1
   size_t w1, b1, w2, b2, w3, b3, mean, std;
   size_t w1n, w2n, w3n;         // the 16-column-tile streams
+  size_t w2t, w3t;              // transposed-role streams of the update kernel (K14): the B operand of dH = dZ W
   size_t total;
 };
 
@@ -44,7 +45,12 @@ __host__ __device__ inline PackLayout pack_layout(int in_dim, int out_dim) {
   L.w1n = L.std + MAX_IN;
   L.w2n = L.w1n + (size_t)(HID / 16) * G1N * 256;
   L.w3n = L.w2n + (size_t)(HID / 16) * (HID / 16) * 256;
-  L.total = L.w3n + (size_t)T3N * (HID / 16) * 256;
+  // K14 (csrc/k14_ppo_update.hip): the data gradients dH1 = dZ2 W2 and dH2 = dZ3 W3 sum over the layer's OUTPUT
+  // index n, so the B operand is  PT[tile][group g][lane][q] = W[n = 16 g + 4 q + (lane >> 4)][k = 16 tile + (lane & 15)]
+  // (W3: n >= out_dim zero; T3N groups of n)
+  L.w2t = L.w3n + (size_t)T3N * (HID / 16) * 256;
+  L.w3t = L.w2t + (size_t)(HID / 16) * (HID / 16) * 256;
+  L.total = L.w3t + (size_t)(HID / 16) * T3N * 256;
   return L;
 }
 

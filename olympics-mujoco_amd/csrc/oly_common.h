@@ -72,6 +72,7 @@ struct oly_ctx {
   bool mlp_attr_done = false;   // dynamic-LDS limit of the fused MLP kernel raised on this device
   bool disc_attr_done = false;  // same for the fused discriminator kernel (K12)
   bool roll_attr_done = false;  // same for the persistent rollout kernel (K13)
+  unsigned upd_attr_done = 0;   // same for the update kernel's instantiations (K14)
   unsigned scan_attr_done = 0;  // dynamic-LDS limit of the pipelined scan kernels raised on this device
   int num_cu;
 };

@@ -117,6 +117,19 @@ A3_PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(A3Re
 # name -> (restype, argtypes); device/host pointers are void*.
 STD_SCALAR, STD_PER_DIM, STD_FULL = 0, 1, 2
 
+
+class PPOUpdate(C.Structure):
+    """oly_ppo_update (K14): one PPO minibatch update's gradient call."""
+    _fields_ = [("B", C.c_int32), ("in_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("parts_actor", C.c_int32), ("parts_critic", C.c_int32),
+                ("normalize_actor", C.c_int32), ("normalize_critic", C.c_int32), ("pad0", C.c_int32),
+                ("obs", vp), ("mir_obs", vp), ("action", vp), ("adv", vp), ("ret", vp), ("old_mu", vp), ("idx", vp),
+                ("packed_actor", vp), ("packed_critic", vp),
+                ("sd", vp), ("log_sd", vp), ("old_sd", vp), ("old_log_sd", vp),
+                ("act_src", vp), ("act_sign", vp),
+                ("clip", C.c_float), ("vf_coeff", C.c_float), ("mirror_coeff", C.c_float), ("pad1", C.c_int32),
+                ("grad_actor", vp), ("grad_critic", vp), ("scal_out", vp), ("ws", vp), ("ws_floats", C.c_int64)]
+
 SIGNATURES = {
     "oly_strerror": (C.c_char_p, [C.c_int]),
     "oly_last_error": (C.c_char_p, [vp]),
@@ -192,6 +205,9 @@ SIGNATURES = {
     "oly_mirror_loss": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "oly_ppo_loss": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp,
                                C.c_float, C.c_float, vp, vp, vp, vp, vp]),
+    "oly_ppo_update_grad_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "oly_ppo_update_ws_floats": (C.c_int64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "oly_ppo_update_grads": (C.c_int, [vp, C.POINTER(PPOUpdate), vp]),
     "oly_event_create": (C.c_int, [C.POINTER(vp)]),
     "oly_event_destroy": (C.c_int, [vp]),
     "oly_event_record": (C.c_int, [vp, vp]),

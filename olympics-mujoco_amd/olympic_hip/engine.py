@@ -457,6 +457,71 @@ class Engine:
                       ptr(packed_b), int(out_b), int(bool(normalize_b)), ptr(y_b), self._s())
         return y_a, y_b
 
+    # -------------------------------------------------------------- K14 (fused PPO update gradients)
+    def ppo_update_plan(self, B, in_dim, act_dim, mirror=False):
+        """(workspace floats, parts_actor, parts_critic) for minibatches of B rows on this device."""
+        from ._ffi import lib
+        pa, pc = C.c_int32(0), C.c_int32(0)
+        n = int(lib().oly_ppo_update_ws_floats(self.ctx.handle, int(B), int(in_dim), int(act_dim), int(bool(mirror)),
+                                               C.byref(pa), C.byref(pc)))
+        if n < 0:
+            raise OlyError(f"ppo_update: unsupported shape B={B} in={in_dim} act={act_dim}")
+        return n, int(pa.value), int(pc.value)
+
+    def ppo_update_grads(self, obs, action, adv, ret, old_mu, packed_actor, packed_critic, sd, log_sd, old_sd, old_log_sd,
+                         grad_actor, grad_critic, scal_out, ws, idx=None, mir_obs=None, act_src=None, act_sign=None,
+                         normalize_actor=True, normalize_critic=False, clip=0.2, vf_coeff=0.5, mirror_coeff=0.0,
+                         parts=(0, 0)):
+        """oly_ppo_update_grads: gradients of one PPO minibatch update (rl/algos/ppo.py:232-282,396-410) into the flat
+        buffers grad_actor / grad_critic (parameter order), the six scalars of update_policy into scal_out [6] f64."""
+        from ._ffi import lib
+        f32, dv = torch.float32, self.device
+        if obs.dim() != 2 or action.dim() != 2:
+            raise OlyError("ppo_update_grads: obs [n, in] and action [n, act] expected")
+        n, in_dim = (int(v) for v in obs.shape)
+        act_dim = int(action.shape[1])
+        _req(obs, "obs", (n, in_dim), f32, dv)
+        _req(action, "action", (n, act_dim), f32, dv)
+        _req(adv, "adv", (n,), f32, dv)
+        _req(ret, "ret", (n,), f32, dv)
+        _req(old_mu, "old_mu", (n, act_dim), f32, dv)
+        _req(mir_obs, "mir_obs", (n, in_dim), f32, dv, optional=True)
+        if idx is not None:
+            if idx.dim() != 1:
+                raise OlyError("idx: expected [B]")
+            _req(idx, "idx", (int(idx.shape[0]),), torch.int32, dv)
+        B = int(idx.shape[0]) if idx is not None else n
+        for t, name in ((sd, "sd"), (log_sd, "log_sd"), (old_sd, "old_sd"), (old_log_sd, "old_log_sd")):
+            _req(t, name, (act_dim,), f32, dv)
+        if mir_obs is not None:
+            _req(act_src, "act_src", (act_dim,), torch.int32, dv)
+            _req(act_sign, "act_sign", (act_dim,), f32, dv)
+        _req(packed_actor, "packed_actor", (self._mlp_floats(in_dim, act_dim),), f32, dv)
+        _req(packed_critic, "packed_critic", (self._mlp_floats(in_dim, 1),), f32, dv)
+        ga = int(lib().oly_ppo_update_grad_floats(in_dim, 256, act_dim))
+        gc = int(lib().oly_ppo_update_grad_floats(in_dim, 256, 1))
+        if ga < 0 or gc < 0:
+            raise OlyError(f"ppo_update_grads: unsupported shape in={in_dim} act={act_dim}")
+        _req(grad_actor, "grad_actor", (ga,), f32, dv)
+        _req(grad_critic, "grad_critic", (gc,), f32, dv)
+        _req(scal_out, "scal_out", (6,), torch.float64, dv)
+        if ws.dim() != 1:
+            raise OlyError("ws: expected a flat float32 workspace")
+        _req(ws, "ws", (int(ws.shape[0]),), f32, dv)
+        u = _abi.PPOUpdate()
+        u.B, u.in_dim, u.act_dim = B, in_dim, act_dim
+        u.parts_actor, u.parts_critic = int(parts[0]), int(parts[1])
+        u.normalize_actor, u.normalize_critic = int(bool(normalize_actor)), int(bool(normalize_critic))
+        u.obs, u.mir_obs, u.action, u.adv, u.ret, u.old_mu, u.idx = (ptr(t) for t in (obs, mir_obs, action, adv, ret, old_mu, idx))
+        u.packed_actor, u.packed_critic = ptr(packed_actor), ptr(packed_critic)
+        u.sd, u.log_sd, u.old_sd, u.old_log_sd = ptr(sd), ptr(log_sd), ptr(old_sd), ptr(old_log_sd)
+        u.act_src, u.act_sign = ptr(act_src if mir_obs is not None else None), ptr(act_sign if mir_obs is not None else None)
+        u.clip, u.vf_coeff, u.mirror_coeff = float(clip), float(vf_coeff), float(mirror_coeff)
+        u.grad_actor, u.grad_critic, u.scal_out = ptr(grad_actor), ptr(grad_critic), ptr(scal_out)
+        u.ws, u.ws_floats = ptr(ws), int(ws.shape[0])
+        self.ctx.call("oly_ppo_update_grads", C.byref(u), self._s())
+        return grad_actor, grad_critic, scal_out
+
     # -------------------------------------------------------------- K6
     def return_scan(self, mode, gamma, lam, rew, val, next_val, flags, ret=None, adv=None, stats3=None):
         """rew [T,N] float32, or float64 (RETURN mode: the un-narrowed reward of env.step).  With

@@ -1110,3 +1110,228 @@ int oly_rollout_cuts_cpu(int N, int max_traj_len, int last_step, const uint8_t* 
   *n_cut = c;
   return OLY_OK;
 }
+
+/* ============================================================================== K14 */
+
+/* One network's share of oly_ppo_update_grads (csrc/k14_ppo_update.hip): the gradients of one PPO minibatch
+ * update, PPO.update_policy + the backward() calls of PPO.train (rl/algos/ppo.py:232-282,396-410), as the f32
+ * matrix cores evaluate them:
+ *   forward     as oly_mlp_forward_cpu (k-ascending fmaf chains, the output layer as eight partial chains);
+ *   loss        oly_ppo_loss_cpu's per-row arithmetic with exp -> oly_exp32_cpu and log(std) given; the mirror
+ *               loss of oly_mirror_loss_cpu (ppo.py:261-268) with d mirror / d det joined to d mu;
+ *   dH          fmaf chain over the layer's output index ascending (padded to 16 for the output layer);
+ *   dW, per part (tiles part, part + parts, ... of 16 rows): ONE fmaf chain over the part's rows in tile order,
+ *               inside a tile rows 0,4,8,12,1,5,9,13,...; bias gradients as four running f32 sums per column
+ *               (rows 4 g .. 4 g + 3 of every tile into sum g), combined as (s0 + s1) + (s2 + s3);
+ *   the parts are added in order in fp64 and rounded once.
+ * critic != 0: out_dim = 1, loss = vf_coeff * mse.  stats[6]: sums of surrogate, kl, clipped, mirror, critic, rows. */
+typedef struct {
+  const float *w1, *b1, *w2, *b2, *w3, *b3, *mean, *std;
+} oly_upd_net;
+
+static void upd_forward(const oly_upd_net* nw, int in_dim, int out_dim, const float* xrow, float* xin, float* h1,
+                        float* h2, float* out16) {
+  enum { H = 256 };
+  for (int k = 0; k < in_dim; ++k) {
+    float v = xrow ? xrow[k] : 0.0f;
+    if (xrow && nw->mean && nw->std) v = (v - nw->mean[k]) / nw->std[k];
+    xin[k] = v;
+  }
+  for (int j = 0; j < H; ++j) {
+    float acc = 0.0f;
+    for (int k = 0; k < in_dim; ++k) acc = fmaf(xin[k], nw->w1[(size_t)j * in_dim + k], acc);
+    const float v = acc + nw->b1[j];
+    h1[j] = (v > 0.0f || v != v) ? v : 0.0f;
+  }
+  for (int j = 0; j < H; ++j) {
+    float acc = 0.0f;
+    for (int k = 0; k < H; ++k) acc = fmaf(h1[k], nw->w2[(size_t)j * H + k], acc);
+    const float v = acc + nw->b2[j];
+    h2[j] = (v > 0.0f || v != v) ? v : 0.0f;
+  }
+  for (int j = 0; j < 16; ++j) {
+    float s = 0.0f;
+    if (j < out_dim) {
+      for (int w = 0; w < 8; ++w) {
+        float acc = 0.0f;
+        for (int k = 32 * w; k < 32 * w + 32; ++k) acc = fmaf(h2[k], nw->w3[(size_t)j * H + k], acc);
+        s = (w == 0) ? acc : s + acc;
+      }
+      s += nw->b3[j];
+    }
+    out16[j] = s;
+  }
+}
+
+static int upd_network(int critic, int B, int in_dim, int out_dim, int parts, const float* obs, const float* mir_obs,
+                       const float* action, const float* adv, const float* ret, const float* old_mu,
+                       const int32_t* idx, const oly_upd_net* nw, const float* sd, const float* log_sd,
+                       const float* old_sd, const float* old_log_sd, const int32_t* act_src, const float* act_sign,
+                       float clip, float vf_coeff, float mirror_coeff, float* grad, double* stats) {
+  enum { H = 256, R = 16 };
+  const float c = 0.9189385332046727f, lo = 1.0f - clip, hi = 1.0f + clip;
+  const float inv_b = 1.0f / (float)B;
+  const float gscale = (float)(2.0 / ((double)B * out_dim));
+  const int mirror = !critic && mir_obs != NULL;
+  const int ntiles = (B + R - 1) / R;
+  const size_t oW1 = 0, ob1 = (size_t)H * in_dim, oW2 = ob1 + H, ob2 = oW2 + (size_t)H * H, oW3 = ob2 + H,
+               ob3 = oW3 + (size_t)out_dim * H, gf = ob3 + out_dim;
+  double* total = (double*)calloc(gf, sizeof(double));
+  float* G = (float*)malloc(gf * sizeof(float));
+  float* sb2 = (float*)malloc(sizeof(float) * H * 4), *sb1 = (float*)malloc(sizeof(float) * H * 4);
+  float* xin = (float*)malloc(sizeof(float) * R * 64), *h1 = (float*)malloc(sizeof(float) * R * H),
+        *h2 = (float*)malloc(sizeof(float) * R * H), *dz2 = (float*)malloc(sizeof(float) * R * H),
+        *dz1 = (float*)malloc(sizeof(float) * R * H);
+  if (!total || !G || !sb2 || !sb1 || !xin || !h1 || !h2 || !dz2 || !dz1) return OLY_EINVAL;
+  for (int part = 0; part < parts; ++part) {
+    memset(G, 0, gf * sizeof(float));
+    memset(sb2, 0, sizeof(float) * H * 4);
+    memset(sb1, 0, sizeof(float) * H * 4);
+    float sb3[16][4];
+    memset(sb3, 0, sizeof(sb3));
+    for (int tile = part; tile < ntiles; tile += parts) {
+      float mir_out[R][16], dmir[R][16];
+      memset(mir_out, 0, sizeof(mir_out));
+      memset(dmir, 0, sizeof(dmir));
+      for (int sp = mirror ? 0 : 1; sp < (mirror ? 3 : 2); ++sp) {
+        float out[R][16], dz3[R][16];
+        memset(dz3, 0, sizeof(dz3));
+        for (int m = 0; m < R; ++m) {
+          const int r = tile * R + m;
+          const float* xrow = NULL;
+          if (r < B) {
+            const size_t s = idx ? (size_t)idx[r] : (size_t)r;
+            xrow = (sp == 1 ? obs : mir_obs) + s * in_dim;
+          }
+          upd_forward(nw, in_dim, out_dim, xrow, xin + m * 64, h1 + m * H, h2 + m * H, out[m]);
+        }
+        if (sp == 0) {
+          memcpy(mir_out, out, sizeof(out));
+          continue;
+        }
+        if (sp == 2) {
+          for (int m = 0; m < R; ++m)
+            for (int j = 0; j < out_dim; ++j) dz3[m][j] = dmir[m][j];
+        } else {
+          for (int m = 0; m < R; ++m) {
+            const int r = tile * R + m;
+            if (r >= B) continue;
+            const size_t s = idx ? (size_t)idx[r] : (size_t)r;
+            if (critic) {
+              const float v = out[m][0], dv = ret[s] - v;
+              stats[4] += (double)(dv * dv);
+              dz3[m][0] = vf_coeff * 2.0f * (v - ret[s]) * inv_b;
+              continue;
+            }
+            float t[16], lp = 0.0f, olp = 0.0f;
+            for (int j = 0; j < out_dim; ++j) {
+              const float a = action[s * out_dim + j];
+              t[j] = a - out[m][j];
+              const float ot = a - old_mu[s * out_dim + j];
+              lp += -(t[j] * t[j]) / (2.0f * (sd[j] * sd[j])) - log_sd[j] - c;
+              olp += -(ot * ot) / (2.0f * (old_sd[j] * old_sd[j])) - old_log_sd[j] - c;
+            }
+            const float lr = lp - olp, ratio = oly_exp32_cpu(lr);
+            const float cpi = ratio * adv[s];
+            const float rc = fminf(fmaxf(ratio, lo), hi);
+            const float cl = rc * adv[s];
+            stats[0] += (double)fminf(cpi, cl);
+            stats[1] += (double)((ratio - 1.0f) - lr);
+            stats[2] += fabsf(ratio - 1.0f) > clip ? 1.0 : 0.0;
+            stats[5] += 1.0;
+            const float inr = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+            const float w = cpi < cl ? 1.0f : (cpi == cl ? 0.5f + 0.5f * inr : inr);
+            const float g_lp = -inv_b * adv[s] * w * ratio;
+            for (int j = 0; j < out_dim; ++j) {
+              float gm = g_lp * t[j] / (sd[j] * sd[j]);
+              if (mirror) {
+                const int i = act_src[j];
+                const float sg = act_sign[j];
+                const float d = out[m][j] - sg * mir_out[m][i];
+                stats[3] += (double)(d * d);
+                const float gg = gscale * d;
+                gm = gm + mirror_coeff * gg;
+                dmir[m][i] = mirror_coeff * (-sg * gg);
+              }
+              dz3[m][j] = gm;
+            }
+          }
+        }
+        /* ---- backward of this tile */
+        for (int m = 0; m < R; ++m)
+          for (int k = 0; k < H; ++k) {
+            float acc = 0.0f;
+            for (int n = 0; n < 16; ++n) acc = fmaf(dz3[m][n], n < out_dim ? nw->w3[(size_t)n * H + k] : 0.0f, acc);
+            dz2[m * H + k] = h2[m * H + k] > 0.0f ? acc : 0.0f;
+          }
+        for (int m = 0; m < R; ++m)
+          for (int k = 0; k < H; ++k) {
+            float acc = 0.0f;
+            for (int n = 0; n < H; ++n) acc = fmaf(dz2[m * H + n], nw->w2[(size_t)n * H + k], acc);
+            dz1[m * H + k] = h1[m * H + k] > 0.0f ? acc : 0.0f;
+          }
+        for (int q = 0; q < 4; ++q)
+          for (int jj = 0; jj < 4; ++jj) {
+            const int m = 4 * jj + q;
+            for (int n = 0; n < out_dim; ++n)
+              for (int k = 0; k < H; ++k) G[oW3 + (size_t)n * H + k] = fmaf(dz3[m][n], h2[m * H + k], G[oW3 + (size_t)n * H + k]);
+            for (int n = 0; n < H; ++n) {
+              const float z2 = dz2[m * H + n], z1 = dz1[m * H + n];
+              float* g2 = G + oW2 + (size_t)n * H;
+              for (int k = 0; k < H; ++k) g2[k] = fmaf(z2, h1[m * H + k], g2[k]);
+              float* g1 = G + oW1 + (size_t)n * in_dim;
+              for (int k = 0; k < in_dim; ++k) g1[k] = fmaf(z1, xin[m * 64 + k], g1[k]);
+            }
+          }
+        for (int g = 0; g < 4; ++g)
+          for (int i = 0; i < 4; ++i) {
+            const int m = 4 * g + i;
+            for (int n = 0; n < H; ++n) {
+              sb2[n * 4 + g] += dz2[m * H + n];
+              sb1[n * 4 + g] += dz1[m * H + n];
+            }
+            for (int n = 0; n < out_dim; ++n) sb3[n][g] += dz3[m][n];
+          }
+      }
+    }
+    for (int n = 0; n < H; ++n) {
+      G[ob2 + n] = (sb2[n * 4] + sb2[n * 4 + 1]) + (sb2[n * 4 + 2] + sb2[n * 4 + 3]);
+      G[ob1 + n] = (sb1[n * 4] + sb1[n * 4 + 1]) + (sb1[n * 4 + 2] + sb1[n * 4 + 3]);
+    }
+    for (int n = 0; n < out_dim; ++n) G[ob3 + n] = (sb3[n][0] + sb3[n][1]) + (sb3[n][2] + sb3[n][3]);
+    for (size_t e = 0; e < gf; ++e) total[e] += (double)G[e];
+  }
+  for (size_t e = 0; e < gf; ++e) grad[e] = (float)total[e];
+  free(total); free(G); free(sb2); free(sb1); free(xin); free(h1); free(h2); free(dz2); free(dz1);
+  return OLY_OK;
+}
+
+int oly_ppo_update_cpu(int B, int in_dim, int act_dim, int parts_actor, int parts_critic, const float* obs,
+                       const float* mir_obs, const float* action, const float* adv, const float* ret,
+                       const float* old_mu, const int32_t* idx, const float* const* actor_wb,
+                       const float* a_mean, const float* a_std, const float* const* critic_wb,
+                       const float* c_mean, const float* c_std, const float* sd, const float* log_sd,
+                       const float* old_sd, const float* old_log_sd, const int32_t* act_src,
+                       const float* act_sign, float clip, float vf_coeff, float mirror_coeff, float* grad_actor,
+                       float* grad_critic, double* scal_out) {
+  if (B <= 0 || in_dim <= 0 || in_dim > 64 || act_dim <= 0 || act_dim > 16 || parts_actor <= 0 || parts_critic <= 0)
+    return OLY_ERANGE;
+  const oly_upd_net a = {actor_wb[0], actor_wb[1], actor_wb[2], actor_wb[3], actor_wb[4], actor_wb[5], a_mean, a_std};
+  const oly_upd_net cn = {critic_wb[0], critic_wb[1], critic_wb[2], critic_wb[3], critic_wb[4], critic_wb[5], c_mean, c_std};
+  double st[6] = {0, 0, 0, 0, 0, 0};
+  int rc = upd_network(0, B, in_dim, act_dim, parts_actor, obs, mir_obs, action, adv, ret, old_mu, idx, &a, sd, log_sd,
+                       old_sd, old_log_sd, act_src, act_sign, clip, vf_coeff, mirror_coeff, grad_actor, st);
+  if (rc != OLY_OK) return rc;
+  rc = upd_network(1, B, in_dim, 1, parts_critic, obs, NULL, action, adv, ret, old_mu, idx, &cn, sd, log_sd, old_sd,
+                   old_log_sd, NULL, NULL, clip, vf_coeff, 0.0f, grad_critic, st);
+  if (rc != OLY_OK) return rc;
+  float ent = 0.0f;
+  for (int j = 0; j < act_dim; ++j) ent += (0.5f + 0.9189385332046727f) + log_sd[j];
+  scal_out[0] = -st[0] / B;
+  scal_out[1] = -(st[5] * (double)ent) / ((double)B * act_dim);
+  scal_out[2] = (double)vf_coeff * st[4] / B;
+  scal_out[3] = st[1] / B;
+  scal_out[4] = mir_obs ? st[3] / ((double)B * act_dim) : 0.0;
+  scal_out[5] = st[2] / B;
+  return OLY_OK;
+}

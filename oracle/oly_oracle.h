@@ -111,6 +111,17 @@ int oly_ppo_loss_cpu(int B, int A, const float* mu, const float* std, int std_mo
                      float clip, float vf_coeff, double* scal_out, float* grad_mu, float* grad_std,
                      float* grad_value);
 
+/* K14 twin: gradients of one PPO minibatch update (rl/algos/ppo.py:232-282,396-410); *_wb = {w1,b1,w2,b2,w3,b3};
+ * grad_* flat in parameter order; scal_out[6] = actor, entropy_penalty, critic, approx_kl, mirror, clip_fraction. */
+int oly_ppo_update_cpu(int B, int in_dim, int act_dim, int parts_actor, int parts_critic, const float* obs,
+                       const float* mir_obs, const float* action, const float* adv, const float* ret,
+                       const float* old_mu, const int32_t* idx, const float* const* actor_wb,
+                       const float* a_mean, const float* a_std, const float* const* critic_wb,
+                       const float* c_mean, const float* c_std, const float* sd, const float* log_sd,
+                       const float* old_sd, const float* old_log_sd, const int32_t* act_src,
+                       const float* act_sign, float clip, float vf_coeff, float mirror_coeff, float* grad_actor,
+                       float* grad_critic, double* scal_out);
+
 /* OpenMP-parallel variant used only by bench.py's cpu_baseline leg (threads <= 0: all). */
 int oly_il_step_cpu_mt(const oly_il_model* m, int T, int N, const double* qpos,
                        const double* qvel, const float* action, double* prev_inout, void* obs,

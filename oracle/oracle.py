@@ -417,3 +417,35 @@ def rollout_cuts(done, traj_len, max_traj_len, last_step):
     _chk(lib().oly_rollout_cuts_cpu(len(done), int(max_traj_len), int(bool(last_step)), _p(done), _p(tl), _p(flags),
                                     _p(nc)), "rollout_cuts")
     return flags, tl, int(nc[0])
+
+
+def ppo_update(obs, action, adv, ret, old_mu, actor_wb, critic_wb, sd, old_sd=None, log_sd=None, old_log_sd=None,
+               idx=None, mir_obs=None, act_src=None, act_sign=None, a_mean=None, a_std=None, c_mean=None, c_std=None,
+               clip=0.2, vf_coeff=0.5, mirror_coeff=0.0, parts_actor=1, parts_critic=1):
+    """K14's twin: gradients of one PPO minibatch update.  *_wb = (w1, b1, w2, b2, w3, b3).
+    -> (grad_actor flat, grad_critic flat, scal[6] = actor, entropy_penalty, critic, approx_kl, mirror, clip_fraction)"""
+    f32 = np.float32
+    obs, action, old_mu = _c(obs, f32), _c(action, f32), _c(old_mu, f32)
+    adv, ret = _c(np.asarray(adv).reshape(-1), f32), _c(np.asarray(ret).reshape(-1), f32)
+    mir_obs = _c(mir_obs, f32)
+    idx = _c(idx, np.int32)
+    in_dim, act_dim = obs.shape[1], action.shape[1]
+    B = len(idx) if idx is not None else obs.shape[0]
+    awb = [_c(a, f32) for a in actor_wb]
+    cwb = [_c(a, f32) for a in critic_wb]
+    sd = _c(np.broadcast_to(np.asarray(sd, f32).reshape(-1), (act_dim,)), f32)
+    old_sd = sd if old_sd is None else _c(np.broadcast_to(np.asarray(old_sd, f32).reshape(-1), (act_dim,)), f32)
+    log_sd = np.log(sd).astype(f32) if log_sd is None else _c(log_sd, f32)
+    old_log_sd = np.log(old_sd).astype(f32) if old_log_sd is None else _c(old_log_sd, f32)
+    act_src, act_sign = _c(act_src, np.int32), _c(act_sign, f32)
+    a_mean, a_std, c_mean, c_std = (_c(a, f32) for a in (a_mean, a_std, c_mean, c_std))
+    ga = np.empty(256 * in_dim + 256 + 65536 + 256 + act_dim * 256 + act_dim, f32)
+    gc = np.empty(256 * in_dim + 256 + 65536 + 256 + 256 + 1, f32)
+    scal = np.zeros(6)
+    arr6 = C.c_void_p * 6
+    _chk(lib().oly_ppo_update_cpu(B, in_dim, act_dim, int(parts_actor), int(parts_critic), _p(obs), _p(mir_obs), _p(action),
+                                  _p(adv), _p(ret), _p(old_mu), _p(idx), arr6(*[a.ctypes.data for a in awb]), _p(a_mean),
+                                  _p(a_std), arr6(*[a.ctypes.data for a in cwb]), _p(c_mean), _p(c_std), _p(sd), _p(log_sd),
+                                  _p(old_sd), _p(old_log_sd), _p(act_src), _p(act_sign), C.c_float(clip),
+                                  C.c_float(vf_coeff), C.c_float(mirror_coeff), _p(ga), _p(gc), _p(scal)), "ppo_update")
+    return ga, gc, scal

@@ -159,3 +159,86 @@ def check_a3_reset_fixture(g, state, next_obs):
     want = g["obs"].astype(np.float32)
     assert np.abs(next_obs - want).max() <= np.spacing(np.float32(1.0)) * max(1.0, np.abs(want).max())
     assert not next_obs[:, -8:].any() and not g["obs"][:, -8:].any()          # goal steps zero after reset
+
+
+# ------------------------------------------------------------------------------ K14 (fused PPO update)
+def ppo_update_case(seed, n=96, in_dim=41, act_dim=12, mirror=True, normalize=True, scale=1.0):
+    """Random actor / old actor / critic (the reference's shapes), a rollout slice of n rows, a mirror table.
+    Weights are drawn so that hidden units are active about half the time and ratios stay O(1)."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+
+    def net(out, head_scale):
+        return [rng.normal(0, scale / np.sqrt(in_dim), (256, in_dim)).astype(f32), rng.normal(0, 0.1, 256).astype(f32),
+                rng.normal(0, scale / 16.0, (256, 256)).astype(f32), rng.normal(0, 0.1, 256).astype(f32),
+                rng.normal(0, head_scale / 16.0, (out, 256)).astype(f32), rng.normal(0, 0.1, out).astype(f32)]
+    actor = net(act_dim, 0.3)
+    old = [a + rng.normal(0, 2e-3, a.shape).astype(f32) for a in actor]
+    critic = net(1, 1.0)
+    obs = rng.normal(0, 1, (n, in_dim)).astype(f32)
+    sd = np.full(act_dim, np.exp(-1.5), f32)
+    c = dict(obs=obs, actor=actor, old=old, critic=critic, sd=sd, log_sd=np.log(sd).astype(f32),
+             adv=rng.normal(0, 1, n).astype(f32), ret=rng.normal(0, 1, n).astype(f32),
+             a_mean=rng.normal(0, 0.2, in_dim).astype(f32) if normalize else None,
+             a_std=rng.uniform(0.7, 1.4, in_dim).astype(f32) if normalize else None)
+    mu = torch_mlp(obs, actor, c["a_mean"], c["a_std"])
+    c["action"] = (mu + sd * rng.normal(0, 1, mu.shape)).astype(f32)
+    c["old_mu"] = torch_mlp(obs, old, c["a_mean"], c["a_std"])
+    if mirror:
+        perm = rng.permutation(in_dim)
+        c["obs_src"], c["obs_sign"] = perm.astype(np.int32), rng.choice([-1.0, 1.0], in_dim).astype(f32)
+        c["mir_obs"] = np.ascontiguousarray(obs[:, perm] * c["obs_sign"])
+        c["act_src"] = rng.permutation(act_dim).astype(np.int32)
+        c["act_sign"] = rng.choice([-1.0, 1.0], act_dim).astype(f32)
+    return c
+
+
+def torch_mlp(x, wb, mean=None, std=None, grad=False):
+    """relu MLP with torch's own float32 Linear layers (numpy in / out unless grad)."""
+    import torch
+    t = [torch.as_tensor(a) for a in wb] if not grad else wb
+    h = torch.as_tensor(x) if not torch.is_tensor(x) else x
+    if mean is not None:
+        h = (h - torch.as_tensor(mean)) / torch.as_tensor(std)
+    h = torch.relu(torch.nn.functional.linear(h, t[0], t[1]))
+    h = torch.relu(torch.nn.functional.linear(h, t[2], t[3]))
+    y = torch.nn.functional.linear(h, t[4], t[5])
+    return y if grad else y.numpy()
+
+
+def torch_ppo_update_grads(c, idx=None, clip=0.2, vf_coeff=0.5, mirror_coeff=0.4, old_mu=None):
+    """What the reference's update_policy + the two backward() calls leave in .grad (rl/algos/ppo.py:232-282,
+    396-410), evaluated with torch ops and autograd on the CPU in float32: flat gradients in parameter order and
+    the six scalars.  `old_mu` overrides the old policy's forward (the kernel takes it as an input)."""
+    import torch
+    sel = slice(None) if idx is None else np.asarray(idx, np.int64)
+    obs, act = torch.as_tensor(c["obs"][sel]), torch.as_tensor(c["action"][sel])
+    adv, ret = torch.as_tensor(c["adv"][sel]).reshape(-1, 1), torch.as_tensor(c["ret"][sel]).reshape(-1, 1)
+    A = [torch.tensor(a, requires_grad=True) for a in c["actor"]]
+    Cw = [torch.tensor(a, requires_grad=True) for a in c["critic"]]
+    sd = torch.as_tensor(c["sd"])
+    mu = torch_mlp(obs, A, c["a_mean"], c["a_std"], grad=True)
+    omu = torch.as_tensor((c["old_mu"] if old_mu is None else old_mu)[sel])
+    pdf, old = torch.distributions.Normal(mu, sd), torch.distributions.Normal(omu, sd)
+    lp, olp = pdf.log_prob(act).sum(-1, keepdim=True), old.log_prob(act).sum(-1, keepdim=True)
+    ratio = (lp - olp).exp()
+    cpi, cl = ratio * adv, ratio.clamp(1.0 - clip, 1.0 + clip) * adv
+    actor_loss = -torch.min(cpi, cl).mean()
+    values = torch_mlp(obs, Cw, grad=True)
+    critic_loss = vf_coeff * torch.nn.functional.mse_loss(ret, values)
+    ent = -pdf.entropy().mean()
+    if "mir_obs" in c and mirror_coeff is not None:
+        mir = torch_mlp(torch.as_tensor(c["mir_obs"][sel]), A, c["a_mean"], c["a_std"], grad=True)
+        mir = mir[:, torch.as_tensor(c["act_src"].astype(np.int64))] * torch.as_tensor(c["act_sign"])
+        mirror_loss = (mu - mir).pow(2).mean()
+        mc = mirror_coeff
+    else:
+        mirror_loss, mc = torch.zeros(()), 0.0
+    (actor_loss + mc * mirror_loss + 0.0 * ent).backward()
+    critic_loss.backward()
+    with torch.no_grad():
+        lr = lp - olp
+        scal = [float(actor_loss), float(ent), float(critic_loss), float(((ratio - 1) - lr).mean()), float(mirror_loss),
+                float(((ratio - 1).abs() > clip).float().mean())]
+    flat = lambda ps: np.concatenate([p.grad.reshape(-1).numpy() for p in ps])
+    return flat(A), flat(Cw), np.array(scal)

@@ -1,0 +1,149 @@
+"""K14 (oly_ppo_update_grads): the gradients of one PPO minibatch update on the f32 matrix cores, through the C ABI,
+against the oracle twin (bit-exact), torch autograd (summation-order tolerance) and the reference-run fixture."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ppo_update_arrays, ppo_update_case, torch_ppo_update_grads
+from test_update_cpu import GRAD_RTOL, assert_grads_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from olympic_hip.engine import Engine
+    return Engine(0)
+
+
+def d(a):
+    return None if a is None else torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def run_kernel(eng, c, idx=None, mirror=False, parts=(0, 0), mirror_coeff=0.4, clip=0.2, old_mu=None):
+    in_dim, act_dim = c["obs"].shape[1], c["action"].shape[1]
+    pa = eng.mlp_pack(*[d(a) for a in c["actor"]], d(c["a_mean"]), d(c["a_std"]))
+    pc = eng.mlp_pack(*[d(a) for a in c["critic"]])
+    B = len(idx) if idx is not None else len(c["obs"])
+    ws_n, p_a, p_c = eng.ppo_update_plan(B, in_dim, act_dim, mirror)
+    if parts != (0, 0):
+        p_a, p_c = parts
+    from olympic_hip._ffi import lib
+    ga = torch.full((int(lib().oly_ppo_update_grad_floats(in_dim, 256, act_dim)),), float("nan"), device="cuda")
+    gc = torch.full((int(lib().oly_ppo_update_grad_floats(in_dim, 256, 1)),), float("nan"), device="cuda")
+    scal = torch.zeros(6, dtype=torch.float64, device="cuda")
+    ws = torch.empty(ws_n + 4096, dtype=torch.float32, device="cuda")
+    sd, lsd = d(c["sd"]), d(c["log_sd"])
+    kw = dict(mir_obs=d(c["mir_obs"]), act_src=d(c["act_src"]), act_sign=d(c["act_sign"])) if mirror else {}
+    eng.ppo_update_grads(d(c["obs"]), d(c["action"]), d(c["adv"]), d(c["ret"]), d(c["old_mu"] if old_mu is None else old_mu),
+                         pa, pc, sd, lsd, sd, lsd, ga, gc, scal, ws, idx=d(idx), normalize_actor=c["a_mean"] is not None,
+                         clip=clip, vf_coeff=0.5, mirror_coeff=mirror_coeff, parts=parts, **kw)
+    torch.cuda.synchronize()
+    return ga.cpu().numpy(), gc.cpu().numpy(), scal.cpu().numpy(), (p_a, p_c)
+
+
+def oracle_update(oracle, c, idx, mirror, parts, mirror_coeff=0.4, clip=0.2, old_mu=None):
+    kw = dict(mir_obs=c["mir_obs"], act_src=c["act_src"], act_sign=c["act_sign"]) if mirror else {}
+    return oracle.ppo_update(c["obs"], c["action"], c["adv"], c["ret"], c["old_mu"] if old_mu is None else old_mu, c["actor"],
+                             c["critic"], c["sd"], log_sd=c["log_sd"], old_log_sd=c["log_sd"], idx=idx, a_mean=c["a_mean"],
+                             a_std=c["a_std"], clip=clip, vf_coeff=0.5, mirror_coeff=mirror_coeff, parts_actor=parts[0],
+                             parts_critic=parts[1], **kw)
+
+
+CASES = [  # n rows in the buffer, B rows of the minibatch (None: all, in order), mirror, normalise, parts (0, 0: the plan's)
+    (16, None, False, False, (0, 0)),          # one full tile
+    (5, None, False, True, (0, 0)),            # one ragged tile
+    (96, None, True, True, (0, 0)),            # one tile per workgroup
+    (96, 50, True, True, (2, 1)),              # several tiles per workgroup, ragged last tile, gathered rows
+    (200, 131, False, True, (3, 4)),
+    (200, 200, True, False, (4, 2)),
+]
+
+
+@pytest.mark.parametrize("n,B,mirror,normalize,parts", CASES)
+def test_ppo_update_kernel_equals_the_oracle(eng, oracle, n, B, mirror, normalize, parts):
+    """Gradients BIT-EXACT (same fma chains, same order, same exp32); the six scalars to 1e-12 (fp64 sums of the same
+    float32 terms in a different, fixed order)."""
+    c = ppo_update_case(100 + n, n=n, mirror=mirror, normalize=normalize)
+    idx = None if B is None else np.random.default_rng(n).permutation(n)[:B].astype(np.int32)
+    ga, gc, scal, used = run_kernel(eng, c, idx, mirror, parts)
+    oa, oc, os_ = oracle_update(oracle, c, idx, mirror, used)
+    assert np.isfinite(ga).all() and np.isfinite(gc).all()
+    assert np.array_equal(ga, oa), np.abs(ga - oa).max()
+    assert np.array_equal(gc, oc), np.abs(gc - oc).max()
+    np.testing.assert_allclose(scal, os_, rtol=1e-12, atol=1e-15)
+
+
+def test_ppo_update_kernel_larger_minibatch_equals_the_oracle(eng, oracle):
+    """2085 gathered rows of a 6000-row buffer with the plan's own split (131 tiles over 128 + 128 workgroups)."""
+    c = ppo_update_case(5, n=6000, mirror=True)
+    idx = np.random.default_rng(0).permutation(6000)[:2085].astype(np.int32)
+    ga, gc, scal, used = run_kernel(eng, c, idx, True)
+    oa, oc, os_ = oracle_update(oracle, c, idx, True, used)
+    assert np.array_equal(ga, oa) and np.array_equal(gc, oc)
+    np.testing.assert_allclose(scal, os_, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("mirror", [False, True])
+def test_ppo_update_kernel_vs_torch_autograd(eng, mirror):
+    """Against what the reference's backward() calls compute (torch autograd, float32, CPU): summation order only."""
+    c = ppo_update_case(11, n=300, mirror=mirror)
+    idx = np.random.default_rng(1).permutation(300)[:256].astype(np.int32)
+    ga, gc, scal, _ = run_kernel(eng, c, idx, mirror)
+    ta, tc, ts = torch_ppo_update_grads(c, idx=idx, mirror_coeff=0.4 if mirror else None)
+    np.testing.assert_allclose(scal, ts, rtol=3e-5, atol=3e-7)
+    assert_grads_close(ga, ta, 41, 12, GRAD_RTOL)
+    assert_grads_close(gc, tc, 41, 1, GRAD_RTOL)
+
+
+def test_ppo_update_kernel_on_the_reference_fixture(eng, golden):
+    """The reference's own update_policy outputs (ppo_update.npz: its Gaussian_FF_Actor / FF_V weights, mirror tables)."""
+    g = golden("ppo_update.npz")
+    a = ppo_update_arrays(g)
+    wb = lambda tag, layers, head: [g[f"{tag}.{layers}.0.weight"], g[f"{tag}.{layers}.0.bias"], g[f"{tag}.{layers}.1.weight"],
+                                    g[f"{tag}.{layers}.1.bias"], g[f"{tag}.{head}.weight"], g[f"{tag}.{head}.bias"]]
+    obs = g["obs"].astype(np.float32)
+    mobs = obs[:, a["obs_src"]] * a["obs_sign"]
+    for i in (31, 32):
+        mobs[:, i] = np.sin(np.arcsin(mobs[:, i]) + np.float32(np.pi))
+    sd = np.full(12, a["std"], np.float32)
+    c = dict(obs=obs, action=a["action"], adv=a["adv"], ret=a["ret"], actor=wb("pi", "actor_layers", "means"),
+             critic=wb("vf", "critic_layers", "network_out"), sd=sd, log_sd=np.log(sd), a_mean=None, a_std=None,
+             mir_obs=mobs.astype(np.float32), act_src=a["act_src"], act_sign=a["act_sign"])
+    old = wb("old", "actor_layers", "means")
+    po = eng.mlp_pack(*[d(x) for x in old])
+    old_mu = torch.empty((64, 12), dtype=torch.float32, device="cuda")
+    eng.mlp_forward2(d(obs), po, 12, old_mu)                 # the old policy's means as the product computes them (K11)
+    c["old_mu"] = old_mu.cpu().numpy()
+    ga, gc, scal, _ = run_kernel(eng, c, None, True, clip=a["clip"])
+    for i, n in enumerate(("actor_loss", "entropy_penalty", "critic_loss", "approx_kl_div", "mirror_loss", "clip_fraction")):
+        np.testing.assert_allclose(scal[i], float(g[n]), rtol=3e-5, atol=3e-7, err_msg=n)
+    ta, tc, _ = torch_ppo_update_grads(c, clip=a["clip"], mirror_coeff=0.4)
+    assert_grads_close(ga, ta, 41, 12, GRAD_RTOL)
+    assert_grads_close(gc, tc, 41, 1, GRAD_RTOL)
+
+
+def test_ppo_update_first_minibatch_has_ratio_one(eng):
+    """old_policy == policy at the first minibatch of an iteration: with old_mu from K11 on the same weights the
+    kernel's own forward must reproduce it bit for bit, i.e. ratio == 1 exactly: approx_kl == 0, clip_fraction == 0,
+    actor_loss == -mean(adv)."""
+    c = ppo_update_case(21, n=500, mirror=False)
+    pa = eng.mlp_pack(*[d(a) for a in c["actor"]], d(c["a_mean"]), d(c["a_std"]))
+    old_mu = torch.empty((500, 12), dtype=torch.float32, device="cuda")
+    eng.mlp_forward2(d(c["obs"]), pa, 12, old_mu, normalize_a=True)
+    ga, gc, scal, _ = run_kernel(eng, c, None, False, old_mu=old_mu.cpu().numpy())
+    assert scal[3] == 0.0 and scal[5] == 0.0
+    np.testing.assert_allclose(scal[0], -np.mean(c["adv"].astype(np.float64)), rtol=1e-12)
+
+
+def test_ppo_update_rejects_bad_arguments(eng):
+    from olympic_hip._ffi import OlyError
+    c = ppo_update_case(1, n=40, mirror=False)
+    with pytest.raises(OlyError, match="parts"):
+        run_kernel(eng, c, None, False, parts=(7, 1))            # 3 tiles cannot feed 7 workgroups
+    with pytest.raises(OlyError, match="idx"):
+        run_kernel(eng, c, np.arange(8, dtype=np.int64), False)  # int64 indices are refused on the host
+    big = dict(c, action=np.zeros((40, 17), np.float32), old_mu=np.zeros((40, 17), np.float32), sd=np.ones(17, np.float32),
+               log_sd=np.zeros(17, np.float32))
+    with pytest.raises(OlyError):
+        run_kernel(eng, big, None, False)                        # 17 actions: the loss wave holds 16 columns
