@@ -115,17 +115,23 @@ __device__ const char* g_k14_base;
 #else
 #define OLY_K14_LOAD(rs, voff, so) __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so, 0)
 #endif
+// first two weight groups of a layer's NT tiles: issued BEFORE the barrier in front of the layer (weights do not depend
+// on it), so that the layer does not open with an exposed L2 round trip on all eight waves at once
 template <int G, int NT>
-__device__ __forceinline__ void layer_tiles16b(const float4* __restrict__ a4, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                               const unsigned (&soff)[NT], int lane, f32x4 (&acc)[NT],
-                                               const float* pbase = nullptr) {
-  u32x4 b[3][NT];
-  float4 a[2];
+__device__ __forceinline__ void preload16b(__amdgpu_buffer_rsrc_t rs, unsigned voff, const unsigned (&soff)[NT],
+                                           u32x4 (&b)[3][NT], const float* pbase = nullptr) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     b[0][t] = OLY_K14_LOAD(rs, voff, soff[t]);
     if (G > 1) b[1][t] = OLY_K14_LOAD(rs, voff, soff[t] + 1024u);
   }
+}
+
+template <int G, int NT>
+__device__ __forceinline__ void layer_tiles16b(const float4* __restrict__ a4, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                               const unsigned (&soff)[NT], int lane, f32x4 (&acc)[NT], u32x4 (&b)[3][NT],
+                                               const float* pbase = nullptr) {
+  float4 a[2];
   a[0] = a4[lane];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -256,10 +262,19 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     }
   };
 
+  // byte offsets of this wave's weight streams
+  const unsigned so1[2] = {(unsigned)(L.w1n * 4) + (unsigned)ta * (G1N * 1024u), (unsigned)(L.w1n * 4) + (unsigned)(ta + 1) * (G1N * 1024u)};
+  const unsigned so2[2] = {(unsigned)(L.w2n * 4) + (unsigned)ta * (HID / 16 * 1024u), (unsigned)(L.w2n * 4) + (unsigned)(ta + 1) * (HID / 16 * 1024u)};
+  const unsigned so3[1] = {(unsigned)(L.w3n * 4) + (unsigned)(2 * wave) * 1024u};
+  const unsigned so3t[2] = {(unsigned)(L.w3t * 4) + (unsigned)ta * (T3N * 1024u), (unsigned)(L.w3t * 4) + (unsigned)(ta + 1) * (T3N * 1024u)};
+  const unsigned so2t[2] = {(unsigned)(L.w2t * 4) + (unsigned)ta * (HID / 16 * 1024u), (unsigned)(L.w2t * 4) + (unsigned)(ta + 1) * (HID / 16 * 1024u)};
+  u32x4 wb[3][2];          // the weight ring of the two-tile layers: its first two groups are requested before the barrier
+
   float xn[2];
   if (n_items > 0) {
     load_x(0, xn);
     store_x(0, xn);
+    preload16b<KT1, 2>(rsP, voff, so1, wb, P);
   }
   __syncthreads();
 
@@ -277,9 +292,8 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
 
     {  // ---- layer 1
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      const unsigned s0 = (unsigned)(L.w1n * 4) + (unsigned)ta * (G1N * 1024u);
-      const unsigned so[2] = {s0, s0 + G1N * 1024u};
-      layer_tiles16b<KT1, 2>(xA4, rsP, voff, so, lane, acc, P);
+      layer_tiles16b<KT1, 2>(xA4, rsP, voff, so1, lane, acc, wb, P);
+      preload16b<HID / 16, 2>(rsP, voff, so2, wb, P);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 v;
@@ -293,9 +307,8 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     f32x4 h2own[2];
     {  // ---- layer 2
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      const unsigned s0 = (unsigned)(L.w2n * 4) + (unsigned)ta * (HID / 16 * 1024u);
-      const unsigned so[2] = {s0, s0 + HID / 16 * 1024u};
-      layer_tiles16b<HID / 16, 2>(reinterpret_cast<const float4*>(h1A), rsP, voff, so, lane, acc, P);
+      layer_tiles16b<HID / 16, 2>(reinterpret_cast<const float4*>(h1A), rsP, voff, so2, lane, acc, wb, P);
+
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -321,8 +334,10 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     }
     {  // ---- output layer: chain `wave` of the eight partial chains (k in [32 wave, 32 wave + 32))
       f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-      const unsigned so[1] = {(unsigned)(L.w3n * 4) + (unsigned)(2 * wave) * 1024u};
-      layer_tiles16b<2, 1>(reinterpret_cast<const float4*>(h2A) + (size_t)(2 * wave) * 64, rsP, voff, so, lane, acc, P);
+      u32x4 wb1[3][1];
+      preload16b<2, 1>(rsP, voff, so3, wb1, P);
+      layer_tiles16b<2, 1>(reinterpret_cast<const float4*>(h2A) + (size_t)(2 * wave) * 64, rsP, voff, so3, lane, acc, wb1, P);
+      if (sp != 0) preload16b<1, 2>(rsP, voff, so3t, wb, P);
 #pragma unroll
       for (int i = 0; i < 4; ++i) part[(wave * UR + 4 * j + i) * PP + c] = acc[0][i];
     }
@@ -437,9 +452,8 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
       f32x4 dz2[2];
       {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned s0 = (unsigned)(L.w3t * 4) + (unsigned)ta * (T3N * 1024u);
-        const unsigned so[2] = {s0, s0 + T3N * 1024u};
-        layer_tiles16b<1, 2>(reinterpret_cast<const float4*>(dz3A), rsP, voff, so, lane, acc, P);
+        layer_tiles16b<1, 2>(reinterpret_cast<const float4*>(dz3A), rsP, voff, so3t, lane, acc, wb, P);
+        preload16b<HID / 16, 2>(rsP, voff, so2t, wb, P);
         const float4 z3 = reinterpret_cast<const float4*>(dz3C)[lane];
         if (wave == 0) {
           db3 += z3.x;
@@ -480,9 +494,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
       __syncthreads();
       {  // ---- dH1 (own tiles) = dZ2 W2; dZ1 = dH1 [H1 > 0]; dW1 (own rows) += dZ1^T X
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned s0 = (unsigned)(L.w2t * 4) + (unsigned)ta * (HID / 16 * 1024u);
-        const unsigned so[2] = {s0, s0 + HID / 16 * 1024u};
-        layer_tiles16b<HID / 16, 2>(reinterpret_cast<const float4*>(dz2A), rsP, voff, so, lane, acc, P);
+        layer_tiles16b<HID / 16, 2>(reinterpret_cast<const float4*>(dz2A), rsP, voff, so2t, lane, acc, wb, P);
         f32x4 dz1[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -511,7 +523,10 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
         }
       }
     }
-    if (more) store_x(pb ^ 1, xn);
+    if (more) {
+      store_x(pb ^ 1, xn);
+      preload16b<KT1, 2>(rsP, voff, so1, wb, P);
+    }
     __syncthreads();
   }
 
@@ -577,38 +592,110 @@ struct FinArgs {
   float vf_coeff;
 };
 
-// grad[e] = sum over the parts in order (fp64), rounded once; block 0 also finishes the six scalars
-__global__ __launch_bounds__(256) void ppo_update_finish_kernel(FinArgs f) {
-  const long na = f.net[0].grad_floats, nc = f.net[1].grad_floats;
-  const long stride = (long)gridDim.x * 256;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < na + nc; e += stride) {
-    const int n = e >= na;
-    const long ee = n ? e - na : e;
-    const float* __restrict__ src = f.net[n].partials + ee;
-    const long gf = f.net[n].grad_floats;
-    double s = 0.0;
-    for (int q = 0; q < f.net[n].parts; ++q) s += (double)src[(size_t)q * gf];
-    f.grad[n][ee] = (float)s;
+// grad[e] = sum over the parts in order (fp64), rounded once; block 0 also finishes the six scalars.  A block owns
+// 512 consecutive elements of one network (thread t: elements t and 256 + t), eight parts in flight per thread.
+__global__ __launch_bounds__(256) void ppo_update_finish_kernel(FinArgs f, int blocks_a) {
+  const int n = (int)blockIdx.x >= blocks_a;
+  const long base = 512L * ((int)blockIdx.x - (n ? blocks_a : 0));
+  const long gf = f.net[n].grad_floats;
+  const int parts = f.net[n].parts;
+  const float* __restrict__ src = f.net[n].partials;
+  const long e0 = base + threadIdx.x, e1 = e0 + 256;
+  const bool on0 = e0 < gf, on1 = e1 < gf;
+  double s0 = 0.0, s1 = 0.0;
+  int q = 0;
+  for (; q + 8 <= parts; q += 8) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = on0 ? src[(size_t)(q + u) * gf + e0] : 0.f;
+      b[u] = on1 ? src[(size_t)(q + u) * gf + e1] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s0 += (double)a[u];
+      s1 += (double)b[u];
+    }
   }
+  for (; q < parts; ++q) {
+    s0 += on0 ? (double)src[(size_t)q * gf + e0] : 0.0;
+    s1 += on1 ? (double)src[(size_t)q * gf + e1] : 0.0;
+  }
+  if (on0) f.grad[n][e0] = (float)s0;
+  if (on1) f.grad[n][e1] = (float)s1;
   if (blockIdx.x == 0 && threadIdx.x < NSTAT) {
-    const int q = threadIdx.x;
+    const int qq = threadIdx.x;
     double s = 0.0;
     const int total = f.net[0].parts + f.net[1].parts;
-    for (int b = 0; b < total; ++b) s += f.stat_partials[(size_t)b * NSTAT + q];
+    for (int b = 0; b < total; ++b) s += f.stat_partials[(size_t)b * NSTAT + qq];
     const double invB = 1.0 / (double)f.B;
     // scal_out: actor, entropy_penalty, critic, approx_kl, mirror, clip_fraction
-    if (q == 0) f.scal_out[0] = -s * invB;
-    if (q == 1) f.scal_out[3] = s * invB;
-    if (q == 2) f.scal_out[5] = s * invB;
-    if (q == 3) f.scal_out[4] = f.mirror ? s / ((double)f.B * f.act_dim) : 0.0;
-    if (q == 4) f.scal_out[2] = (double)f.vf_coeff * s * invB;
-    if (q == 5) {
+    if (qq == 0) f.scal_out[0] = -s * invB;
+    if (qq == 1) f.scal_out[3] = s * invB;
+    if (qq == 2) f.scal_out[5] = s * invB;
+    if (qq == 3) f.scal_out[4] = f.mirror ? s / ((double)f.B * f.act_dim) : 0.0;
+    if (qq == 4) f.scal_out[2] = (double)f.vf_coeff * s * invB;
+    if (qq == 5) {
       // entropy of a fixed-std Gaussian: the same f32 row value for every row (Normal.entropy: 0.5 + 0.5 log(2 pi) + log(std))
       float ent = 0.f;
       for (int a = 0; a < f.act_dim; ++a) ent += (0.5f + LOG_SQRT_2PI) + f.log_sd[a];
       f.scal_out[1] = -(s * (double)ent) / ((double)f.B * f.act_dim);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The optimiser half of the update (rl/algos/ppo.py:396-410): torch.nn.utils.clip_grad_norm_ + Adam.step for both
+// networks on flat parameter / gradient / moment buffers, then the re-pack of the stepped weights: three launches
+// instead of torch's ~60 (the foreach Adam and the norm clip are ~30 small kernels per network; at every minibatch
+// size the host could not issue them as fast as the GPU ran them).
+struct AdamNet {
+  float *param, *exp_avg, *exp_avg_sq;
+  const float* grad;
+  int n, blocks;          // elements; 512-element blocks of the norm pass
+};
+struct AdamArgs {
+  AdamNet net[2];
+  double* sumsq;          // [2][OLY_ADAM_MAX_BLOCKS] block partials of sum g^2
+  float w1, beta2, w2, eps, neg_step, bc2_sqrt, max_norm;
+};
+constexpr int ADAM_MAX_BLOCKS = 512;
+
+// block partials of sum g^2: thread t squares elements t and 256 + t of its 512, fp64, wave tree, waves in order
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(AdamArgs a) {
+  __shared__ double sh[4];
+  const int n = (int)blockIdx.x >= a.net[0].blocks;
+  const int blk = (int)blockIdx.x - (n ? a.net[0].blocks : 0);
+  const AdamNet nt = a.net[n];
+  const long e0 = 512L * blk + threadIdx.x, e1 = e0 + 256;
+  const double g0 = e0 < nt.n ? (double)nt.grad[e0] : 0.0, g1 = e1 < nt.n ? (double)nt.grad[e1] : 0.0;
+  const double s = wave_sum(g0 * g0 + g1 * g1);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) a.sumsq[n * ADAM_MAX_BLOCKS + blk] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// clip_grad_norm_: g *= min(max_norm / (||g|| + 1e-6), 1) per network; Adam (torch.optim.Adam, amsgrad off, no decay):
+//   m += (g - m)(1 - b1); v = v b2 + ((1 - b2) g) g; p += -(lr / (1 - b1^t)) (m / (sqrt(v) / sqrt(1 - b2^t) + eps))
+__global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
+  const long na = a.net[0].n;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= na + a.net[1].n) return;
+  const int n = e >= na;
+  const AdamNet nt = a.net[n];
+  const long i = n ? e - na : e;
+  double ss = 0.0;
+  for (int b = 0; b < nt.blocks; ++b) ss += a.sumsq[n * ADAM_MAX_BLOCKS + b];
+  const float norm = (float)sqrt(ss);
+  const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
+  const float g = nt.grad[i] * coef;
+  float m = nt.exp_avg[i], v = nt.exp_avg_sq[i];
+  m = m + (g - m) * a.w1;
+  v = v * a.beta2 + (a.w2 * g) * g;
+  nt.exp_avg[i] = m;
+  nt.exp_avg_sq[i] = v;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  nt.param[i] = nt.param[i] + a.neg_step * (m / denom);
 }
 
 // input images 4 XI, hidden images 3 HI, partial tiles, mirror rows, dZ3 images, constants, statistics; + dW1: 16 KT1 KB
@@ -713,9 +800,51 @@ extern "C" int oly_ppo_update_grads(oly_ctx* ctx, const oly_ppo_update* u, oly_s
   f.log_sd = u->log_sd;
   f.B = u->B; f.act_dim = u->act_dim; f.mirror = mirror;
   f.vf_coeff = u->vf_coeff;
-  const long total = (long)gfa + gfc;
-  const int fb = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(ppo_update_finish_kernel, dim3(fb), dim3(256), 0, oly_s(stream), f);
+  const int fba = (gfa + 511) / 512, fbc = (gfc + 511) / 512;
+  hipLaunchKernelGGL(ppo_update_finish_kernel, dim3(fba + fbc), dim3(256), 0, oly_s(stream), f, fba);
   OLY_LAUNCH_CHECK(ctx, "ppo_update_finish_kernel");
+  return OLY_OK;
+}
+
+extern "C" int oly_ppo_adam_step(oly_ctx* ctx, const oly_ppo_adam* a, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!a) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_adam_step: NULL argument block");
+  if (a->in_dim <= 0 || a->in_dim > MAX_IN || a->step <= 0 || !a->ws)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_adam_step: bad in_dim / step / workspace");
+  if (!(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f) || !(a->lr >= 0.f) || !(a->eps >= 0.f))
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_adam_step: bad hyper-parameters");
+  AdamArgs k;
+  for (int n = 0; n < 2; ++n) {
+    const oly_adam_net& s = a->net[n];
+    if (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq || s.out_dim <= 0 || s.out_dim > 16)
+      OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_adam_step: network %d: NULL buffer or bad out_dim", n);
+    const int gf = grad_floats(a->in_dim, s.out_dim);
+    k.net[n] = AdamNet{s.param, s.exp_avg, s.exp_avg_sq, s.grad, gf, (gf + 511) / 512};
+    if (k.net[n].blocks > ADAM_MAX_BLOCKS) OLY_FAIL(ctx, OLY_ERANGE, "oly_ppo_adam_step: network too large");
+  }
+  k.sumsq = a->ws;
+  // the step-dependent scalars in fp64 on the host (torch's non-capturable Adam forms them as python floats)
+  const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+  k.w1 = (float)(1.0 - (double)a->beta1);
+  k.beta2 = a->beta2;
+  k.w2 = (float)(1.0 - (double)a->beta2);
+  k.eps = a->eps;
+  k.neg_step = (float)(-((double)a->lr / bc1));
+  k.bc2_sqrt = (float)sqrt(bc2);
+  k.max_norm = a->max_grad_norm;
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(k.net[0].blocks + k.net[1].blocks), dim3(256), 0, oly_s(stream), k);
+  const long total = (long)k.net[0].n + k.net[1].n;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, oly_s(stream), k);
+  OLY_LAUNCH_CHECK(ctx, "adam step kernels");
+  for (int n = 0; n < 2; ++n) {
+    const oly_adam_net& s = a->net[n];
+    if (!s.packed) continue;
+    const float* p = s.param;
+    const size_t ob1 = (size_t)HID * a->in_dim, oW2 = ob1 + HID, ob2 = oW2 + (size_t)HID * HID, oW3 = ob2 + HID,
+                 ob3 = oW3 + (size_t)s.out_dim * HID;
+    const int rc = oly_mlp_pack(ctx, a->in_dim, HID, s.out_dim, p, p + ob1, p + oW2, p + ob2, p + oW3, p + ob3, s.in_mean,
+                                s.in_std, s.packed, stream);
+    if (rc != OLY_OK) return rc;
+  }
   return OLY_OK;
 }

@@ -118,6 +118,18 @@ A3_PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(A3Re
 STD_SCALAR, STD_PER_DIM, STD_FULL = 0, 1, 2
 
 
+class AdamNet(C.Structure):
+    """oly_adam_net: one network's flat optimiser buffers."""
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("packed", vp), ("in_mean", vp),
+                ("in_std", vp), ("out_dim", C.c_int32), ("pad", C.c_int32)]
+
+
+class PPOAdam(C.Structure):
+    """oly_ppo_adam (K14's optimiser half): clip_grad_norm_ + Adam.step + re-pack for actor and critic."""
+    _fields_ = [("in_dim", C.c_int32), ("step", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("max_grad_norm", C.c_float), ("pad", C.c_int32), ("net", AdamNet * 2), ("ws", vp)]
+
+
 class PPOUpdate(C.Structure):
     """oly_ppo_update (K14): one PPO minibatch update's gradient call."""
     _fields_ = [("B", C.c_int32), ("in_dim", C.c_int32), ("act_dim", C.c_int32),
@@ -208,6 +220,7 @@ SIGNATURES = {
     "oly_ppo_update_grad_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "oly_ppo_update_ws_floats": (C.c_int64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "oly_ppo_update_grads": (C.c_int, [vp, C.POINTER(PPOUpdate), vp]),
+    "oly_ppo_adam_step": (C.c_int, [vp, C.POINTER(PPOAdam), vp]),
     "oly_event_create": (C.c_int, [C.POINTER(vp)]),
     "oly_event_destroy": (C.c_int, [vp]),
     "oly_event_record": (C.c_int, [vp, vp]),

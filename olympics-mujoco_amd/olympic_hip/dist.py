@@ -131,3 +131,20 @@ def allreduce_gradients(params, weight=None, total_weight=None):
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+def allreduce_flat(tensors, weight=None, total_weight=None):
+    """allreduce_gradients for gradients that already live in flat buffers (ppo.KernelUpdate): the same weighted mean, one
+    all-reduce per buffer, results written in place."""
+    if not is_dist():
+        return
+    for flat in tensors:
+        if weight is not None:
+            flat *= float(weight)
+        if _via_host(flat):
+            h = flat.cpu()
+            dist.all_reduce(h)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat)
+        flat /= float(total_weight) if weight is not None else dist.get_world_size()

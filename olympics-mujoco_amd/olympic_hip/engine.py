@@ -522,6 +522,35 @@ class Engine:
         self.ctx.call("oly_ppo_update_grads", C.byref(u), self._s())
         return grad_actor, grad_critic, scal_out
 
+    def ppo_adam_step(self, in_dim, step, lr, eps, max_grad_norm, nets, ws, beta1=0.9, beta2=0.999):
+        """oly_ppo_adam_step: clip_grad_norm_ + Adam.step + weight re-pack for (actor, critic).  nets: two dicts with
+        flat f32 tensors param / grad / exp_avg / exp_avg_sq, out_dim, and optionally packed / in_mean / in_std."""
+        from ._ffi import lib
+        f32, dv = torch.float32, self.device
+        a = _abi.PPOAdam()
+        a.in_dim, a.step = int(in_dim), int(step)
+        a.lr, a.beta1, a.beta2, a.eps, a.max_grad_norm = float(lr), float(beta1), float(beta2), float(eps), float(max_grad_norm)
+        if len(nets) != 2:
+            raise OlyError("ppo_adam_step: nets = (actor, critic)")
+        for i, nt in enumerate(nets):
+            out_dim = int(nt["out_dim"])
+            gf = int(lib().oly_ppo_update_grad_floats(int(in_dim), 256, out_dim))
+            if gf < 0:
+                raise OlyError(f"ppo_adam_step: unsupported shape in={in_dim} out={out_dim}")
+            for k in ("param", "grad", "exp_avg", "exp_avg_sq"):
+                _req(nt[k], k, (gf,), f32, dv)
+            packed = nt.get("packed")
+            if packed is not None:
+                _req(packed, "packed", (self._mlp_floats(in_dim, out_dim),), f32, dv)
+            _req(nt.get("in_mean"), "in_mean", (int(in_dim),), f32, dv, optional=True)
+            _req(nt.get("in_std"), "in_std", (int(in_dim),), f32, dv, optional=True)
+            s = a.net[i]
+            s.param, s.grad, s.exp_avg, s.exp_avg_sq = ptr(nt["param"]), ptr(nt["grad"]), ptr(nt["exp_avg"]), ptr(nt["exp_avg_sq"])
+            s.packed, s.in_mean, s.in_std, s.out_dim = ptr(packed), ptr(nt.get("in_mean")), ptr(nt.get("in_std")), out_dim
+        _req(ws, "ws", (1024,), torch.float64, dv)
+        a.ws = ptr(ws)
+        self.ctx.call("oly_ppo_adam_step", C.byref(a), self._s())
+
     # -------------------------------------------------------------- K6
     def return_scan(self, mode, gamma, lam, rew, val, next_val, flags, ret=None, adv=None, stats3=None):
         """rew [T,N] float32, or float64 (RETURN mode: the un-narrowed reward of env.step).  With

@@ -80,8 +80,13 @@ class FusedMLPForward:
             for lin in parts:
                 out += [lin.weight.detach().to(torch.float32).contiguous(), lin.bias.detach().to(torch.float32).contiguous()]
             return out
+        self._norm = ((a_mean, a_std), (c_mean, c_std))
         self.packed_a = self.eng.mlp_pack(*params(self.pa), a_mean, a_std, packed=self.packed_a)
         self.packed_c = self.eng.mlp_pack(*params(self.pc), c_mean, c_std, packed=self.packed_c)
+
+    def norm_tables(self):
+        """((actor mean, std), (critic mean, std)) as the last refresh() packed them (None where not normalised)."""
+        return self._norm
 
     def std(self, state, act_dim):
         sd = getattr(self.policy, "fixed_std", None)

@@ -137,6 +137,119 @@ class FusedMirrorLoss(torch.autograd.Function):
         return None, g * gd, g * gm, None, None
 
 
+class KernelUpdate:
+    """One PPO minibatch update (rl/algos/ppo.py:232-282,396-410) as six launches of this repository's own kernels:
+      oly_ppo_update_grads (K14)  actor and critic forward, the loss terms of update_policy (mirror loss included) and the
+                                  backward pass on the f32 matrix cores, + the finishing launch that adds the parts;
+      oly_ppo_adam_step           torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step for both networks on flat
+                                  buffers (2 launches) and the re-pack of the stepped weights (2 launches).
+    The modules keep their parameters: `.data` of every weight / bias becomes a view of one flat buffer per network
+    (same values), `.grad` a view of the flat gradient buffer the kernel writes; Adam's moments and the step count live
+    here.  Per iteration (`begin`): the old policy's means of every rollout row (the old policy is constant during an
+    update phase: one K11 forward instead of one per minibatch) and the mirrored observations (the env's own
+    mirror_clock_observation, any function).  Per minibatch (`step`): the rows are gathered by index inside the
+    kernel."""
+
+    def __init__(self, eng, policy, critic, old_policy, clip, vf_coeff, mirror_coeff, obs_mirr=None, act_src=None,
+                 act_sign=None, lr=1e-4, eps=1e-5, max_grad_norm=0.05, betas=(0.9, 0.999)):
+        from ._ffi import lib
+        from .mlp import FusedMLPForward
+        self.eng, self.policy, self.critic, self.old_policy = eng, policy, critic, old_policy
+        self.fw = FusedMLPForward(eng, policy, critic)
+        self.fw_old = None
+        self.clip, self.vf_coeff, self.mirror_coeff = float(clip), float(vf_coeff), float(mirror_coeff)
+        self.lr, self.eps, self.max_grad_norm, self.betas = float(lr), float(eps), float(max_grad_norm), betas
+        self.obs_mirr = obs_mirr if act_src is not None else None
+        dev = eng.device
+        self.act_src = act_src.to(dev, torch.int32).contiguous() if act_src is not None else None
+        self.act_sign = act_sign.to(dev, torch.float32).contiguous() if act_sign is not None else None
+        in_dim, act_dim = self.fw.in_dim, self.fw.act_dim
+        self.nets = []
+        for parts, out_dim, packed in ((self.fw.pa, act_dim, self.fw.packed_a), (self.fw.pc, 1, self.fw.packed_c)):
+            gf = int(lib().oly_ppo_update_grad_floats(in_dim, 256, out_dim))
+            z = lambda: torch.zeros(gf, dtype=torch.float32, device=dev)
+            nt = dict(param=z(), grad=z(), exp_avg=z(), exp_avg_sq=z(), out_dim=out_dim, packed=packed)
+            off = 0
+            with torch.no_grad():
+                for lin in parts:                           # W1 | b1 | W2 | b2 | W3 | b3: the kernel's flat order
+                    for prm in (lin.weight, lin.bias):
+                        n = prm.numel()
+                        nt["param"][off:off + n].copy_(prm.detach().reshape(-1))
+                        prm.data = nt["param"][off:off + n].view_as(prm)
+                        prm.grad = nt["grad"][off:off + n].view_as(prm)
+                        off += n
+            assert off == gf
+            self.nets.append(nt)
+        self.grad_actor, self.grad_critic = self.nets[0]["grad"], self.nets[1]["grad"]
+        self.scal = torch.zeros(6, dtype=torch.float64, device=dev)
+        self.adam_ws = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self.steps = 0
+        self._ws = {}
+        self.old_mu = self.mir_obs = None
+
+    @staticmethod
+    def supports(policy, critic, act_mirr_is_table):
+        from .mlp import FusedMLPForward
+        return (FusedMLPForward.supports(policy, critic) and act_mirr_is_table
+                and next(policy.parameters()).is_cuda and policy.means.out_features <= 16)
+
+    def _std(self, module):
+        """(std [A], log std [A]) of a fixed-std Gaussian policy (actor.py:199-201)."""
+        t = torch.as_tensor(module.fixed_std, dtype=torch.float32, device=self.eng.device).reshape(-1)
+        sd = t.expand(self.fw.act_dim).contiguous() if t.numel() == 1 else t.contiguous()
+        return sd, torch.log(sd)
+
+    @torch.no_grad()
+    def begin(self, observations):
+        """Once per iteration, after old_policy.load_state_dict(policy.state_dict())."""
+        from .mlp import FusedMLPForward
+        self.fw.refresh()
+        self.nets[0]["packed"], self.nets[1]["packed"] = self.fw.packed_a, self.fw.packed_c
+        if self.fw_old is None:
+            self.fw_old = FusedMLPForward(self.eng, self.old_policy, self.critic)
+        else:
+            self.fw_old.refresh()
+        n = int(observations.shape[0])
+        if self.old_mu is None or self.old_mu.shape[0] != n:
+            self.old_mu = torch.empty((n, self.fw.act_dim), dtype=torch.float32, device=self.eng.device)
+        self.eng.mlp_forward2(observations, self.fw_old.packed_a, self.fw.act_dim, self.old_mu, normalize_a=True)
+        self.mir_obs = self.obs_mirr(observations).to(torch.float32).contiguous() if self.obs_mirr is not None else None
+        self.sd, self.log_sd = self._std(self.policy)
+        self.old_sd, self.old_log_sd = self._std(self.old_policy)
+
+    def grads(self, observations, actions, returns, advantages, idx, scal=None, repack=False):
+        """Gradients of the minibatch `idx` (int32 row indices) into the parameters' .grad; -> scal [6] f64 (device):
+        actor_loss, entropy_penalty, critic_loss, approx_kl, mirror_loss, clip_fraction."""
+        if repack:
+            self.fw.refresh()                               # someone else moved the weights (not `step`)
+        B = int(idx.shape[0])
+        if B not in self._ws:
+            n_ws, pa, pc = self.eng.ppo_update_plan(B, self.fw.in_dim, self.fw.act_dim, self.mir_obs is not None)
+            self._ws[B] = (torch.empty(n_ws, dtype=torch.float32, device=self.eng.device), (pa, pc))
+        ws, parts = self._ws[B]
+        scal = self.scal if scal is None else scal
+        self.eng.ppo_update_grads(observations, actions, advantages.reshape(-1), returns.reshape(-1), self.old_mu,
+                                  self.fw.packed_a, self.fw.packed_c, self.sd, self.log_sd, self.old_sd, self.old_log_sd,
+                                  self.grad_actor, self.grad_critic, scal, ws, idx=idx, mir_obs=self.mir_obs,
+                                  act_src=self.act_src, act_sign=self.act_sign, normalize_actor=self.fw.norm_a,
+                                  normalize_critic=self.fw.norm_c, clip=self.clip, vf_coeff=self.vf_coeff,
+                                  mirror_coeff=self.mirror_coeff, parts=parts)
+        return scal
+
+    def apply(self):
+        """clip_grad_norm_ + Adam.step on both networks and the re-pack of the stepped weights (ppo.py:399-410)."""
+        self.steps += 1
+        for nt, norm, (mean, std) in zip(self.nets, (self.fw.norm_a, self.fw.norm_c), self.fw.norm_tables()):
+            nt["in_mean"], nt["in_std"] = (mean, std) if norm else (None, None)
+        self.eng.ppo_adam_step(self.fw.in_dim, self.steps, self.lr, self.eps, self.max_grad_norm, self.nets, self.adam_ws,
+                               beta1=self.betas[0], beta2=self.betas[1])
+
+    def step(self, observations, actions, returns, advantages, idx, scal=None):
+        scal = self.grads(observations, actions, returns, advantages, idx, scal)
+        self.apply()
+        return scal
+
+
 _GRAPH_STREAMS = {}
 
 
@@ -277,10 +390,11 @@ class GraphedActorCritic:
         return self.mu + (self.scale * self.anneal) * torch.randn_like(self.mu), self.value
 
 
-def _global_episode_means(ep_ret, ep_len, multi_rank):
-    """(mean return, mean length) over the episodes of every rank (this rank's alone without a process group)."""
-    tot = [float(np.sum(ep_ret)) if len(ep_ret) else 0.0, float(np.sum(ep_len)) if len(ep_len) else 0.0,
-           float(len(ep_ret))]
+def _global_episode_means(ep_ret, ep_len, multi_rank, sums=None):
+    """(mean return, mean length) over the episodes of every rank (this rank's alone without a process group).
+    sums: (sum of returns, sum of lengths, episodes) already reduced on the device (RolloutBuffer.episode_sums)."""
+    tot = list(sums) if sums is not None else [float(np.sum(ep_ret)) if len(ep_ret) else 0.0,
+                                                float(np.sum(ep_len)) if len(ep_len) else 0.0, float(len(ep_ret))]
     if multi_rank:
         from . import dist as odist
         tot = odist.allreduce_sum(tot)
@@ -469,6 +583,17 @@ class PPO:
             act_sign = env._act_sgn.to(env.eng.device, torch.float32)
         elif act_mirr is not None:
             fused = False                                   # mirror given as a function: unfused torch path
+        # the update path: "kernel" (default where it applies: K14), else the fused-loss torch update (graph-replayed
+        # with use_graph), else plain torch
+        use_kernel = (fused and getattr(self, "update_kernel", True) and (act_mirr is None or act_src is not None)
+                      and KernelUpdate.supports(policy, critic, True))
+        kupd = None
+        # The minibatch permutation: the reference's BatchSampler(SubsetRandomSampler) draws torch.randperm(n) from the
+        # default CPU generator.  For config 3's 1.6 M rows that draw costs the host 25-35 ms per epoch, longer than the GPU
+        # needs for the epoch's 25 kernel updates, so the kernel path draws the permutation on the device
+        # (`device_permutation = False` keeps the host draw, e.g. to train seed-for-seed like the torch paths).
+        device_perm = getattr(self, "device_permutation", None)
+        device_perm = use_kernel if device_perm is None else bool(device_perm)
         T = max(1, self.batch_size // env.num_envs)
         curr_anneal, start = 1.0, time.time()
         history = []
@@ -499,7 +624,18 @@ class PPO:
             t1 = time.time()
             stats = []
             graphed = None
-            if use_graph and fused:
+            kernel = None
+            if use_kernel:
+                # K14: forward + losses + backward of a minibatch in one launch; gradient clipping and Adam stay torch's
+                if kupd is None:
+                    kupd = KernelUpdate(env.eng, policy, critic, self.old_policy, self.clip, self.vf_coeff,
+                                        self.mirror_coeff, obs_mirr, act_src, act_sign, lr=self.lr, eps=self.eps,
+                                        max_grad_norm=self.grad_clip)
+                kernel = kupd
+                kernel.begin(observations)
+                kstats = torch.zeros((self.epochs * max(n_batches, 1), 6), dtype=torch.float64, device=observations.device)
+                adv_flat, ret_flat = advantages.reshape(-1).contiguous(), returns.reshape(-1).contiguous()
+            elif use_graph and fused:
                 # Captured anew for every iteration's update phase (~15 ms).  profiles/r02/graph_drift/README.md:
                 # a captured torch update replays bit-exactly until a [synchronize -> kernel write into a newly
                 # allocated block of >= 1 MB] happens between two replays; after that the multi-block
@@ -510,13 +646,32 @@ class PPO:
                 # lifetime is one update phase.
                 graphed = GraphedUpdate(self, env.eng, minibatch, observations.shape[1], actions.shape[1],
                                         obs_mirr, act_src, act_sign)
-            for _ in range(self.epochs):
+            for epoch in range(self.epochs):
                 # BatchSampler(SubsetRandomSampler(range(n)), minibatch, drop_last=True) draws ONE
                 # torch.randperm(n) from the default CPU generator and cuts it into consecutive
                 # batches; the same permutation is cut on the device here (no per-index Python loop)
-                perm = torch.randperm(n).to(observations.device)
+                # Drawing 1.6 M indices takes the host ~20 ms, as long as the GPU needs for a whole epoch of kernel updates: the
+                # permutation of the NEXT epoch (or of the next iteration's first one) is drawn right after this epoch's
+                # minibatches have been queued, while the GPU works through them.  Same draws in the same order.
+                if device_perm:
+                    perm = torch.randperm(n, device=observations.device).to(torch.int32)
+                else:
+                    perm_host = self._next_perm if getattr(self, "_next_perm", None) is not None and len(self._next_perm) == n \
+                        else torch.randperm(n)
+                    self._next_perm = None
+                    perm = (perm_host.to(torch.int32) if kernel is not None else perm_host).to(observations.device)
                 for b in range(n_batches):
                     idx = perm[b * minibatch:(b + 1) * minibatch]
+                    if kernel is not None:
+                        slot = kstats[len(stats)]
+                        if multi_rank:
+                            kernel.grads(observations, actions, ret_flat, adv_flat, idx, slot)
+                            odist.allreduce_flat([kernel.grad_actor, kernel.grad_critic], weight=minibatch, total_weight=rows_all)
+                            kernel.apply()
+                        else:
+                            kernel.step(observations, actions, ret_flat, adv_flat, idx, slot)
+                        stats.append(slot)
+                        continue
                     if graphed is not None:
                         every = getattr(self, "graph_recapture_every", None)     # test hook: fresh graph every k replays
                         if every and len(stats) and len(stats) % every == 0:
@@ -549,6 +704,8 @@ class PPO:
                     torch.nn.utils.clip_grad_norm_(critic.parameters(), self.grad_clip)
                     self.critic_optimizer.step()
                     stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), float(clipf)))
+                if kernel is not None and not device_perm and (epoch + 1 < self.epochs or itr + 1 < n_itr):
+                    self._next_perm = torch.randperm(n)            # behind the queued minibatches
             if stats and torch.is_tensor(stats[0]):
                 stats = torch.stack(stats).cpu().tolist()      # one device->host copy per iteration
             if graphed is not None:
@@ -556,8 +713,11 @@ class PPO:
                     p_.grad = None                             # gradients live in the graph's pool
                 graphed.close()
             del graphed
-            ep_ret, ep_len = buf.episode_stats()
-            mean_ret, mean_len = _global_episode_means(ep_ret, ep_len, multi_rank)
+            if hasattr(buf, "episode_sums"):
+                mean_ret, mean_len = _global_episode_means(None, None, multi_rank, buf.episode_sums().cpu().tolist())
+            else:
+                ep_ret, ep_len = buf.episode_stats()
+                mean_ret, mean_len = _global_episode_means(ep_ret, ep_len, multi_rank)
             if is_writer:
                 with open(self.train_fn, "a") as out:
                     out.write("{},{}\n".format(mean_ret, mean_len))

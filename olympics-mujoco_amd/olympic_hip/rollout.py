@@ -58,6 +58,21 @@ class RolloutBuffer:
         return (end - base).cpu().tolist(), (t_i - prev_t).cpu().tolist()
 
 
+def _episode_sums(self):
+    """(sum of episode returns, sum of episode lengths, episodes) of the segments that end inside the block as ONE [3] f64
+    device tensor: the means PPO.train logs (ppo.py:418-421) without copying every episode to the host.  Every stored
+    step belongs to exactly one such segment (the block's last row closes the open ones), so the sums are those of
+    the rewards and of the steps."""
+    last = (self.flags & _abi.FLAG_LAST).bool()
+    last[-1] = True
+    T, N = self.rewards.shape
+    return torch.stack([self.rewards.double().sum(), torch.tensor(float(T * N), dtype=torch.float64, device=self.rewards.device),
+                        last.sum().double()])
+
+
+RolloutBuffer.episode_sums = _episode_sums
+
+
 class PPORollout:
     """finish_path + advantage normalisation for a whole [T,N] block on the device."""
 

@@ -1335,3 +1335,45 @@ int oly_ppo_update_cpu(int B, int in_dim, int act_dim, int parts_actor, int part
   scal_out[5] = st[2] / B;
   return OLY_OK;
 }
+
+/* oly_ppo_adam_step's twin for ONE network: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step
+ * (rl/algos/ppo.py:399-410; amsgrad off, no weight decay) on flat buffers, float32 per element in the kernel's
+ * order; the squared norm as the kernel sums it: blocks of 512 elements, thread t takes elements t and 256 + t,
+ * a 64-lane tree per wave, the four waves in order, the blocks in order (fp64).                           */
+int oly_ppo_adam_step_cpu(int n, int step, float lr, float beta1, float beta2, float eps, float max_norm,
+                          float* param, const float* grad, float* exp_avg, float* exp_avg_sq) {
+  if (n <= 0 || step <= 0) return OLY_EINVAL;
+  const int blocks = (n + 511) / 512;
+  double ss = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    double wsum[4];
+    for (int w = 0; w < 4; ++w) {
+      double v[64];
+      for (int l = 0; l < 64; ++l) {
+        const long e0 = 512L * b + 64 * w + l, e1 = e0 + 256;
+        const double g0 = e0 < n ? (double)grad[e0] : 0.0, g1 = e1 < n ? (double)grad[e1] : 0.0;
+        v[l] = g0 * g0 + g1 * g1;
+      }
+      for (int off = 32; off > 0; off >>= 1)
+        for (int l = 0; l < off; ++l) v[l] += v[l + off];
+      wsum[w] = v[0];
+    }
+    ss += ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  }
+  const float norm = (float)sqrt(ss);
+  const float coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
+  const float neg_step = (float)(-((double)lr / bc1)), bc2_sqrt = (float)sqrt(bc2);
+  for (int i = 0; i < n; ++i) {
+    const float g = grad[i] * coef;
+    float m = exp_avg[i], v = exp_avg_sq[i];
+    m = m + (g - m) * w1;
+    v = v * beta2 + (w2 * g) * g;
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    param[i] = param[i] + neg_step * (m / denom);
+  }
+  return OLY_OK;
+}

@@ -122,6 +122,9 @@ int oly_ppo_update_cpu(int B, int in_dim, int act_dim, int parts_actor, int part
                        const float* act_sign, float clip, float vf_coeff, float mirror_coeff, float* grad_actor,
                        float* grad_critic, double* scal_out);
 
+int oly_ppo_adam_step_cpu(int n, int step, float lr, float beta1, float beta2, float eps, float max_norm,
+                          float* param, const float* grad, float* exp_avg, float* exp_avg_sq);
+
 /* OpenMP-parallel variant used only by bench.py's cpu_baseline leg (threads <= 0: all). */
 int oly_il_step_cpu_mt(const oly_il_model* m, int T, int N, const double* qpos,
                        const double* qvel, const float* action, double* prev_inout, void* obs,

@@ -449,3 +449,13 @@ def ppo_update(obs, action, adv, ret, old_mu, actor_wb, critic_wb, sd, old_sd=No
                                   _p(old_sd), _p(old_log_sd), _p(act_src), _p(act_sign), C.c_float(clip),
                                   C.c_float(vf_coeff), C.c_float(mirror_coeff), _p(ga), _p(gc), _p(scal)), "ppo_update")
     return ga, gc, scal
+
+
+def ppo_adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.05):
+    """K15's twin for one network's flat buffers: clip_grad_norm_ + Adam.step -> (param, exp_avg, exp_avg_sq) copies."""
+    f32 = np.float32
+    p, m, v = (np.array(a, f32, copy=True).reshape(-1) for a in (param, exp_avg, exp_avg_sq))
+    g = _c(np.asarray(grad).reshape(-1), f32)
+    _chk(lib().oly_ppo_adam_step_cpu(len(p), int(step), C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+                                     C.c_float(max_norm), _p(p), _p(g), _p(m), _p(v)), "ppo_adam_step")
+    return p, m, v

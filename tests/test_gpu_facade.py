@@ -234,7 +234,7 @@ def test_vec_a3_env_replays_golden_sequence(golden):
 
 
 @pytest.mark.parametrize("minibatch,n_itr", [(2048, 2), (256, 2)])
-@pytest.mark.parametrize("mode", ["torch_losses", "fused", "fused_graph", "fused_graph_fresh"])
+@pytest.mark.parametrize("mode", ["torch_losses", "fused", "fused_graph", "fused_graph_fresh", "kernel"])
 def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr):
     """Config 3 end to end: VecA3Env (synthetic physics readback) -> PPO.train: rollout,
     return scan + adv-norm on the device, clipped-surrogate updates in PyTorch."""
@@ -281,6 +281,8 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr
     ppo = PPO(args, str(tmp_path))
     ppo.use_device_rollout = False               # this test drives the per-step host loop (custom reset above)
     ppo.fused_loss, ppo.use_graph = mode != "torch_losses", mode.startswith("fused_graph")
+    ppo.update_kernel = mode == "kernel"         # K14: forward + losses + backward of a minibatch in one launch
+    ppo.device_permutation = False               # every mode cuts the same host-drawn permutation: same seed, same batches
     if mode == "fused_graph_fresh":
         ppo.graph_recapture_every = 1            # every update runs as the FIRST replay of a new capture
     torch.manual_seed(0)

@@ -147,3 +147,74 @@ def test_ppo_update_rejects_bad_arguments(eng):
                log_sd=np.zeros(17, np.float32))
     with pytest.raises(OlyError):
         run_kernel(eng, big, None, False)                        # 17 actions: the loss wave holds 16 columns
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-4])
+def test_ppo_adam_step_equals_the_oracle_and_torch(eng, oracle, scale):
+    """oly_ppo_adam_step: clip_grad_norm_ + Adam.step for both networks + the re-pack, four steps in a row.  Bit-exact
+    against the oracle twin; against torch's own clip + Adam on the CPU to float32 rounding; the re-packed stream equals
+    a fresh oly_mlp_pack of the stepped parameters."""
+    from test_update_cpu import adam_case, torch_clip_adam
+    from olympic_hip._ffi import lib
+    sizes = (int(lib().oly_ppo_update_grad_floats(41, 256, 12)), int(lib().oly_ppo_update_grad_floats(41, 256, 1)))
+    cases = [adam_case(5 + i, n=n, scale=scale) for i, n in enumerate(sizes)]
+    mean, std = d(np.linspace(-1, 1, 41, dtype=np.float32)), d(np.linspace(0.5, 2, 41, dtype=np.float32))
+    nets = []
+    for (p0, grads, _), out_dim in zip(cases, (12, 1)):
+        z = torch.zeros(len(p0), device="cuda")
+        nets.append(dict(param=d(p0), grad=z.clone(), exp_avg=z.clone(), exp_avg_sq=z.clone(), out_dim=out_dim,
+                         packed=torch.zeros(eng._mlp_floats(41, out_dim), device="cuda"),
+                         in_mean=mean if out_dim == 12 else None, in_std=std if out_dim == 12 else None))
+    ws = torch.zeros(1024, dtype=torch.float64, device="cuda")
+    ref = [(c[0].copy(), np.zeros_like(c[0]), np.zeros_like(c[0])) for c in cases]
+    for t in range(4):
+        for nt, c in zip(nets, cases):
+            nt["grad"].copy_(d(c[1][t]))
+        eng.ppo_adam_step(41, t + 1, 1e-4, 1e-5, 0.05, nets, ws)
+        ref = [oracle.ppo_adam_step(r[0], c[1][t], r[1], r[2], t + 1, 1e-4, eps=1e-5, max_norm=0.05) for r, c in zip(ref, cases)]
+    torch.cuda.synchronize()
+    for nt, r, (p0, grads, cuts) in zip(nets, ref, cases):
+        for k, want in zip(("param", "exp_avg", "exp_avg_sq"), r):
+            assert np.array_equal(nt[k].cpu().numpy(), want), k
+        cuts = np.cumsum([256 * 41, 256, 65536, 256, nt["out_dim"] * 256])
+        tw = np.concatenate([a.reshape(-1) for a in torch_clip_adam(np.split(p0, cuts), [np.split(g, cuts) for g in grads],
+                                                                      1e-4, 1e-5, 0.05)])
+        assert np.abs(nt["param"].cpu().numpy() - tw).max() <= 8e-7
+        parts = [a.contiguous() for a in torch.split(nt["param"], [256 * 41, 256, 65536, 256, nt["out_dim"] * 256, nt["out_dim"]])]
+        fresh = eng.mlp_pack(parts[0].view(256, 41), parts[1], parts[2].view(256, 256), parts[3], parts[4].view(-1, 256), parts[5],
+                             nt["in_mean"], nt["in_std"])
+        assert torch.equal(fresh, nt["packed"])
+
+
+def test_kernel_update_object_steps_like_torch(eng):
+    """ppo.KernelUpdate on the reference-shaped modules: after begin() + three step()s the modules' own parameters (now
+    views of the flat buffers) equal a plain torch run of update_policy + backward + clip_grad_norm_ + Adam.step on
+    copies of the modules, to float32 rounding."""
+    import copy
+    from olympic_hip.ppo import PPO, KernelUpdate, MLPCritic, MLPGaussianActor
+    torch.manual_seed(3)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    pi.obs_mean, pi.obs_std = torch.randn(41, device="cuda") * 0.1, torch.rand(41, device="cuda") + 0.5
+    old = copy.deepcopy(pi)
+    pi_t, vf_t, old_t = copy.deepcopy(pi), copy.deepcopy(vf), copy.deepcopy(pi)
+    n, B = 512, 128
+    obs, act = torch.randn(n, 41, device="cuda"), torch.randn(n, 12, device="cuda") * 0.3
+    ret, adv = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    ku = KernelUpdate(eng, pi, vf, old, 0.2, 0.5, 0.0, lr=1e-3, eps=1e-5, max_grad_norm=0.05)
+    ku.begin(obs)
+    ppo = PPO.__new__(PPO)
+    ppo.clip, ppo.vf_coeff, ppo.policy, ppo.critic, ppo.old_policy = 0.2, 0.5, pi_t, vf_t, old_t
+    oa = torch.optim.Adam(pi_t.parameters(), lr=1e-3, eps=1e-5)
+    oc = torch.optim.Adam(vf_t.parameters(), lr=1e-3, eps=1e-5)
+    for s in range(3):
+        idx = torch.randperm(n, device="cuda")[:B]
+        scal = ku.step(obs, act, ret, adv, idx.to(torch.int32)).clone()
+        out = ppo.update_policy(obs[idx], act[idx], ret[idx].reshape(-1, 1), adv[idx].reshape(-1, 1), 1)
+        oa.zero_grad(); oc.zero_grad()
+        out[0].backward(); out[2].backward()
+        torch.nn.utils.clip_grad_norm_(pi_t.parameters(), 0.05); oa.step()
+        torch.nn.utils.clip_grad_norm_(vf_t.parameters(), 0.05); oc.step()
+        np.testing.assert_allclose(scal[[0, 2, 3]].cpu().numpy(), [float(out[0]), float(out[2]), float(out[3])], rtol=5e-5, atol=1e-6)
+    for a, b in zip(list(pi.parameters()) + list(vf.parameters()), list(pi_t.parameters()) + list(vf_t.parameters())):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-3)
+    assert ku.steps == 3

@@ -215,7 +215,8 @@ def test_struct_layouts_match_the_header():
               "oly_a3_state": _abi.A3State, "oly_a3_readback": _abi.A3Readback, "oly_il_contacts": _abi.IlContacts,
               "oly_a3_blocks": _abi.A3Blocks, "oly_a3_reset_record": _abi.A3ResetRecord,
               "oly_a3_rollout": _abi.A3Rollout, "oly_contact_record": _abi.ContactRecord,
-              "oly_ppo_update": _abi.PPOUpdate}
+              "oly_ppo_update": _abi.PPOUpdate, "oly_adam_net": _abi.AdamNet,
+              "oly_ppo_adam": _abi.PPOAdam}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/olympic_hip.h"', "int main(){"]
     for cname, cls in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

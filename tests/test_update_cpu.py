@@ -83,3 +83,38 @@ def test_ppo_update_oracle_part_count_changes_only_the_last_bits(oracle):
     idx = np.arange(16, dtype=np.int32)
     s1 = oracle.ppo_update(*args, idx=idx, parts_actor=1, parts_critic=1, **kw)
     assert np.isfinite(s1[0]).all()
+
+
+def torch_clip_adam(params, grads_per_step, lr, eps, max_norm):
+    """torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (the reference's optimiser calls, ppo.py:399-410) on a
+    list of parameter arrays, one gradient list per step -> the stepped parameters (float32, CPU)."""
+    import torch
+    ps = [torch.nn.Parameter(torch.tensor(p)) for p in params]
+    opt = torch.optim.Adam(ps, lr=lr, eps=eps)
+    for grads in grads_per_step:
+        for p, g in zip(ps, grads):
+            p.grad = torch.tensor(g)
+        torch.nn.utils.clip_grad_norm_(ps, max_norm)
+        opt.step()
+    return [p.detach().numpy() for p in ps]
+
+
+def adam_case(seed, n=79628, steps=4, scale=1.0):
+    rng = np.random.default_rng(seed)
+    cuts = np.cumsum([256 * 41, 256, 65536, 256])          # several parameter tensors: the norm is over all of them
+    p0 = rng.normal(0, 0.1, n).astype(np.float32)
+    grads = [(scale * rng.normal(0, 10.0 ** rng.uniform(-4, -1), n)).astype(np.float32) for _ in range(steps)]
+    return p0, grads, cuts
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-4])           # gradients far above / below the clip threshold
+def test_ppo_adam_oracle_matches_torch_clip_and_adam(oracle, scale):
+    p0, grads, cuts = adam_case(3, scale=scale)
+    want = np.concatenate([a.reshape(-1) for a in torch_clip_adam(np.split(p0, cuts), [np.split(g, cuts) for g in grads],
+                                                                  1e-4, 1e-5, 0.05)])
+    p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for t, g in enumerate(grads):
+        p, m, v = oracle.ppo_adam_step(p, g, m, v, t + 1, 1e-4, eps=1e-5, max_norm=0.05)
+    # same formulas, float32 rounding of a handful of operations per step on updates of size ~lr
+    assert np.abs(p - want).max() <= 2e-7 * 4, np.abs(p - want).max()
+    assert np.abs(p - p0).max() > 1e-6

@@ -44,7 +44,8 @@ def main():
     ap.add_argument("--itr", type=int, default=3)
     ap.add_argument("--minibatch", type=int, default=65536)
     ap.add_argument("--epochs", type=int, default=3)
-    ap.add_argument("--mode", default="fused_graph", choices=["torch_losses", "fused", "fused_graph"])
+    ap.add_argument("--mode", default="kernel", choices=["torch_losses", "fused", "fused_graph", "kernel"],
+                    help="kernel: K14 gradients (one launch per minibatch) + torch clip / Adam")
     ap.add_argument("--rollout", default="host", choices=["host", "device"],
                     help="host: one env.step per python iteration (K5, K3, K2 launches); device: one fused K10 launch "
                          "per vec step, replayed from a HIP graph, resets on the device")
@@ -79,6 +80,7 @@ def main():
               eval_freq=10 ** 9)
     ppo = PPO(hp, tempfile.mkdtemp(prefix="oly_ppo_"))
     ppo.fused_loss, ppo.use_graph = args.mode != "torch_losses", args.mode == "fused_graph"
+    ppo.update_kernel = args.mode == "kernel"
     ppo.use_graph_rollout = args.mode == "fused_graph"
     ppo.use_device_rollout = args.rollout == "device"
     ppo.tuned_gemms = args.tuned_gemms

@@ -15,7 +15,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from olympic_hip.engine import Engine  # noqa: E402
-from olympic_hip.ppo import PPO, GraphedUpdate, MLPCritic, MLPGaussianActor  # noqa: E402
+from olympic_hip.ppo import PPO, GraphedUpdate, KernelUpdate, MLPCritic, MLPGaussianActor  # noqa: E402
 from olympic_hip.wrappers import SymmetricEnv, _signed_perm  # noqa: E402
 
 MIRROR_OBS = [0.1, -1, 2, -3, -4, 5, -6, -13, -14, 15, 16, 17, 18, -7, -8, 9, 10, 11, 12, -25, -26, 27, 28, 29, 30, -19, -20,
@@ -44,7 +44,7 @@ def main():
         ret, adv = torch.randn(B, 1, device=dev), torch.randn(B, 1, device=dev)
         row = {}
         for mirror in (False, True):
-            for fused in (False, True, "graph"):
+            for fused in (False, True, "graph", "kernel"):
                 ppo.policy = MLPGaussianActor(41, 12).to(dev)
                 ppo.old_policy = MLPGaussianActor(41, 12).to(dev)
                 ppo.critic = MLPCritic(41).to(dev)
@@ -56,8 +56,22 @@ def main():
                     gu = GraphedUpdate(ppo, eng, B, 41, 12, sym.mirror_clock_observation if mirror else None,
                                        a_src if mirror else None, a_sgn if mirror else None)
                     idx = torch.arange(B, device=dev)
+                if fused == "kernel":
+                    ku = KernelUpdate(eng, ppo.policy, ppo.critic, ppo.old_policy, 0.2, 0.5, 0.4,
+                                      sym.mirror_clock_observation if mirror else None, a_src if mirror else None,
+                                      a_sgn if mirror else None)
+                    ku.begin(obs)
+                    idx32 = torch.arange(B, device=dev, dtype=torch.int32)
+                    ret1, adv1 = ret.reshape(-1).contiguous(), adv.reshape(-1).contiguous()
 
                 def step():
+                    if fused == "kernel":
+                        ku.grads(obs, act, ret1, adv1, idx32)
+                        torch.nn.utils.clip_grad_norm_(ppo.policy.parameters(), 0.05)
+                        opt_a.step()
+                        torch.nn.utils.clip_grad_norm_(ppo.critic.parameters(), 0.05)
+                        opt_c.step()
+                        return
                     if fused == "graph":
                         gu(obs, act, ret, adv, idx)
                         return
@@ -82,7 +96,7 @@ def main():
                 for _ in range(reps):
                     step()
                 torch.cuda.synchronize()
-                row[("mirror_" if mirror else "") + {False: "torch", True: "fused", "graph": "fused_graph"}[fused] + "_ms"] = (time.perf_counter() - t0) / reps * 1e3
+                row[("mirror_" if mirror else "") + {False: "torch", True: "fused", "graph": "fused_graph", "kernel": "kernel"}[fused] + "_ms"] = (time.perf_counter() - t0) / reps * 1e3
         out[f"minibatch_{B}"] = row
     print(json.dumps(out, indent=1))
 
