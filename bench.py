@@ -480,6 +480,84 @@ def cpu_baseline_config3(seconds=8.0):
                       f"{steps} vec steps in {dt:.1f} s, 1 thread"}
 
 
+def _update_flop_per_row(n_in, n_act, mirror):
+    """Algorithmic FLOP of one row of a PPO minibatch update (2 x multiply-adds): forward + backward (data gradients of the
+    two hidden layers, weight gradients of all three) of the actor and the critic; with the mirror loss the actor runs
+    forward + backward on the mirrored row as well.  (The kernel's recomputed third forward is not credited.)"""
+    fb = lambda o: 2 * (n_in * 256 + 65536 + 256 * o) + 2 * (2 * 256 * o + 2 * 65536 + 256 * n_in)
+    return fb(n_act) * (2 if mirror else 1) + fb(1)
+
+
+def config3_iteration(env, pi, vf, args, minibatch=65536, epochs=3, n_itr=5):
+    """A WHOLE config-3 iteration as PPO.train runs it (rl/algos/ppo.py:305-420): rollout (K13) -> return scan +
+    statistics + normalisation (K6 / K7) -> `epochs` x (n / minibatch) minibatch updates, each = K14 (forward, losses
+    incl. the mirror-symmetry loss the reference's train_a3_walk.py switches on by default, backward) + clip + Adam +
+    re-pack (oly_ppo_adam_step).  Wall clock from PPO.train's own instrumentation, steady iterations only."""
+    import tempfile
+
+    import numpy as np
+    import torch
+    from olympic_hip import specs
+    from olympic_hip.ppo import PPO, KernelUpdate
+    from olympic_hip.wrappers import SymmetricEnv
+    N, T = env.num_envs, 400
+    spec = specs.A3Spec(mass=41.5)
+    out = {}
+    for label, mirror in (("with_mirror_loss", True), ("without_mirror_loss", False)):
+        hp = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=minibatch,
+                  epochs=epochs, max_traj_len=T, use_gae=False, num_procs=N, max_grad_norm=0.05,
+                  mirror_coeff=0.4 if mirror else 0.0, eval_freq=10 ** 9)
+        ppo = PPO(hp, tempfile.mkdtemp(prefix="oly_bench_ppo_"))
+        torch.manual_seed(0)
+        pi_, vf_ = type(pi)(41, 12).to(env.eng.device), type(vf)(41).to(env.eng.device)
+        sym = SymmetricEnv(lambda: env, mirrored_obs=list(spec.mirrored_obs), mirrored_act=list(spec.mirrored_acts),
+                           clock_inds=list(spec.clock_inds))
+        hist = ppo.train((lambda: sym) if mirror else (lambda: env), pi_, vf_, n_itr=n_itr, verbose=False)
+        steady = hist[2:] or hist[1:] or hist
+        sample_s = float(np.mean([h["sample_s"] for h in steady]))
+        optim_s = float(np.mean([h["optim_s"] for h in steady]))
+        n_upd = epochs * ((N * T) // minibatch)
+        out[label] = {"sample_s": sample_s, "update_s": optim_s, "updates": n_upd, "update_ms_per_minibatch": 1e3 * optim_s / n_upd,
+                      "env_steps_per_s": N * T / (sample_s + optim_s), "losses_finite": bool(np.isfinite(hist[-1]["losses"]).all())}
+    # the update's kernels alone, HIP events on the launch stream: gradients (K14 main + finishing launch) and the
+    # optimiser half (norm, clip + Adam, two packs), on minibatches gathered from a full-size buffer
+    n = N * T
+    dev = env.eng.device
+    obs, act = torch.randn(n, 41, device=dev), 0.3 * torch.randn(n, 12, device=dev)
+    ret, adv = torch.randn(n, device=dev), torch.randn(n, device=dev)
+    import copy
+    stream = env.eng.ctx.stream
+    kern = {}
+    for label, mirror in (("with_mirror_loss", True), ("without_mirror_loss", False)):
+        pi_, vf_ = type(pi)(41, 12).to(dev), type(vf)(41).to(dev)
+        sym = SymmetricEnv(lambda: env, mirrored_obs=list(spec.mirrored_obs), mirrored_act=list(spec.mirrored_acts),
+                           clock_inds=list(spec.clock_inds))
+        ku = KernelUpdate(env.eng, pi_, vf_, copy.deepcopy(pi_), 0.2, 0.5, 0.4 if mirror else 0.0,
+                          sym.mirror_clock_observation if mirror else None,
+                          sym._act_src if mirror else None, sym._act_sgn if mirror else None)
+        ku.begin(obs)
+        row = {}
+        for B in (minibatch, 64):
+            idx = torch.randperm(n, device=dev)[:B].to(torch.int32)
+            g_ms = event_ms(stream, 30 if B > 4096 else 200, lambda: ku.grads(obs, act, ret, adv, idx))
+            a_ms = event_ms(stream, 200, lambda: ku.apply(), wake_s=0.0)
+            flop = _update_flop_per_row(41, 12, mirror) * B
+            row[f"minibatch_{B}"] = {
+                "gradients_ms": g_ms, "clip_adam_repack_ms": a_ms, "update_ms": g_ms + a_ms, "launches": 6,
+                "roofline": {"bound": "mfma", "achieved": flop / (g_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": flop / (g_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                             "alg_flop_per_row": flop // B,
+                             "note": "ppo_update_kernel + ppo_update_finish_kernel (K14), both launches in the time"}}
+        kern[label] = row
+    out["kernels"] = kern
+    out["workload"] = (f"{N} envs x {T} steps per iteration, {epochs} epochs x {(N * T) // minibatch} minibatches of {minibatch} rows, "
+                       "policy 41-256-256-12 + critic 41-256-256-1, Adam + grad-norm clip; rounds 1-3 ran this phase as "
+                       "PyTorch GEMMs (0.24-0.30 s per iteration)")
+    out["value"] = out["with_mirror_loss"]["env_steps_per_s"]
+    out["unit"] = "env-steps/s over a whole iteration (sampling + update)"
+    return out
+
+
 def config3_block(rk, args):
     """BASELINE config 3 on one GPU: the sampling loop's wall clock per vec step, and its kernels against their
     rooflines, HIP-event timed on the launch stream: K13 (the whole rollout in one launch; f32 MFMA), K11 (actor +
@@ -537,6 +615,11 @@ def config3_block(rk, args):
            "timing": "HIP events on the launch stream, back-to-back launches (K11 / K10: 100 each; K13: best of 4 whole "
                      "rollouts / T)"}
     env._dev_rollout.close()
+    try:
+        out["iteration"] = config3_iteration(env, pi, vf, args)
+    except Exception as e:                                   # never lose the sampling numbers to the second half
+        out["iteration"] = {"error": f"{type(e).__name__}: {e}"}
+    out["workload"] = out["workload"].replace("update phase = PyTorch-ROCm, not timed here", "whole iterations under `iteration`")
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_config3()
     return out
