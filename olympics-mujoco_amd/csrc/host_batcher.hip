@@ -380,9 +380,9 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
   b->overflow_env.store(-1);
   b->pool.run();
   const double t2 = now_s();
-  if (const int oe = b->overflow_env.load(); oe >= 0)
-    OLY_FAIL(ctx, OLY_ERANGE, "oly_batcher_step: environment %d has more contacts than the %d staged slots and a sensor pair "
-             "without a contact among them (or a negative count): enable contacts with more slots", oe, b->C);
+  // A contact overflow is reported AFTER the step has been completed on the device: the host physics has already
+  // advanced, so returning here would leave the device-side state (prev, observations) one step behind it.
+  const int oe = b->overflow_env.load();
   // (3) state rows up, post-physics path on the device
   if (!(b->mapped & 2)) {
     OLY_HIP(ctx, hipMemcpyAsync(b->d_qpos, b->h_qpos, sizeof(double) * b->N * b->nq, hipMemcpyHostToDevice, s));
@@ -411,6 +411,11 @@ extern "C" int oly_batcher_step(oly_batcher* b, const float* action, void* obs, 
                    absorbing, fall_code, nullptr, out_flags & ~OLY_OUT_CTRL_F64, stream);
   const double t3 = now_s();
   b->timing[0] = t1 - t0; b->timing[1] = t2 - t1; b->timing[2] = t3 - t2;
+  if (rc == OLY_OK && oe >= 0)
+    OLY_FAIL(ctx, OLY_ERANGE, "oly_batcher_step: environment %d has more contacts than the %d staged slots and a sensor pair "
+             "without a contact among them (or a negative count): its foot-force columns of this step are not the "
+             "reference's; the step itself was completed (host and device state agree); enable contacts with more slots",
+             oe, b->C);
   return rc;
 }
 

@@ -941,8 +941,14 @@ extern "C" int oly_a3_rollout_persistent(oly_ctx* ctx, int N, const oly_a3_block
   a.normalize[1] = normalize_critic;
   a.mu_out = mu_out;
   a.value_out = value_out;
+#ifdef OLY_DIAG   // diagnostic builds only (__graft_entry__.build(diag=True), tools/time_k13.py): a shipped library never
+                  // reads a variable that drops phases of the kernel or overwrites outputs with timer sums
   static const int skip = [] { const char* e = getenv("OLY_K13_SKIP"); return e ? atoi(e) : 0; }();
+  if ((skip & 8) && (long)ro->T * N < 36) OLY_FAIL(ctx, OLY_EINVAL, "OLY_K13_SKIP bit 3 needs T * N >= 36 (the stamps go to buf_values[0..35])");
   a.skip = skip;
+#else
+  a.skip = 0;
+#endif
   if (!ctx->roll_attr_done) {
     OLY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(a3_rollout_kernel<3>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS));

@@ -1,7 +1,8 @@
 // ctx management, error reporting and measurement helpers of libolympic_hip.so.
 #include "oly_common.h"
 
-extern "C" const char* oly_version(void) { return "olympic_hip 0.1 (gfx950)"; }
+extern "C" const char* oly_version(void) { return "olympic_hip 0.4 (gfx950)"; }
+extern "C" int oly_abi_version(void) { return OLY_ABI_VERSION; }
 
 extern "C" const char* oly_strerror(int code) {
   switch (code) {

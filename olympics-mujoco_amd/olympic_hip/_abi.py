@@ -116,6 +116,7 @@ A3_PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(A3Re
 
 # name -> (restype, argtypes); device/host pointers are void*.
 STD_SCALAR, STD_PER_DIM, STD_FULL = 0, 1, 2
+ABI_VERSION = 4          # OLY_ABI_VERSION of include/olympic_hip.h this table mirrors
 
 
 class AdamNet(C.Structure):
@@ -146,6 +147,7 @@ SIGNATURES = {
     "oly_strerror": (C.c_char_p, [C.c_int]),
     "oly_last_error": (C.c_char_p, [vp]),
     "oly_version": (C.c_char_p, []),
+    "oly_abi_version": (C.c_int, []),
     "oly_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "oly_destroy": (None, [vp]),
     "oly_il_configure": (C.c_int, [vp, C.POINTER(IlModel)]),

@@ -36,6 +36,9 @@ def lib():
             fn = getattr(L, name)   # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        if int(L.oly_abi_version()) != _abi.ABI_VERSION:
+            raise OlyError(f"{LIB_PATH} exports ABI version {int(L.oly_abi_version())}, this binding mirrors version "
+                           f"{_abi.ABI_VERSION} of include/olympic_hip.h: rebuild the library")
         _lib = L
     return _lib
 

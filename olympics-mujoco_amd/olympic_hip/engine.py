@@ -623,12 +623,13 @@ class Engine:
         self.n_grf_pairs = len(pairs)
         return self
 
-    def il_ground_forces(self, ncon, geom1, geom2, force6, want_steps=False, check=True):
+    def il_ground_forces(self, ncon, geom1, geom2, force6, want_steps=False, check=False):
         """[W,N,...] substep contact slots -> dict(mean [N,3P], steps [W,N,3P] or None, overflow [N] u8).
         `ncon` is the raw data.ncon.  An environment whose count exceeded the staged slots in a substep where a
         sensor pair found no contact among them cannot be reproduced (the reference scans every contact,
-        UnitreeH1.py:113-123): with check=True (default; one host round trip) that raises, with check=False
-        the caller owns the `overflow` bytes."""
+        UnitreeH1.py:113-123): the kernel flags it in `overflow` and the caller owns those bytes (VecLocoEnv keeps a
+        sticky copy and reads it in its next host round trip: reset() / raise_if_contact_overflow()).  check=True reads
+        them back HERE: a blocking device-to-host round trip per call, which also breaks graph capture of the caller."""
         if not getattr(self, "n_grf_pairs", 0):
             raise OlyError("il_ground_forces before grf_configure")
         W, N, Cc = (int(v) for v in geom1.shape)

@@ -214,11 +214,28 @@ class VecLocoEnv:
         c = None if fresh else self.physics.substep_contacts()
         if c is None:
             return torch.zeros((1, self.num_envs, self.spec.n_grf), dtype=torch.float64, device=self.device)
-        return self.eng.il_ground_forces(c["ncon"], c["geom1"], c["geom2"], c["force6"])["mean"].unsqueeze(0)
+        o = self.eng.il_ground_forces(c["ncon"], c["geom1"], c["geom2"], c["force6"])
+        # sticky per-environment overflow flags, no host round trip per step: read in reset() / raise_if_contact_overflow()
+        self._grf_overflow = o["overflow"] if getattr(self, "_grf_overflow", None) is None else torch.maximum(self._grf_overflow, o["overflow"])
+        return o["mean"].unsqueeze(0)
+
+    def raise_if_contact_overflow(self):
+        """One device-to-host read of the sticky overflow flags of every il_ground_forces call since the last check: an
+        environment whose contact count exceeded the staged slots in a substep where a sensor pair found none among them
+        (the foot-force columns of that step cannot match the reference, UnitreeH1.py:113-123)."""
+        over = getattr(self, "_grf_overflow", None)
+        if over is not None and self.num_envs and bool(over.any().item()):
+            bad = torch.nonzero(over).flatten()[:8].tolist()
+            self._grf_overflow = None
+            raise OlyError(f"il_ground_forces: more contacts than the staged slots and a sensor pair without a contact "
+                           f"among them (or a negative count) in environments {bad} since the last check: stage more slots")
+        self._grf_overflow = None
 
     # ----- reset (loco_env_base.py:568-657)
     def reset(self, env_mask=None, obs=None):
         N = self.num_envs
+        if env_mask is None:
+            self.raise_if_contact_overflow()          # a full reset is a host-synchronous point of every rollout loop
         if obs is not None:
             full = torch.cat([torch.zeros((N, self.spec.n_drop), dtype=torch.float64, device=self.device),
                               torch.as_tensor(obs, dtype=torch.float64, device=self.device).reshape(N, -1)], dim=1)

@@ -101,15 +101,23 @@ class DiscriminatorReward:
                 and n.encoder[1].out_features == 128 and n.mu_out.out_features == 128)
 
     def packed(self):
-        """The MFMA operand stream of the current weights; re-packed (one launch) whenever an optimiser step
-        or a load has touched a parameter."""
+        """The MFMA operand stream of the CURRENT weights: re-packed on every call (one ~6 us launch into the same
+        buffer), as FusedMLPForward.refresh() does per rollout.  A cache keyed on (data_ptr, _version) would miss writes
+        through `.data` (dist.broadcast_parameters, load paths that copy into p.data): `_version` does not move for
+        those, and the reward would silently keep the old weights.  `cache_packed = True` opts into that cache for
+        callers that own every write to the parameters (benchmarks of a frozen network)."""
         ps = self._params()
-        ver = tuple((p.data_ptr(), p._version) for p in ps)
-        if ver != self._packed_ver:
-            self._packed = self.eng.disc_pack(*[p.detach().to(torch.float32).contiguous() for p in ps],
-                                              packed=self._packed)
+        if getattr(self, "cache_packed", False):
+            ver = tuple((p.data_ptr(), p._version) for p in ps)
+            if ver == self._packed_ver and self._packed is not None:
+                return self._packed
             self._packed_ver = ver
+        self._packed = self.eng.disc_pack(*[p.detach().to(torch.float32).contiguous() for p in ps], packed=self._packed)
         return self._packed
+
+    def invalidate(self):
+        """Forget the cached stream (only meaningful with cache_packed)."""
+        self._packed_ver = None
 
     def _update_statistics(self, x):
         """Standardizer.forward's update_mean_std on the masked batch (networks.py:70,76-81)."""

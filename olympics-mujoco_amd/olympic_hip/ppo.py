@@ -617,10 +617,18 @@ class PPO:
             n_batches = n // minibatch
             rows_all = float(minibatch)
             if multi_rank:
-                # shards may differ in size (shard_range hands out near-equal ranges): every rank must enter the same
-                # number of gradient all-reduces, and a rank's gradient counts with its minibatch's rows
+                # Convention: minibatch_size is PER RANK (every rank contributes `minibatch` rows to each of the
+                # min-over-ranks n_batches updates, so the global minibatch is world x minibatch rows and a rank with a
+                # larger shard drops its surplus tail rows of the epoch's permutation; to keep the reference's single-learner
+                # batch, pass minibatch_size / world).  Shards may differ in size (shard_range hands out near-equal
+                # ranges): every rank must enter the same number of gradient all-reduces, and a rank's gradient counts
+                # with its minibatch's rows
                 n_batches = odist.allreduce_min(n_batches)
                 rows_all = odist.allreduce_sum([minibatch])[0]
+            if n_batches == 0:
+                # np.mean over an empty loss list would put NaN into the history and the epoch loop would silently do nothing
+                raise ValueError(f"PPO.train: minibatch_size {minibatch} exceeds the {n} samples of "
+                                 f"{'the smallest rank shard' if multi_rank else 'one iteration'}: no update would run")
             t1 = time.time()
             stats = []
             graphed = None

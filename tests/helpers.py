@@ -242,3 +242,93 @@ def torch_ppo_update_grads(c, idx=None, clip=0.2, vf_coeff=0.5, mirror_coeff=0.4
                 float(((ratio - 1).abs() > clip).float().mean())]
     flat = lambda ps: np.concatenate([p.grad.reshape(-1).numpy() for p in ps])
     return flat(A), flat(Cw), np.array(scal)
+
+
+# ------------------------------------------------------------------------------ K13 against the oracle, directly
+def check_persistent_rollout_against_oracle(eng, orc, N=70, T=12, max_len=5, K=5, seed=3, det=False, normalize=True):
+    """oly_a3_rollout_persistent (K13: all T steps of PPO.sample, rl/algos/ppo.py:169-196, in ONE launch) against a loop
+    of the oracle's own functions: oly_mlp_forward_cpu (actor, critic) + oly_a3_vec_step_cpu, step by step.
+
+    The kernel runs all T steps on its own.  The oracle then replays them; at step t its forward reads the observation
+    row the KERNEL stored (checked to be within one float32 ulp of the oracle's own: device libm vs glibc in the
+    observation's trigonometric terms), so that every later comparison of the step is exact where the arithmetic is:
+    mu / value / sampled action / stored value / PD target BIT-EXACT (k-ordered fma chains, f32 mul + add), flags,
+    counters, integer task state, cursors BIT-EXACT, float64 rewards 1e-11, goal / sequence 1e-11.  Returns a summary."""
+    import torch
+    from olympic_hip import _abi, specs
+    from olympic_hip.a3 import clock_lut
+    from olympic_hip.synthetic import A3_FLOOR_BODY, A3_GEOM_BODYID, A3_LFOOT_BODY, A3_RFOOT_BODY, a3_synthetic_blocks
+    from olympic_hip.vecstep import draw_reset_records
+    spec = specs.A3Spec(mass=41.5)
+    lut = clock_lut(spec.swing_duration, spec.stance_duration, 0.1, "grounded", 1 / spec.control_dt, spec.period)
+    contact = (A3_GEOM_BODYID, A3_FLOOR_BODY, A3_RFOOT_BODY, A3_LFOOT_BODY)
+    eng.a3_configure(spec, lut)
+    eng.contact_configure(*contact)
+    rng = np.random.default_rng(seed)
+    nobs, nu, depth = spec.n_obs, spec.nu, 3
+    slots = T // max_len + 2
+    blocks = a3_synthetic_blocks(N, K, seed=seed, p_bad=0.05, p_low=0.02)
+    pool = draw_reset_records(np.random.RandomState(seed), N * depth, spec, iter_count=6000)
+    z = lambda dt, *sh: np.zeros((N,) + sh, dt)
+    state = dict(phase=z(np.int32), t1=z(np.int32), t2=z(np.int32), reached_frames=z(np.int32), target_reached=z(np.uint8),
+                 mode=np.full(N, _abi.MODE_STANDING, np.int32), seq_len=np.ones(N, np.int32),
+                 sequence=z(np.float64, _abi.OLY_MAX_SEQ, 4), goal=z(np.float64, 8))
+    ro = dict(T=T, max_traj_len=max_len, deterministic=det, side_slots=slots, pool_depth=depth, mu=z(np.float32, nu),
+              value=z(np.float32), scale=None if det else rng.uniform(0.05, 0.4, nu).astype(np.float32),
+              eps=None if det else rng.normal(0, 1, (T, N, nu)).astype(np.float32), state=z(np.float32, nobs),
+              pd_target=z(np.float64, nu), buf_states=np.zeros((T, N, nobs), np.float32),
+              buf_actions=np.zeros((T, N, nu), np.float32), buf_rewards=np.zeros((T, N)),
+              buf_values=np.zeros((T, N), np.float32), buf_flags=np.zeros((T, N), np.uint8), buf_rew6=None,
+              traj_len=z(np.int32), side_obs=np.zeros((N * slots, nobs), np.float32), side_t=np.full(N * slots, -1, np.int32),
+              side_count=z(np.int32), pool=pool.view(np.uint8).reshape(-1).copy(), pool_count=z(np.int32),
+              ctr=np.array([0, 2], np.int32))
+    wa = [rng.normal(0, s, sh).astype(np.float32) for s, sh in ((0.2, (256, nobs)), (0.1, (256,)), (0.08, (256, 256)), (0.1, (256,)),
+                                                                 (0.05, (nu, 256)), (0.1, (nu,)))]
+    wc = [rng.normal(0, s, sh).astype(np.float32) for s, sh in ((0.2, (256, nobs)), (0.1, (256,)), (0.08, (256, 256)), (0.1, (256,)),
+                                                                 (0.1, (1, 256)), (0.1, (1,)))]
+    mean = rng.normal(0, 0.1, nobs).astype(np.float32) if normalize else None
+    std = rng.uniform(0.8, 1.3, nobs).astype(np.float32) if normalize else None
+    d = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    d_blocks = {k: d(v) for k, v in blocks.items()}
+    d_state = {k: d(v) for k, v in state.items()}
+    d_ro = {k: (d(v) if isinstance(v, np.ndarray) else v) for k, v in ro.items()}
+    ctr = torch.zeros(eng.a3_vec_ctr_len(N), dtype=torch.int32, device="cuda")
+    ctr[1:-2:2] = int(ro["ctr"][1])
+    d_ro["ctr"] = ctr
+    launch = eng.a3_vec_prepare(d_blocks, d_state, d_ro)
+    pa, pc = eng.mlp_pack(*[d(a) for a in wa], d(mean), d(std)), eng.mlp_pack(*[d(a) for a in wc])
+    launch(_abi.VSTEP_RESET_ALL)
+    launch.persistent(pa, normalize, pc, False)                  # the whole rollout: ONE launch
+    torch.cuda.synchronize()
+    h = lambda t_: t_.cpu().numpy()
+    got = {k: h(v) for k, v in d_ro.items() if torch.is_tensor(v)}
+    got_state = {k: h(v) for k, v in d_state.items()}
+    ulp = np.spacing(np.float32(1.0))
+    orc.a3_vec_step(spec, lut, contact, blocks, state, ro, _abi.VSTEP_RESET_ALL)
+    for t in range(T):
+        x = got["buf_states"][t]                                 # the row K13's forward read at step t
+        assert np.abs(x - ro["state"]).max() <= ulp * max(1.0, np.abs(ro["state"]).max()), ("observation", t)
+        ro["state"][...] = x
+        mu = orc.mlp_forward(x, *wa, mean, std)
+        val = orc.mlp_forward(x, *wc)[:, 0]
+        ro["mu"][...], ro["value"][...] = mu, val
+        orc.a3_vec_step(spec, lut, contact, blocks, state, ro, 0)
+        assert np.array_equal(got["buf_values"][t], val), ("value", t)
+        assert np.array_equal(got["buf_actions"][t], ro["buf_actions"][t]), ("action", t)
+        assert np.array_equal(got["buf_flags"][t], ro["buf_flags"][t]), ("flags", t)
+        np.testing.assert_allclose(got["buf_rewards"][t], ro["buf_rewards"][t], rtol=1e-11, atol=1e-13)
+    assert np.array_equal(got["mu"], ro["mu"]) and np.array_equal(got["value"], ro["value"])     # the last forward
+    assert np.array_equal(got["pd_target"], ro["pd_target"])
+    for k in ("traj_len", "side_count", "side_t", "pool_count"):
+        assert np.array_equal(got[k], ro[k]), k
+    for k in ("phase", "t1", "t2", "reached_frames", "target_reached", "mode", "seq_len"):
+        assert np.array_equal(got_state[k], state[k]), k
+    np.testing.assert_allclose(got_state["sequence"], state["sequence"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(got_state["goal"], state["goal"], rtol=1e-11, atol=1e-12)
+    for k in ("state", "side_obs"):
+        assert np.abs(got[k] - ro[k]).max() <= ulp * max(1.0, np.abs(ro[k]).max()), k
+    c = got["ctr"].reshape(-1, 2)
+    assert (c[:-1, 0] == T).all() and (c[:-1, 1] == 2 + T).all() and c[-1, 0] == 0
+    fl = ro["buf_flags"]
+    return dict(N=N, T=T, resets=int(ro["pool_count"].sum()) - N, cuts=int(((fl & _abi.FLAG_LAST) != 0).sum()),
+                bootstrap_rows=int((ro["side_t"] >= 0).sum()))

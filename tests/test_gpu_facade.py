@@ -320,6 +320,36 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr
 _TRAINED = {}
 
 
+def test_discriminator_reward_follows_writes_through_dot_data(golden):
+    """parameters written through `.data` (what dist.broadcast_parameters and load paths do) do not bump
+    `_version`; the fused reward must still use the new weights (the stream is re-packed per call)."""
+    from olympic_hip.engine import Engine
+    from olympic_hip.gail import DiscriminatorReward, VariationalDiscriminator
+    g = golden("vail_disc.npz")
+    eng = Engine(0)
+    net = VariationalDiscriminator().load_reference_arrays(g).cuda()
+    dr = DiscriminatorReward(eng, net, state_mask=np.arange(32))
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.empty((300, 32), device="cuda").normal_(0, 1, generator=gen)
+    eps = torch.empty((300, 128), device="cuda").normal_(0, 1, generator=gen)
+    before = dr.forward(x, eps, want=("logits",))["logits"].clone()
+    v0 = net.decoder.weight._version
+    net.decoder.weight.data.mul_(2.0)
+    net.encoder[0].bias.data.add_(0.25)
+    assert net.decoder.weight._version == v0                     # the write the version counter does not see
+    after = dr.forward(x, eps, want=("logits",))["logits"]
+    assert not torch.equal(before, after)
+    ref, _, _ = dr.logits_unfused(x, eps)                        # torch GEMMs on the CURRENT parameters
+    np.testing.assert_allclose(host(after), host(ref), rtol=2e-4, atol=2e-4)
+    dr.cache_packed = True                                       # the opt-in cache: explicit invalidation
+    dr.forward(x, eps, want=("logits",))
+    net.decoder.weight.data.mul_(0.5)
+    stale = dr.forward(x, eps, want=("logits",))["logits"].clone()
+    dr.invalidate()
+    fresh = dr.forward(x, eps, want=("logits",))["logits"]
+    assert torch.equal(stale, after) and not torch.equal(fresh, stale)
+
+
 def test_gail_fit_reward_and_advantage_pipeline(golden, oracle):
     """Config 4 at N = 4096: discriminator reward -> GAE(0.97) -> biased-std normalisation."""
     from olympic_hip.engine import Engine

@@ -1330,15 +1330,15 @@ def test_il_ground_forces_vs_oracle(eng, oracle, W, N, C):
     assert np.array_equal(host(o["mean"]), e_mean)
     assert (e_step != 0).any() or N == 1
     # ncon > C: exact while every sensor pair has its first contact among the C staged slots (the reference scans
-    # all data.ncon contacts, UnitreeH1.py:113-123), flagged otherwise; bit-exact flags, and the default call raises
+    # all data.ncon contacts, UnitreeH1.py:113-123), flagged otherwise; bit-exact flags; check=True reads them back and raises
     assert np.array_equal(host(o["overflow"]), e_over)
     if N > 2:
         assert e_over[1] == 1 and 0 < e_over.sum() < N, "the case must hold flagged and unflagged ncon > C environments"
         assert ((ncon > C).any(0) & (e_over == 0)).any()
         with pytest.raises(OlyError, match="staged slots"):
-            eng.il_ground_forces(dev(ncon), dev(g1), dev(g2), dev(f6))
+            eng.il_ground_forces(dev(ncon), dev(g1), dev(g2), dev(f6), check=True)
         keep = e_over == 0                                            # without the flagged environments: no error
-        o2 = eng.il_ground_forces(dev(ncon[:, keep]), dev(g1[:, keep]), dev(g2[:, keep]), dev(f6[:, keep]))
+        o2 = eng.il_ground_forces(dev(ncon[:, keep]), dev(g1[:, keep]), dev(g2[:, keep]), dev(f6[:, keep]), check=True)
         assert np.array_equal(host(o2["mean"]), e_mean[keep])
     # the dense form (rows already reduced per substep, as the packed host batcher stages them)
     assert np.array_equal(host(eng.il_grf_window(dev(e_step))), e_mean)
@@ -1347,6 +1347,7 @@ def test_il_ground_forces_vs_oracle(eng, oracle, W, N, C):
 def test_h1_env_with_foot_forces(eng, oracle):
     """UnitreeH1(use_foot_forces=True): obs = [joint obs, mean_grf / 1000] with the window mean of
     the control step's substep contacts; zeros right after reset."""
+    from olympic_hip._ffi import OlyError
     from olympic_hip.envs import ReplayPhysics, VecLocoEnv
     sp = specs.unitree_h1("walk").with_foot_forces("UnitreeH1")
     assert sp.n_grf == 6 and sp.n_obs == 38 and sp.geom_group[0] == 0 and sp.geom_group[22] == 1 and sp.geom_group[12] == 2
@@ -1369,6 +1370,20 @@ def test_h1_env_with_foot_forces(eng, oracle):
         assert np.array_equal(host(o), ref["obs"][t])
         assert np.array_equal(host(o)[:, 32:], (means[t] / 1000.0).astype(np.float32))
         assert np.array_equal(host(a), ref["absorbing"][t].astype(bool))
+    env.raise_if_contact_overflow()                                            # nothing was flagged
+    # more contacts than staged slots, none of the staged ones between a sensor pair: step() does not block on it,
+    # the sticky flag is read at the next host-synchronous point
+    con2 = {k: v.copy() for k, v in con.items()}
+    con2["ncon"][0, 3, 7] = C + 4
+    con2["geom2"][0, 3, 7, :] = 5
+    phys2 = ReplayPhysics(sp, dev(qpos), dev(qvel), contacts={k: dev(v) for k, v in con2.items()})
+    env2 = VecLocoEnv(sp, N, engine=eng, physics=phys2, random_start=False)
+    env2.reset()
+    env2.step(dev(act[0]))
+    env2.step(dev(act[1]))
+    with pytest.raises(OlyError, match=r"environments \[7\]"):
+        env2.reset()
+    env2.reset()                                                               # the flags were consumed
     with pytest.raises(NotImplementedError):
         specs.atlas("walk").with_foot_forces("Atlas")
 

@@ -314,6 +314,16 @@ def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K, C)
     assert env._dev_rollout._fw.norm_c == bool(N % 2)
 
 
+@pytest.mark.parametrize("N,T,max_len,det,normalize", [(70, 12, 5, False, True), (16, 9, 3, True, False), (261, 20, 6, False, True)])
+def test_persistent_rollout_against_the_oracle_directly(eng, oracle, N, T, max_len, det, normalize):
+    """K13 pinned to the oracle itself (not only to the K11 + K10 loop): one launch for all T steps against a loop of
+    oly_mlp_forward_cpu x 2 + oly_a3_vec_step_cpu, resets on, stochastic actions from a supplied noise block, the
+    actor's input normalisation on (rl/algos/ppo.py:169-196; bars in helpers.check_persistent_rollout_against_oracle)."""
+    from helpers import check_persistent_rollout_against_oracle
+    info = check_persistent_rollout_against_oracle(eng, oracle, N=N, T=T, max_len=max_len, det=det, normalize=normalize, seed=N + T)
+    assert info["resets"] > 0 and info["cuts"] > N and info["bootstrap_rows"] > 0     # the case exercises the cut rules
+
+
 def test_a_step_past_the_last_row_writes_nothing_and_is_reported(eng, golden, oracle):
     """The step index lives on the device: a launch with t outside [0, T) (one replay too many, counters never
     rewound) must not write beyond the rollout buffers.  K10 and K13 touch nothing, advance nothing and leave a sticky

@@ -206,6 +206,9 @@ def test_library_exports_every_declared_symbol():
     assert set(_abi.SIGNATURES) <= exported
     assert L.oly_strerror(_abi.OLY_EINVAL) == b"invalid argument"
     assert b"gfx950" in L.oly_version()
+    # the ABI version of the header, the library and the binding table agree (a mismatch makes lib() refuse to load)
+    hdr = int(re.search(r"#define OLY_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "olympic_hip.h")).read()).group(1))
+    assert hdr == _abi.ABI_VERSION == int(L.oly_abi_version())
 
 
 def test_struct_layouts_match_the_header():

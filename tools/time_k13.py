@@ -57,8 +57,11 @@ def main():
     variants = [(0, "everything", None), (1, "no_mfma_layers", None), (2, "no_environment_step", None), (3, "neither", None)]
     if "--stamps" in sys.argv:    # bit 3: per-interval work / barrier-wait times of workgroup 0 (s_memtime)
         variants = [(8, "everything", None), (10, "no_environment_step", None), (9, "no_mfma_layers", None)]
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    diag_lib = graft.build(diag=True)          # -DOLY_DIAG: the shipped library does not read OLY_K13_SKIP
     for skip, label, _ in variants:
-        env = dict(os.environ, OLY_K13_SKIP=str(skip))
+        env = dict(os.environ, OLY_K13_SKIP=str(skip), OLYMPIC_HIP_LIB=diag_lib)
         r = subprocess.run([sys.executable, "-c", CHILD, str(N), str(T)], env=env, capture_output=True, text=True)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         out[label] = json.loads(line[-1]) if line else {"error": r.stderr[-300:]}
