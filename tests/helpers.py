@@ -298,7 +298,9 @@ def check_persistent_rollout_against_oracle(eng, orc, N=70, T=12, max_len=5, K=5
     launch = eng.a3_vec_prepare(d_blocks, d_state, d_ro)
     pa, pc = eng.mlp_pack(*[d(a) for a in wa], d(mean), d(std)), eng.mlp_pack(*[d(a) for a in wc])
     launch(_abi.VSTEP_RESET_ALL)
-    launch.persistent(pa, normalize, pc, False)                  # the whole rollout: ONE launch
+    mu_out = torch.zeros((N, nu), dtype=torch.float32, device="cuda")
+    value_out = torch.zeros(N, dtype=torch.float32, device="cuda")
+    launch.persistent(pa, normalize, pc, False, mu_out, value_out)     # the whole rollout: ONE launch
     torch.cuda.synchronize()
     h = lambda t_: t_.cpu().numpy()
     got = {k: h(v) for k, v in d_ro.items() if torch.is_tensor(v)}
@@ -317,7 +319,7 @@ def check_persistent_rollout_against_oracle(eng, orc, N=70, T=12, max_len=5, K=5
         assert np.array_equal(got["buf_actions"][t], ro["buf_actions"][t]), ("action", t)
         assert np.array_equal(got["buf_flags"][t], ro["buf_flags"][t]), ("flags", t)
         np.testing.assert_allclose(got["buf_rewards"][t], ro["buf_rewards"][t], rtol=1e-11, atol=1e-13)
-    assert np.array_equal(got["mu"], ro["mu"]) and np.array_equal(got["value"], ro["value"])     # the last forward
+    assert np.array_equal(h(mu_out), ro["mu"]) and np.array_equal(h(value_out), ro["value"])     # the last step's forward
     assert np.array_equal(got["pd_target"], ro["pd_target"])
     for k in ("traj_len", "side_count", "side_t", "pool_count"):
         assert np.array_equal(got[k], ro[k]), k

@@ -342,12 +342,14 @@ def test_discriminator_reward_follows_writes_through_dot_data(golden):
     ref, _, _ = dr.logits_unfused(x, eps)                        # torch GEMMs on the CURRENT parameters
     np.testing.assert_allclose(host(after), host(ref), rtol=2e-4, atol=2e-4)
     dr.cache_packed = True                                       # the opt-in cache: explicit invalidation
-    dr.forward(x, eps, want=("logits",))
+    p1 = dr.packed().clone()
     net.decoder.weight.data.mul_(0.5)
-    stale = dr.forward(x, eps, want=("logits",))["logits"].clone()
+    assert torch.equal(dr.packed(), p1)                          # the documented hazard of the cache
     dr.invalidate()
-    fresh = dr.forward(x, eps, want=("logits",))["logits"]
-    assert torch.equal(stale, after) and not torch.equal(fresh, stale)
+    assert not torch.equal(dr.packed(), p1)
+    dr.cache_packed = False
+    net.decoder.weight.data.mul_(3.0)
+    assert not torch.equal(dr.packed().clone(), p1)
 
 
 def test_gail_fit_reward_and_advantage_pipeline(golden, oracle):
