@@ -433,9 +433,35 @@ def _k10_bytes_per_env_step(spec, C):
     return rd + wr
 
 
-def cpu_baseline_config3(seconds=8.0):
-    """The oracle's restatement of one sampling step (oly_mlp_forward_cpu for actor and critic, then
-    oly_a3_vec_step_cpu) on a bounded sample: 256 environments, repeated for ~`seconds`, one thread."""
+def _cpu_rate_all_cores(make_job, seconds, cores=None):
+    """Units per second of `cores` host threads, each looping its OWN job (a closure over its own slice of the workload
+    that returns the units of one pass) until the deadline.  The oracle's C functions are single-threaded; ctypes
+    releases the GIL around them, so Python threads do run them side by side.  -> (rate, cores)."""
+    import threading
+    from oracle import oracle as orc
+    # the GPU box hands one GPU's job a CPU share of 16 cores (more threads only time-slice them; 128 OpenMP threads
+    # run config 2's port ~10x faster than one): 32 threads cover the share with room for stalls
+    cores = int(cores or min(orc.max_threads(), 32))
+    jobs = [make_job(i, cores) for i in range(cores)]
+    for j in jobs[:1]:
+        j()                                     # warm (page in the oracle, first-touch the arrays)
+    done = [0] * cores
+    t0 = time.perf_counter()
+    deadline = t0 + seconds
+
+    def run(i):
+        while time.perf_counter() < deadline:
+            done[i] += jobs[i]()
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(cores)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    return sum(done) / (time.perf_counter() - t0), cores
+
+
+def _config3_cpu_job(N, seed=0):
+    """One sampling step of N environments through the oracle: oly_mlp_forward_cpu (actor, critic) + oly_a3_vec_step_cpu."""
     import numpy as np
     from oracle import oracle as orc
     from olympic_hip import _abi, specs
@@ -445,9 +471,9 @@ def cpu_baseline_config3(seconds=8.0):
     spec = specs.A3Spec(mass=41.5)
     lut = clock_lut(spec.swing_duration, spec.stance_duration, 0.1, "grounded", 1 / spec.control_dt, spec.period)
     contact = (A3_GEOM_BODYID, A3_FLOOR_BODY, A3_RFOOT_BODY, A3_LFOOT_BODY)
-    N, K, T, nobs, nu, depth = 256, 8, 1 << 20, spec.n_obs, spec.nu, 4
-    rng = np.random.default_rng(0)
-    blocks = a3_synthetic_blocks(N, K, seed=1)
+    K, T, nobs, nu, depth = 8, 1 << 20, spec.n_obs, spec.nu, 4
+    rng = np.random.default_rng(seed)
+    blocks = a3_synthetic_blocks(N, K, seed=1 + seed)
     z = lambda dt, *sh: np.zeros((N,) + sh, dt)
     state = dict(phase=z(np.int32), t1=z(np.int32), t2=z(np.int32), reached_frames=z(np.int32), target_reached=z(np.uint8),
                  mode=np.full(N, _abi.MODE_STANDING, np.int32), seq_len=np.ones(N, np.int32),
@@ -459,25 +485,36 @@ def cpu_baseline_config3(seconds=8.0):
               buf_actions=np.zeros((Tb, N, nu), np.float32), buf_rewards=np.zeros((Tb, N)),
               buf_values=np.zeros((Tb, N), np.float32), buf_flags=np.zeros((Tb, N), np.uint8), buf_rew6=None,
               traj_len=z(np.int32), side_obs=np.zeros((N * 4, nobs), np.float32), side_t=np.full(N * 4, -1, np.int32),
-              side_count=z(np.int32), pool=draw_reset_records(np.random.RandomState(0), N * depth, spec, 5000)
+              side_count=z(np.int32), pool=draw_reset_records(np.random.RandomState(seed), N * depth, spec, 5000)
               .view(np.uint8).reshape(-1).copy(), pool_count=z(np.int32), ctr=np.zeros(2, np.int32))
     wa = [rng.normal(0, 0.1, sh).astype(np.float32) for sh in ((256, nobs), (256,), (256, 256), (256,), (nu, 256), (nu,))]
     wc = [rng.normal(0, 0.1, sh).astype(np.float32) for sh in ((256, nobs), (256,), (256, 256), (256,), (1, 256), (1,))]
     orc.a3_vec_step(spec, lut, contact, blocks, state, ro, _abi.VSTEP_RESET_ALL)
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < seconds:
+
+    def job():
         ro["mu"][:] = orc.mlp_forward(ro["state"], *wa)
         ro["value"][:] = orc.mlp_forward(ro["state"], *wc)[:, 0]
         orc.a3_vec_step(spec, lut, contact, blocks, state, ro, 0)
-        steps += 1
         if ro["ctr"][0] >= Tb:
             ro["ctr"][0] = 0
             ro["side_count"][:] = 0
-    dt = time.perf_counter() - t0
-    return {"value": steps * N / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"oracle actor + critic forward (oly_mlp_forward_cpu) + oly_a3_vec_step_cpu on {N} environments, "
-                      f"{steps} vec steps in {dt:.1f} s, 1 thread"}
+        return N
+    return job
+
+
+PORT_NOTE = ("the port evaluates every layer as scalar k-ordered fma chains (the matrix cores' exact order, kept for "
+             "bit-exact parity); a BLAS forward, which is what the reference's torch CPU path runs, would be several "
+             "times faster per core")
+
+
+def cpu_baseline_config3(seconds=9.0, N=4096):
+    """The oracle's restatement of one sampling step (oly_mlp_forward_cpu for actor and critic, then
+    oly_a3_vec_step_cpu) on N environments split over all host threads, and on one thread."""
+    rate, cores = _cpu_rate_all_cores(lambda i, c: _config3_cpu_job(max(16, N // c), seed=i), seconds * 0.65)
+    one, _ = _cpu_rate_all_cores(lambda i, c: _config3_cpu_job(256, seed=0), seconds * 0.35, cores=1)
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1thread": one,
+            "sample": f"oracle actor + critic forward (oly_mlp_forward_cpu) + oly_a3_vec_step_cpu on {max(16, N // cores) * cores} "
+                      f"environments split over {cores} threads for ~{seconds * 0.65:.0f} s (1 thread: 256 environments); " + PORT_NOTE}
 
 
 def _update_flop_per_row(n_in, n_act, mirror):
@@ -640,28 +677,41 @@ def disc_flop_per_sample(D=32):
     return 2 * (D * 256 + 256 * 128 + 2 * 128 * 128 + 128)
 
 
-def cpu_baseline_config4(weights, seconds=8.0):
+def _config4_cpu_job(weights, B, seed, pipeline=True):
+    """make_discrim_reward -> compute_gae(0.99, 0.97) -> biased-std normalisation on B samples (one [1, B] block)."""
     import numpy as np
     from oracle import oracle as orc
-    rng = np.random.default_rng(4)
-    B = 1024
+    from olympic_hip import _abi
+    rng = np.random.default_rng(seed)
     x = rng.normal(0, 1, (B, 32)).astype(np.float32)
     eps = rng.normal(0, 1, (B, 128)).astype(np.float32)
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < seconds:
+    v, nv = (rng.normal(0, 1, (1, B)).astype(np.float32) for _ in range(2))
+    fl = ((rng.uniform(size=(1, B)) < 0.01) * (_abi.FLAG_LAST | _abi.FLAG_ABSORBING)).astype(np.uint8)
+
+    def job():
         cs = orc.col_stats(x)
-        orc.disc_forward(x, weights, colstats=cs, eps=eps)
-        reps += 1
-    dt = time.perf_counter() - t0
-    return {"value": reps * B / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"oracle column statistics + oly_disc_forward_cpu on {B} samples, {reps} passes in {dt:.1f} s, 1 thread"}
+        r = orc.disc_forward(x, weights, colstats=cs, eps=eps)["reward"]
+        if pipeline:
+            _, adv = orc.return_scan(_abi.SCAN_GAE, 0.99, 0.97, r.reshape(1, B), v, nv, fl)
+            orc.adv_normalize(adv, orc.adv_stats(adv), 0, 1e-8)
+        return B
+    return job
+
+
+def cpu_baseline_config4(weights, seconds=9.0, B=4096):
+    rate, cores = _cpu_rate_all_cores(lambda i, c: _config4_cpu_job(weights, max(32, B // c), i), seconds * 0.65)
+    one, _ = _cpu_rate_all_cores(lambda i, c: _config4_cpu_job(weights, 1024, 0), seconds * 0.35, cores=1)
+    return {"value": rate, "unit": "samples/s", "cores": cores, "kind": "port", "value_1thread": one,
+            "sample": f"oracle column statistics + oly_disc_forward_cpu + GAE(0.97) scan + biased-std normalisation on "
+                      f"{max(32, B // cores) * cores} samples split over {cores} threads for ~{seconds * 0.65:.0f} s (1 thread: 1024 "
+                      "samples); " + PORT_NOTE}
 
 
 def config4_block(rk, args):
     """BASELINE config 4: the VAIL discriminator reward (imitation_lib/imitation/gail_TRPO.py:320-327 ->
     VariationalNet.forward, utils/networks.py:258-284) for B = 4096 samples and for a [400,4096] block:
-    oly_col_stats (the Standardizer's running update) + oly_disc_forward (K12, one launch on the f32 matrix cores)."""
+    oly_col_stats (the Standardizer's running update) + oly_disc_forward (K12, one launch on the f32 matrix cores),
+    and the whole reward -> GAE(0.97) -> normalisation pipeline of GAIL.fit (gail_TRPO.py:116-129)."""
     import numpy as np
     import torch
     from olympic_hip.engine import Engine
@@ -699,7 +749,48 @@ def config4_block(rk, args):
                          "unit": "TFLOP/s", "frac": fl / (ms_k12 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": src, "kernel": "disc_forward_kernel<4>", "alg_flop_per_sample": disc_flop_per_sample(),
                          "hbm_bytes_per_sample": 4 * (32 + 128 + 1)}}
-        del x, eps, bufs
+        # the pipeline SURVEY 8(d) names for this config: reward -> compute_gae(gamma .99, lambda .97) -> advantage
+        # normalisation (ddof 0, 1e-8)  (gail_TRPO.py:116-129): one [T, N] block, critic values given
+        from olympic_hip import _abi
+        from olympic_hip.rollout import GAERollout, RolloutBuffer
+        T = B // args.N
+        buf = RolloutBuffer(T, args.N, 32, 1, dev)
+        buf.values.normal_(0, 1, generator=g)
+        buf.next_values.normal_(0, 1, generator=g)
+        buf.flags.copy_(((torch.rand((T, args.N), device=dev, generator=g) < 0.01) * (_abi.FLAG_LAST | _abi.FLAG_ABSORBING)).to(torch.uint8))
+        buf.ptr = T
+        post = GAERollout(eng, gamma=0.99, lam=0.97)
+        rew_out = dict(reward=buf.rewards.view(-1))
+
+        rstep = dr.prepared(x, eps, out=rew_out)          # arguments validated once (the per-call checks cost ~20 us of host time)
+
+        def pipeline():
+            rstep()                                        # re-pack + Standardizer update + K12, reward straight into the block
+            post.finish(buf, normalize=True)               # GAE scan with fused statistics, normalise (ddof 0)
+        ms_pipe = event_ms(stream, reps, pipeline)
+        ms_rew = event_ms(stream, reps, rstep, wake_s=0.0)
+        dr.cache_packed = True                             # a frozen network: no re-pack launch in front of the statistics
+        rstep_frozen = dr.prepared(x, eps, out=rew_out)
+        ms_rew_frozen = event_ms(stream, reps, rstep_frozen, wake_s=0.0)
+        dr.cache_packed = False
+        ms_gae = event_ms(stream, reps, lambda: post.finish(buf, normalize=False), wake_s=0.0)
+        ms_full = event_ms(stream, reps, lambda: post.finish(buf, normalize=True), wake_s=0.0)
+        parts3 = post._stats.reshape(1, 3)
+        ms_norm = event_ms(stream, reps, lambda: eng.adv_normalize(buf.advantages, parts3, 0, 1e-8), wake_s=0.0)
+        scan_bytes = (21 + 8) * B                          # GAE scan 21 B / element, normalise 8 B / element
+        out["shapes"][label]["pipeline"] = {
+            "stages": "Standardizer update + K12 reward | K6 GAE(0.99, 0.97) + statistics | K7 normalise (ddof 0, 1e-8)",
+            "us": 1e3 * ms_pipe, "samples_per_s": B / (ms_pipe * 1e-3),
+            "stages_us": {"reward_step": 1e3 * ms_rew, "reward_step_frozen_weights": 1e3 * ms_rew_frozen,
+                          "gae_scan_with_statistics": 1e3 * ms_gae,
+                          "normalise": 1e3 * ms_norm},
+            "launches": 4 + 2 + 1,
+            "note": "reward_step = ONE C call: re-pack of the live weights (so a reward never uses weights an optimiser step or "
+                    "a broadcast has replaced), two statistics launches, K12; *_frozen_weights skips the re-pack",
+            "roofline_scan_and_normalise": {"bound": "hbm", "achieved": scan_bytes / (ms_full * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": scan_bytes / (ms_full * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "traffic": None, "alg_bytes_per_sample": 29}}
+        del x, eps, bufs, buf
     out["value"] = out["shapes"]["T400xN4096"]["samples_per_s"]
     out["round1_layer_by_layer_us_at_B4096"] = 249.0
     if not args.no_cpu_baseline:
@@ -842,23 +933,28 @@ def bench_config2(args, rk):
 
 
 # ------------------------------------------------------------------------------------ config 5
-def cpu_baseline_config5(T, N, seconds=10.0):
+def _config5_cpu_job(T, N, seed):
     import numpy as np
     from oracle import oracle as orc
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + seed)
     r = rng.uniform(-0.3, 1.0, (T, N))
     v, nv = (rng.normal(0, 1, (T, N)).astype(np.float32) for _ in range(2))
     fl = ((rng.uniform(size=(T, N)) < 1 / 300) * 2).astype(np.uint8)
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < seconds:
+
+    def job():
         _, adv = orc.return_scan_r64(0.99, r, v, nv, fl)
         orc.adv_normalize(adv, orc.adv_stats(adv), 1, 1e-5)
-        reps += 1
-    dt = time.perf_counter() - t0
-    return {"value": reps * T * N / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"oracle return scan (f64 rewards) + statistics + normalisation on one [T={T},N={N}] shard, "
-                      f"1 thread, repeated for ~{seconds:.0f} s"}
+        return T * N
+    return job
+
+
+def cpu_baseline_config5(T, N, seconds=9.0):
+    rate, cores = _cpu_rate_all_cores(lambda i, c: _config5_cpu_job(T, max(8, N // c), i), seconds * 0.65)
+    one, _ = _cpu_rate_all_cores(lambda i, c: _config5_cpu_job(T, N, 0), seconds * 0.35, cores=1)
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1thread": one,
+            "sample": f"oracle return scan (f64 rewards) + statistics + normalisation on one [T={T},N={N}] shard, its "
+                      f"environments split over {cores} threads (each normalises its own slice: an upper bound of a "
+                      f"shared-statistics run), ~{seconds * 0.65:.0f} s; 1 thread: the whole shard"}
 
 
 def measure_config5_tail(rk, eng, T, N, steps, warmup):

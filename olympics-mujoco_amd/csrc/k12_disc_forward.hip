@@ -593,3 +593,23 @@ extern "C" int oly_disc_forward(oly_ctx* ctx, int64_t B, int Dx, int D, const fl
   OLY_LAUNCH_CHECK(ctx, "disc_forward_kernel");
   return OLY_OK;
 }
+
+// make_discrim_reward's whole device path in ONE call: (optionally) the re-pack of the current weights, then
+// Standardizer.update_mean_std on the batch (networks.py:70,76-81: the running sums take the batch in BEFORE it is
+// standardised) and the fused forward on those statistics: four launches issued from C (from Python the separate
+// ctypes calls cost more host time than the kernels take at B = 4096).
+extern "C" int oly_disc_reward_step(oly_ctx* ctx, int64_t B, int D, const float* x, double* colstats, int accumulate,
+                                    const float* const* weights, float* packed, const float* eps, float* reward,
+                                    float* logits, float* mu, float* logvar, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (B < 0 || B > 0x7fffffffL || !colstats || !packed) OLY_FAIL(ctx, OLY_EINVAL, "oly_disc_reward_step: bad B or NULL colstats / packed");
+  int rc;
+  if (weights) {
+    rc = oly_disc_pack(ctx, D, H1, H2, ZD, weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
+                       weights[7], weights[8], weights[9], packed, stream);
+    if (rc != OLY_OK) return rc;
+  }
+  rc = oly_col_stats(ctx, (int)B, D, x, colstats, accumulate, stream);
+  if (rc != OLY_OK) return rc;
+  return oly_disc_forward(ctx, B, D, D, x, nullptr, nullptr, nullptr, colstats, packed, eps, reward, logits, mu, logvar, stream);
+}

@@ -211,6 +211,7 @@ SIGNATURES = {
     "oly_disc_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "oly_disc_pack": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 12),
     "oly_disc_forward": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int] + [vp] * 12),
+    "oly_disc_reward_step": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int] + [vp] * 8),
     "oly_grf_configure": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     "oly_il_ground_forces": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "oly_rollout_cuts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

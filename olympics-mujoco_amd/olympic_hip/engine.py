@@ -749,6 +749,57 @@ class Engine:
                       ptr(packed), ptr(eps), g("reward"), g("logits"), g("mu"), g("logvar"), self._s())
         return out
 
+    def disc_reward_step(self, x, packed, colstats, accumulate, eps=None, want=("reward",), out=None, weights=None):
+        """oly_disc_reward_step: (re-pack of `weights`, the ten parameter tensors in oly_disc_pack's order, when given,)
+        the Standardizer's running update with x (into colstats [3,D] f64, accumulate: added to the running sums) and
+        the fused forward on the updated statistics, one C call.  x [B,D] f32, whole rows.  accumulate=None: validate
+        now and return `launch(accumulate)` for repeated calls on the same tensors."""
+        from ._ffi import lib
+        f32, dv = torch.float32, self.device
+        B, D = (int(v) for v in x.shape)
+        _req(x, "x", (B, D), f32, dv)
+        _req(colstats, "colstats", (3, D), torch.float64, dv)
+        cache = self.__dict__.setdefault("_disc_sizes", {})
+        if D not in cache:
+            cache[D] = int(lib().oly_disc_packed_floats(D, 256, 128, 128))
+        _req(packed, "packed", (cache[D],), f32, dv)
+        _req(eps, "eps", (B, 128), f32, dv, optional=True)
+        wp = None
+        if weights is not None:
+            shapes_w = ((256, D), (256,), (128, 256), (128,), (128, 128), (128,), (128, 128), (128,), (1, 128), (1,))
+            if len(weights) != 10:
+                raise OlyError("disc_reward_step: weights = the ten tensors of disc_pack")
+            for i, (t, sh) in enumerate(zip(weights, shapes_w)):
+                _req(t, f"weights[{i}]", sh, f32, dv)
+            wp = (C.c_void_p * 10)(*[t.data_ptr() for t in weights])
+        shapes = dict(reward=(B,), logits=(B,), mu=(B, 128), logvar=(B, 128))
+        out = dict(out or {})
+        if not want:
+            raise OlyError("disc_reward_step: no output requested")
+        for k in want:
+            if k not in shapes:
+                raise OlyError(f"disc_reward_step: unknown output {k!r}")
+            out[k] = _req(out.get(k) if out.get(k) is not None else self._new(shapes[k], f32), k, shapes[k], f32, dv)
+        g = lambda k: ptr(out[k]) if k in want else None
+        if accumulate is None:
+            # validated once: `launch(accumulate)` re-issues the same call on the current stream with no per-call checks
+            # (at B = 4096 the kernels take ~20 us; the checks above cost the host more than that)
+            from ._ffi import check
+            fn, h = lib().oly_disc_reward_step, self.ctx.handle
+            args = (C.c_int64(B), D, ptr(x), ptr(colstats))
+            tail = (wp, ptr(packed), ptr(eps), g("reward"), g("logits"), g("mu"), g("logvar"))
+            keep = (x, colstats, packed, eps, weights, out)
+
+            def launch(acc):
+                rc = fn(h, *args, 1 if acc else 0, *tail, self._s())
+                if rc:
+                    check(h, rc, "oly_disc_reward_step")
+                return keep[-1]
+            return launch
+        self.ctx.call("oly_disc_reward_step", C.c_int64(B), D, ptr(x), ptr(colstats), int(bool(accumulate)), wp, ptr(packed),
+                      ptr(eps), g("reward"), g("logits"), g("mu"), g("logvar"), self._s())
+        return out
+
     # -------------------------------------------------------------- K9
     def signed_perm(self, x, src, sign, out=None):
         B, D = int(x.shape[0]), int(x.shape[1])

@@ -352,6 +352,52 @@ def test_discriminator_reward_follows_writes_through_dot_data(golden):
     assert not torch.equal(dr.packed().clone(), p1)
 
 
+@pytest.mark.parametrize("T,N", [(1, 4096), (5, 4096)])
+def test_config4_three_stage_pipeline_against_the_oracle(golden, oracle, T, N):
+    """BASELINE config 4 as SURVEY 8(d) states it, B = N = 4096: Standardizer update + VAIL reward (one C call:
+    oly_disc_reward_step) -> compute_gae(0.99, 0.97) -> (adv - mean) / (biased std + 1e-8)  (gail_TRPO.py:116-129),
+    every stage against the oracle: reward / logits bit-exact, GAE targets and raw advantages bit-exact, statistics 1e-12,
+    normalised advantages one float32 ulp.  Two batches in a row: the second accumulates onto the running statistics."""
+    from olympic_hip.engine import Engine
+    from olympic_hip.gail import DiscriminatorReward, VariationalDiscriminator
+    from olympic_hip.rollout import GAERollout, RolloutBuffer
+    g = golden("vail_disc.npz")
+    eng = Engine(0)
+    net = VariationalDiscriminator().load_reference_arrays(g).cuda()
+    w = {k: np.asarray(g[k]) for k in ("enc_w0", "enc_b0", "enc_w1", "enc_b1", "mu_w", "mu_b", "lv_w", "lv_b", "dec_w", "dec_b")}
+    dr = DiscriminatorReward(eng, net, state_mask=np.arange(32))
+    post = GAERollout(eng, gamma=0.99, lam=0.97)
+    gen = torch.Generator(device="cuda").manual_seed(T)
+    B = T * N
+    cs_ref = None
+    for batch in range(2):
+        x = torch.empty((B, 32), device="cuda").normal_(0.3 * batch, 1 + batch, generator=gen)
+        eps = torch.empty((B, 128), device="cuda").normal_(0, 1, generator=gen)
+        buf = RolloutBuffer(T, N, 32, 1, "cuda")
+        buf.values.normal_(0, 1, generator=gen)
+        buf.next_values.normal_(0, 1, generator=gen)
+        last = torch.rand((T, N), device="cuda", generator=gen) < 0.1
+        absorbing = last & (torch.rand((T, N), device="cuda", generator=gen) < 0.5)
+        buf.flags.copy_((last.to(torch.uint8) * _abi.FLAG_LAST) | (absorbing.to(torch.uint8) * _abi.FLAG_ABSORBING))
+        buf.ptr = T
+        o = dr.forward(x, eps, want=("reward", "logits"), out=dict(reward=buf.rewards.view(-1)))
+        # stage 1 against the oracle: running column statistics, then the fused forward on them
+        cs = oracle.col_stats(host(x))
+        cs_ref = cs if cs_ref is None else cs_ref + cs
+        np.testing.assert_allclose(host(dr.stand.colstats), cs_ref, rtol=1e-12)
+        e = oracle.disc_forward(host(x), w, colstats=host(dr.stand.colstats), eps=host(eps))
+        assert np.array_equal(host(o["logits"]), e["logits"]) and np.array_equal(host(buf.rewards).reshape(-1), e["reward"])
+        # stages 2 + 3
+        v_target, adv = post.finish(buf, normalize=True)
+        e_ret, e_adv = oracle.return_scan(_abi.SCAN_GAE, 0.99, 0.97, host(buf.rewards), host(buf.values), host(buf.next_values),
+                                          host(buf.flags))
+        assert np.array_equal(host(v_target), e_ret)
+        st = oracle.adv_stats(e_adv)
+        np.testing.assert_allclose(host(post._stats), st, rtol=1e-12)
+        e_norm = oracle.adv_normalize(e_adv, st, 0, 1e-8)
+        assert np.abs(host(adv) - e_norm).max() <= np.spacing(np.float32(1.0)) * max(1.0, np.abs(e_norm).max())
+
+
 def test_gail_fit_reward_and_advantage_pipeline(golden, oracle):
     """Config 4 at N = 4096: discriminator reward -> GAE(0.97) -> biased-std normalisation."""
     from olympic_hip.engine import Engine

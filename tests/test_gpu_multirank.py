@@ -99,6 +99,29 @@ def test_bench_starts_its_own_ranks(config):
         assert "configs" not in line and "per_step" not in line
 
 
+@pytest.mark.parametrize("config", [2, 5])
+def test_bench_six_ranks_in_the_drivers_command_shape(config):
+    """The driver's multi-GPU command shape with as many ranks as one box may put on its GPU (six processes; the
+    8-rank all-gather / tree sum itself runs on the CPU in test_host_cpu.py::test_adv_stats_allgather_two_ranks_gloo[8]):
+    `bench.py --gpus 6` starts six ranks, the process group sees six, the ONE all-gather returns six triples, the
+    default command's line carries config5_tail."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--backend", "gloo",
+                          "--share-device", "--config", str(config), "--steps", "3", "--warmup", "1",
+                          "--T", "50", "--N", "1024", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 6 and line["scaling"] == "weak" and line["value"] > 0
+    tail = line if config == 5 else line["config5_tail"]
+    assert "error" not in tail, tail
+    if config == 5:
+        assert line["config"]["ranks_seen"] == 6
+    else:
+        assert tail["ranks_seen"] == 6 and tail["gathered_rows"] == 6 and tail["backend"] == "gloo"
+    assert set(tail["stages_ms"]) >= {"scan_with_fused_stats", "all_gather_host_wall", "normalise"}
+
+
 def test_bench_launcher_ends_when_a_rank_dies_before_the_rendezvous():
     """Rank 1 exits before init_process_group; rank 0 is then blocked in the rendezvous.  The launcher polls all its
     children, ends the survivors and fails, instead of waiting on rank 0 forever."""
@@ -132,6 +155,15 @@ def test_bench_default_line_carries_every_baseline_config():
         assert r["bound"] == bound and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c4 = c["config4_vail_reward"]
     assert c4["shapes"]["T400xN4096"]["roofline"]["frac"] > 0.3 and c4["shapes"]["B4096"]["disc_forward_us"] < 40
+    # round 4: a WHOLE config-3 iteration (sampling + kernel update) and config 4's three-stage pipeline in the line
+    it = c3["iteration"]
+    assert "error" not in it and it["with_mirror_loss"]["losses_finite"] and it["without_mirror_loss"]["losses_finite"]
+    assert it["with_mirror_loss"]["env_steps_per_s"] > 5e6 and it["with_mirror_loss"]["updates"] == 75
+    kr = it["kernels"]["without_mirror_loss"]["minibatch_65536"]
+    assert kr["roofline"]["bound"] == "mfma" and 0.2 < kr["roofline"]["frac"] < 1 and kr["update_ms"] < 1.5
+    assert it["kernels"]["without_mirror_loss"]["minibatch_64"]["update_ms"] < 0.6     # the torch graph replay took 0.60
+    pipe = c4["shapes"]["B4096"]["pipeline"]
+    assert set(pipe["stages_us"]) >= {"reward_step", "gae_scan_with_statistics", "normalise"} and pipe["us"] < 200
     assert set(c["config5_tail_world1"]["stages_ms"]) >= {"scan_with_fused_stats", "normalise"}
     assert line["per_step"]["config3_a3_ppo_sampling"] == c3["sampling"]
 

@@ -259,34 +259,41 @@ def test_shard_range():
     assert [b - a for a, b in parts] == [3, 3, 2, 2] and parts[-1][1] == 10
 
 
-def test_adv_stats_allgather_two_ranks_gloo(tmp_path):
-    """world_size 2 over gloo: each rank reduces its env shard to (count, sum, sumsq), ONE
-    all-gather, both ranks normalise with the same global statistics = the single-process
-    result (PPO ddof 1 / 1e-5 and GAIL ddof 0 / 1e-8)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_adv_stats_allgather_two_ranks_gloo(tmp_path, world):
+    """world_size 2 and 8 (the driver's 8-GPU shape) over gloo: each rank reduces its env shard to (count, sum, sumsq),
+    ONE all-gather of one triple per rank, every rank normalises with the same global statistics = the single-process
+    result (PPO ddof 1 / 1e-5 and GAIL ddof 0 / 1e-8); the eight near-equal shards of 1001 environments tile them."""
     script = os.path.join(ROOT, "tests", "_dist_worker.py")
     import socket
     with socket.socket() as sk:                      # a port that is free right now
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(tmp_path)],
-                         capture_output=True, text=True, timeout=300)
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert out.returncode == 0, out.stdout + out.stderr
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert np.array_equal(r0["total"], r1["total"])                      # identical on every rank
+    rs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    r0 = rs[0]
+    for r in rs[1:]:
+        assert np.array_equal(r0["total"], r["total"]) and np.array_equal(r0["parts"], r["parts"])   # identical on every rank
+    assert r0["parts"].shape == (world, 3) and r0["parts"][:, 0].sum() == r0["total"][0]              # one triple per rank
     adv = np.load(tmp_path / "full.npy")
     for ddof, eps, key in ((1, 1e-5, "ppo"), (0, 1e-8, "gail")):
         ref = (adv - adv.mean()) / (adv.std(ddof=ddof) + eps)
-        got = np.concatenate([r0[key], r1[key]], axis=1)
+        got = np.concatenate([r[key] for r in rs], axis=1)
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
     assert r0["total"][0] == adv.size
     # replicated learner: identical weights after the broadcast, gradients = mean over ranks
-    assert np.array_equal(r0["w_after_broadcast"], r1["w_after_broadcast"])
+    for r in rs[1:]:
+        assert np.array_equal(r0["w_after_broadcast"], r["w_after_broadcast"])
     torch.manual_seed(100)
     net0 = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 2))
     assert np.array_equal(r0["w_after_broadcast"], torch.cat([p.detach().reshape(-1) for p in net0.parameters()]).numpy())
-    want = np.concatenate([np.full(n, 1.5 * (i + 1), np.float32) for i, n in enumerate((35, 7, 14, 2))])
-    assert np.array_equal(r0["g_after_allreduce"], want) and np.array_equal(r1["g_after_allreduce"], want)
+    mean_rank = (world + 1) / 2.0
+    want = np.concatenate([np.full(n, mean_rank * (i + 1), np.float32) for i, n in enumerate((35, 7, 14, 2))])
+    for r in rs:
+        np.testing.assert_allclose(r["g_after_allreduce"], want, rtol=1e-6)
 
 
 # ------------------------------------------------------------------------------ A3 host side
