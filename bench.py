@@ -336,10 +336,92 @@ def per_step_block(rk, eng, spec, N):
     out["h1_graph_of_10_steps"] = {"us_per_vec_step": us10, "env_steps_per_s": N / (us10 * 1e-6),
                                    "launches_per_step": 1, "note": "ten consecutive vec steps per graph replay"}
     try:
-        out["h1_through_the_host_batcher"] = h1_host_batcher(eng, spec, N, qpos_h, qvel_h, act)
+        hb = h1_host_batcher(eng, spec, N, qpos_h, qvel_h, act)
+        up, down = N * 8 * (spec.nq + spec.nv), N * 8 * spec.nu
+        pc = pcie_bandwidth(rk.dev, sizes=((64 << 20, "64MB"), (up, "state_rows"), (down, "controls")))
+        # the path's roofline: the larger of the two directions at this box's measured pinned streaming rate (PCIe is full
+        # duplex: a perfectly pipelined step would hide the other direction and the physics behind it) + nothing else
+        floor_us = 1e6 * max(up / (pc["h2d_64MB"]["GBps"] * 1e9), down / (pc["d2h_64MB"]["GBps"] * 1e9))
+        hb["roofline"] = {"bound": "pcie", "achieved": (up + down) / (hb["us_per_vec_step"] * 1e-6) / 1e9,
+                          "peak": pc["h2d_64MB"]["GBps"], "unit": "GB/s (pinned H2D, 64 MB blocks, measured in this run)",
+                          "frac": floor_us / hb["us_per_vec_step"], "traffic": None, "floor_us_per_vec_step": floor_us,
+                          "measured_copies": pc,
+                          "note": "frac = (time of the larger direction at the streaming rate) / (measured step): what chunked, "
+                                  "double-buffered staging could approach; a copy of the step's own size costs the wall "
+                                  "clock under measured_copies (latency-bound)"}
+        out["h1_through_the_host_batcher"] = hb
     except Exception as e:                                   # never take the headline line down
         out["h1_through_the_host_batcher"] = {"error": repr(e)[:200]}
+    try:
+        out["a3_through_the_host_batcher"] = a3_host_batcher(eng, N)
+    except Exception as e:
+        out["a3_through_the_host_batcher"] = {"error": repr(e)[:200]}
     return out
+
+
+def pcie_bandwidth(dev, sizes=((64 << 20, "large"),)):
+    """Measured pinned-memory copy rates of this box, the roofline of every path that has host memory in the loop:
+    H2D and D2H of a 64 MB block (streaming rate) and of the per-step sizes (latency included), wall clock per copy."""
+    import torch
+    out = {}
+    for nbytes, label in sizes:
+        h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        for name, src, dst in (("h2d", h, d), ("d2h", d, h)):
+            for _ in range(3):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            reps = 20 if nbytes >= (8 << 20) else 200
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / reps
+            out[f"{name}_{label}"] = {"bytes": nbytes, "us": 1e6 * dt, "GBps": nbytes / dt / 1e9}
+    return out
+
+
+def a3_host_batcher(eng, N, reps=200):
+    """The RL robot's batcher (compact staging): PD targets to the host, the physics stand-in on the worker threads, the
+    compact readback (base quaternion / angular velocity, actuator and site rows, the USED contact slots) up, K3 (CSR
+    form) + K2.  PCIe included; never `value`."""
+    import numpy as np
+    import torch
+    from olympic_hip import specs
+    from olympic_hip.batcher import A3HostBatcher
+    a3 = specs.A3Spec(mass=41.5)
+    eng.a3_configure(a3, np.zeros((4, a3.period)))
+    eng.contact_configure(np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 10], np.int32), 0, 7, 10)
+    b = A3HostBatcher(eng, N, 16, None, n_threads=min(16, os.cpu_count() or 1)).set_mapped(1).set_compact(1)
+    try:
+        rng = np.random.default_rng(0)
+        nc_all = np.minimum(rng.poisson(4, N), 16)                 # config 3: ncon ~ Poisson(4) clipped to the slots
+        for e in range(N):
+            sl = b.slots(e)
+            sl["root_quat"][:] = [1, 0, 0, 0]
+            k_ = int(nc_all[e])
+            sl["ncon"][0] = k_
+            sl["geom2"][:k_] = 7 + 3 * (np.arange(k_) % 2)
+            sl["force6"][:k_] = rng.normal(0, 100, (k_, 6))
+        z = lambda dt, *sh: torch.zeros((N,) + sh, dtype=dt, device="cuda")
+        st = dict(phase=z(torch.int32), t1=z(torch.int32), t2=z(torch.int32) + 1, reached_frames=z(torch.int32),
+                  target_reached=z(torch.uint8), mode=z(torch.int32) + 2, seq_len=z(torch.int32) + 20,
+                  sequence=z(torch.float64, 20, 4), goal=z(torch.float64, 8))
+        a = torch.zeros((N, 12), device="cuda")
+        for _ in range(20):
+            b.step(a, st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            b.step(a, st)
+        torch.cuda.synchronize()
+        us = 1e6 * (time.perf_counter() - t0) / reps
+    finally:
+        b.close()
+    up = int(N * (8 * (7 + 12 * 2 + 3 * 6 + 4 + 3) + 4 + 8) + int(nc_all.sum()) * 64)     # fixed compact row + used 64-B records
+    return {"us_per_vec_step": us, "env_steps_per_s": N / (us * 1e-6), "pcie_bytes_per_step": {"down": N * 8 * 12, "up": up},
+            "note": "compact staging (oly_a3_batcher_set_compact), mapped PD targets; contact density Poisson(4) of 16 slots; "
+                    "physics is a kinematic stand-in"}
 
 
 def h1_host_batcher(eng, spec, N, qpos_h, qvel_h, act, reps=300):

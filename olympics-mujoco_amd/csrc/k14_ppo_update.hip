@@ -40,7 +40,7 @@ namespace {
 
 constexpr int UT = 512;          // 8 waves, two per SIMD
 constexpr int UR = 16;           // rows per tile
-constexpr int PP = 17;           // pitch of the output layer's partial tiles
+constexpr int PP = 20;           // pitch of the output layer's partial tiles (rows 16-byte aligned: four columns per read)
 constexpr int XI = MAX_IN * UR;  // floats of one input image
 constexpr int HI = HID * UR;     // floats of one hidden image
 constexpr float LOG_SQRT_2PI = 0.9189385332046727f;
@@ -86,8 +86,8 @@ struct UpdArgs {
   const int* act_src;
   const float* act_sign;
   double* stat_partials;  // [parts_actor + parts_critic][NSTAT]
-#ifdef OLY_K14_DUMP
-  float* dbg;
+#ifdef OLY_DIAG
+  unsigned long long* stamps;   // diagnostic build: s_memtime at every phase boundary, [block < 2][wave < 8][item < 64][16]
 #endif
 };
 constexpr int NSTAT = 6;   // surrogate, kl, clipped, mirror, critic, rows
@@ -115,29 +115,33 @@ __device__ const char* g_k14_base;
 #else
 #define OLY_K14_LOAD(rs, voff, so) __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so, 0)
 #endif
-// first two weight groups of a layer's NT tiles: issued BEFORE the barrier in front of the layer (weights do not depend
+constexpr int RD = 2;    // weight groups in flight ahead of the MFMAs (ring of RD + 1 register sets per tile)
+
+// the first RD weight groups of a layer's NT tiles: issued BEFORE the barrier in front of the layer (weights do not depend
 // on it), so that the layer does not open with an exposed L2 round trip on all eight waves at once
 template <int G, int NT>
 __device__ __forceinline__ void preload16b(__amdgpu_buffer_rsrc_t rs, unsigned voff, const unsigned (&soff)[NT],
-                                           u32x4 (&b)[3][NT], const float* pbase = nullptr) {
+                                           u32x4 (&b)[RD + 1][NT], const float* pbase = nullptr) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    b[0][t] = OLY_K14_LOAD(rs, voff, soff[t]);
-    if (G > 1) b[1][t] = OLY_K14_LOAD(rs, voff, soff[t] + 1024u);
+  for (int d = 0; d < RD; ++d) {
+    if (d < G) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[d][t] = OLY_K14_LOAD(rs, voff, soff[t] + (unsigned)d * 1024u);
+    }
   }
 }
 
 template <int G, int NT>
 __device__ __forceinline__ void layer_tiles16b(const float4* __restrict__ a4, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                               const unsigned (&soff)[NT], int lane, f32x4 (&acc)[NT], u32x4 (&b)[3][NT],
+                                               const unsigned (&soff)[NT], int lane, f32x4 (&acc)[NT], u32x4 (&b)[RD + 1][NT],
                                                const float* pbase = nullptr) {
   float4 a[2];
   a[0] = a4[lane];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    if (g + 2 < G) {
+    if (g + RD < G) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[(g + 2) % 3][t] = OLY_K14_LOAD(rs, voff, soff[t] + (unsigned)(g + 2) * 1024u);
+      for (int t = 0; t < NT; ++t) b[(g + RD) % (RD + 1)][t] = OLY_K14_LOAD(rs, voff, soff[t] + (unsigned)(g + RD) * 1024u);
     }
     if (g + 1 < G) a[(g + 1) & 1] = a4[(g + 1) * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);      // keep the loads above ahead of this group's MFMAs
@@ -146,7 +150,7 @@ __device__ __forceinline__ void layer_tiles16b(const float4* __restrict__ a4, __
       const float aq = q == 0 ? a[g & 1].x : q == 1 ? a[g & 1].y : q == 2 ? a[g & 1].z : a[g & 1].w;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const u32x4 bb = b[g % 3][t];
+        const u32x4 bb = b[g % (RD + 1)][t];
         const float bq = __uint_as_float(q == 0 ? bb.x : q == 1 ? bb.y : q == 2 ? bb.z : bb.w);
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq, acc[t], 0, 0, 0);
       }
@@ -154,6 +158,16 @@ __device__ __forceinline__ void layer_tiles16b(const float4* __restrict__ a4, __
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+#ifdef OLY_DIAG
+#define OLY_STAMP(i)                                                                                      \
+  do {                                                                                                    \
+    if (p.stamps && (blockIdx.x == 0 || blockIdx.x == (unsigned)p.net[0].parts) && lane == 0 && it < 64)  \
+      p.stamps[(((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + it) * 16 + (i)] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+#else
+#define OLY_STAMP(i)
+#endif
 
 template <int KT1>      // groups of 16 inputs
 __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
@@ -170,7 +184,12 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   float* dz3A = dmirL + UR * 16;   // [256]     d loss / d out as an A operand (one group of 16)
   float* dz3C = dz3A + 256;        // [256]     the same in the C/D layout: A operand of dW3
   float* cstL = dz3C + 256;        // [8][16]   per-column constants of the loss (wave 0 reads them per tile)
-  double* stL = reinterpret_cast<double*>(cstL + 128);   // [NSTAT][64] wave 0's per-lane statistics
+  float* lossL = cstL + 128;       // [10][64]  wave 0: the loss inputs of the next tile (action 4, old mean 4, adv, ret per lane)
+  float* termL = lossL + 640;      // [2][16][16] wave 0: per-(row, column) log-prob terms of the new / old policy
+  double* stL = reinterpret_cast<double*>(termL + 512);  // [NSTAT][64] wave 0's per-lane statistics
+  float4* parkL = reinterpret_cast<float4*>(h2A);   // [16][64] wave 0 parks half of its dW2 accumulators here while it runs the
+                                   //           loss (the loss needs ~70 registers, 40 are free); h2A is dead between the
+                                   //           output layer and dZ2
   float4* dW1L = reinterpret_cast<float4*>(stL + NSTAT * 64);   // [16][KT1][64] dW1 in the C/D layout: the accumulators
                                    //           of a tile are read, run through its four MFMAs and written back
 
@@ -268,13 +287,63 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   const unsigned so3[1] = {(unsigned)(L.w3n * 4) + (unsigned)(2 * wave) * 1024u};
   const unsigned so3t[2] = {(unsigned)(L.w3t * 4) + (unsigned)ta * (T3N * 1024u), (unsigned)(L.w3t * 4) + (unsigned)(ta + 1) * (T3N * 1024u)};
   const unsigned so2t[2] = {(unsigned)(L.w2t * 4) + (unsigned)ta * (HID / 16 * 1024u), (unsigned)(L.w2t * 4) + (unsigned)(ta + 1) * (HID / 16 * 1024u)};
-  u32x4 wb[3][2];          // the weight ring of the two-tile layers: its first two groups are requested before the barrier
+  u32x4 wb[RD + 1][2];     // the weight ring of the two-tile layers: its first RD groups are requested before the barrier
+
+  // wave 0's loss inputs (lane: row c, columns 4 j ..) of a tile: fetched one tile ahead into registers behind the
+  // backward phases, parked in LDS at the item's end (a random row of HBM costs ~2 us: in front of the loss they were
+  // 4 K of a tile's 47 K cycles on every wave)
+  auto loss_fetch = [&](int tile_, float (&v)[10]) {
+#pragma unroll
+    for (int q = 0; q < 10; ++q) v[q] = 0.f;
+    const int row = tile_ * UR + c;
+    if (tile_ < p.ntiles && row < B) {
+      const long r = p.idx ? (long)p.idx[row] : (long)row;
+      if (critic) {
+        v[9] = p.ret[r];
+      } else {
+        v[8] = p.adv[r];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int col = 4 * j + cc;
+          if (col < out_dim) { v[cc] = p.action[r * out_dim + col]; v[4 + cc] = p.old_mu[r * out_dim + col]; }
+        }
+      }
+    }
+  };
+  auto loss_park = [&](const float (&v)[10]) {
+#pragma unroll
+    for (int q = 0; q < 10; ++q) lossL[q * 64 + lane] = v[q];
+  };
+
+  // dW2 (own rows) += dZ2^T H1 of one tile: 128 MFMAs per wave, the two tiles' chains alternating (consecutive MFMAs on one
+  // accumulator wait on the 40-cycle dependent latency of the 32-cycle instruction)
+  auto dW2_accumulate = [&](const f32x4 (&dz)[2], const float4* __restrict__ h1c) {
+    float4 hb[2];
+    hb[0] = h1c[lane];
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      if (kt + 1 < 16) hb[(kt + 1) & 1] = h1c[(kt + 1) * 64 + lane];
+      const float4 b = hb[kt & 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float bq = q == 0 ? b.x : q == 1 ? b.y : q == 2 ? b.z : b.w;
+        dW2[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[0][q], bq, dW2[0][kt], 0, 0, 0);
+        dW2[1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[1][q], bq, dW2[1][kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
   float xn[2];
   if (n_items > 0) {
     load_x(0, xn);
     store_x(0, xn);
     preload16b<KT1, 2>(rsP, voff, so1, wb, P);
+    if (wave == 0) {
+      float lv[10];
+      loss_fetch(part_id, lv);
+      loss_park(lv);
+    }
   }
   __syncthreads();
 
@@ -289,6 +358,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     const float4* xA4 = reinterpret_cast<const float4*>(xA + pb * XI);
     const float4* xC4 = reinterpret_cast<const float4*>(xC + pb * XI);
     float4* h1C4 = reinterpret_cast<float4*>(h1C);
+    OLY_STAMP(0);
 
     {  // ---- layer 1
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -303,7 +373,9 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
         h1C4[(ta + t) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
+    OLY_STAMP(1);
     __syncthreads();
+    OLY_STAMP(2);
     f32x4 h2own[2];
     {  // ---- layer 2
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -316,53 +388,44 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
         store_act16(h2own[t], ta + t, lane, h2A);
       }
     }
+    OLY_STAMP(3);
     __syncthreads();
-    // wave 0: the loss inputs of this tile (lane: row c, columns 4 j ..), requested behind the output layer
-    float act[4] = {0.f, 0.f, 0.f, 0.f}, omu[4] = {0.f, 0.f, 0.f, 0.f}, advv = 0.f, retv = 0.f;
-    if (wave == 0 && sp == 1 && valid) {
-      const long r = p.idx ? (long)p.idx[grow] : (long)grow;
-      if (critic) {
-        retv = p.ret[r];
-      } else {
-        advv = p.adv[r];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int col = 4 * j + cc;
-          if (col < out_dim) { act[cc] = p.action[r * out_dim + col]; omu[cc] = p.old_mu[r * out_dim + col]; }
-        }
-      }
-    }
+    OLY_STAMP(4);
     {  // ---- output layer: chain `wave` of the eight partial chains (k in [32 wave, 32 wave + 32))
       f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-      u32x4 wb1[3][1];
+      u32x4 wb1[RD + 1][1];
       preload16b<2, 1>(rsP, voff, so3, wb1, P);
       layer_tiles16b<2, 1>(reinterpret_cast<const float4*>(h2A) + (size_t)(2 * wave) * 64, rsP, voff, so3, lane, acc, wb1, P);
       if (sp != 0) preload16b<1, 2>(rsP, voff, so3t, wb, P);
 #pragma unroll
       for (int i = 0; i < 4; ++i) part[(wave * UR + 4 * j + i) * PP + c] = acc[0][i];
     }
+    OLY_STAMP(5);
     __syncthreads();
+    OLY_STAMP(6);
     if (wave == 0) {  // ---- out = partial chains in order + bias; loss terms; d loss / d out   (lane: row c, columns 4 j ..)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) parkL[k * 64 + lane] = make_float4(dW2[0][k][0], dW2[0][k][1], dW2[0][k][2], dW2[0][k][3]);
       float o[4], g[4] = {0.f, 0.f, 0.f, 0.f};
+      const float act[4] = {lossL[lane], lossL[64 + lane], lossL[128 + lane], lossL[192 + lane]};
+      const float omu[4] = {lossL[256 + lane], lossL[320 + lane], lossL[384 + lane], lossL[448 + lane]};
+      const float advv = lossL[512 + lane], retv = lossL[576 + lane];
       const float4* cst4 = reinterpret_cast<const float4*>(cstL);
       const float4 b3q = cst4[j];
       const float b3v[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
+      {
+        float4 pq[4];
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int col = 4 * j + cc;
-        float s = part[c * PP + col];
+        for (int w = 0; w < 4; ++w) pq[w] = reinterpret_cast<const float4*>(part + (w * UR + c) * PP)[j];
+        float4 sq = pq[0];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) s += part[(w * UR + c) * PP + col];
-        o[cc] = s + b3v[cc];
+        for (int w = 1; w < 4; ++w) { sq.x += pq[w].x; sq.y += pq[w].y; sq.z += pq[w].z; sq.w += pq[w].w; }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) pq[w] = reinterpret_cast<const float4*>(part + ((w + 4) * UR + c) * PP)[j];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sq.x += pq[w].x; sq.y += pq[w].y; sq.z += pq[w].z; sq.w += pq[w].w; }
+        o[0] = sq.x + b3v[0]; o[1] = sq.y + b3v[1]; o[2] = sq.z + b3v[2]; o[3] = sq.w + b3v[3];
       }
-#ifdef OLY_K14_DUMP
-      if (it == 0) {
-        float* dd = p.dbg + blockIdx.x * 8192;
-        for (int cc = 0; cc < 4; ++cc) dd[c * 16 + 4 * j + cc] = o[cc];
-        for (int e = lane; e < 1024; e += 64) dd[256 + e] = xA[pb * XI + e];
-        for (int e = lane; e < 4096; e += 64) dd[256 + 1024 + e] = h1A[e];
-      }
-#endif
       if (sp == 0) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) mirL[c * 16 + 4 * j + cc] = o[cc];
@@ -393,13 +456,25 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
           lt[cc] = on ? -(t[cc] * t[cc]) / sdv2[cc] - lsd[cc] - LOG_SQRT_2PI : 0.f;
           olt[cc] = on ? -(ot * ot) / osdv2[cc] - olsd[cc] - LOG_SQRT_2PI : 0.f;
         }
-        float lp = 0.f, olp = 0.f;      // sums over the action dimension in order, as torch's .sum(-1) of 12 terms does
+        // sums over the action dimension in order, as torch's .sum(-1) does: the terms of a row go through LDS so that
+        // every lane of the row adds all sixteen in sequence (columns >= act_dim hold exact zeros: x + 0 = x)
+        float4* t4 = reinterpret_cast<float4*>(termL);
+        t4[c * 4 + j] = make_float4(lt[0], lt[1], lt[2], lt[3]);
+        t4[64 + c * 4 + j] = make_float4(olt[0], olt[1], olt[2], olt[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float lp = 0.f, olp = 0.f;
+        {
+          float4 a4[4];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-          if (jj < out_dim) {
-            lp += __shfl(lt[jj & 3], c + 16 * (jj >> 2), 64);
-            olp += __shfl(olt[jj & 3], c + 16 * (jj >> 2), 64);
-          }
+          for (int q = 0; q < 4; ++q) a4[q] = t4[c * 4 + q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { lp += a4[q].x; lp += a4[q].y; lp += a4[q].z; lp += a4[q].w; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a4[q] = t4[64 + c * 4 + q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { olp += a4[q].x; olp += a4[q].y; olp += a4[q].z; olp += a4[q].w; }
         }
         const float log_ratio = lp - olp;
         const float ratio = exp32(log_ratio);
@@ -445,9 +520,20 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
           dz3C[c16_index(col, c)] = g[cc];
         }
       }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float4 v = parkL[k * 64 + lane];
+        dW2[0][k] = f32x4{v.x, v.y, v.z, v.w};
+      }
     }
+    OLY_STAMP(7);
+    // wave 0: the next tile's loss inputs, requested behind this item's backward phases (the item before a tile's loss)
+    float lnext[10];
+    const bool fetch_loss = wave == 0 && more && sp == (mirror ? 2 : 1);
+    if (fetch_loss) loss_fetch(tile + parts, lnext);
     if (sp != 0) {
       __syncthreads();
+      OLY_STAMP(8);
       // ---- dH2 (own tiles) = dZ3 W3; dZ2 = dH2 [H2 > 0]; dW3 (own columns) += dZ3^T H2; dW2 (own rows) += dZ2^T H1
       f32x4 dz2[2];
       {
@@ -475,23 +561,10 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
           dW3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(z3.w, h2own[t][3], dW3[t], 0, 0, 0);
         }
       }
-      {
-        float4 hb[2];
-        hb[0] = h1C4[lane];
-#pragma unroll
-        for (int kt = 0; kt < 16; ++kt) {
-          if (kt + 1 < 16) hb[(kt + 1) & 1] = h1C4[(kt + 1) * 64 + lane];
-          const float4 b = hb[kt & 1];
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            dW2[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[t][0], b.x, dW2[t][kt], 0, 0, 0);
-            dW2[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[t][1], b.y, dW2[t][kt], 0, 0, 0);
-            dW2[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[t][2], b.z, dW2[t][kt], 0, 0, 0);
-            dW2[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[t][3], b.w, dW2[t][kt], 0, 0, 0);
-          }
-        }
-      }
+      dW2_accumulate(dz2, h1C4);
+      OLY_STAMP(9);
       __syncthreads();
+      OLY_STAMP(10);
       {  // ---- dH1 (own tiles) = dZ2 W2; dZ1 = dH1 [H1 > 0]; dW1 (own rows) += dZ1^T X
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         layer_tiles16b<HID / 16, 2>(reinterpret_cast<const float4*>(dz2A), rsP, voff, so2t, lane, acc, wb, P);
@@ -506,20 +579,33 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) db1[t] += dz1[t][i];
         }
+        // dW1's accumulators live in LDS: all 2 KT1 tiles are read first, then their MFMAs run as independent chains
+        // (one tile at a time is four DEPENDENT MFMAs behind an LDS round trip), then all go back
+        f32x4 a1[2][KT1];
+        float4 xb[KT1];
 #pragma unroll
         for (int kt = 0; kt < KT1; ++kt) {
-          const float4 b = xC4[kt * 64 + lane];
+          xb[kt] = xC4[kt * 64 + lane];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            float4* slot = dW1L + ((ta + t) * KT1 + kt) * 64 + lane;
-            const float4 a0 = *slot;
-            f32x4 a = {a0.x, a0.y, a0.z, a0.w};
-            a = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][0], b.x, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][1], b.y, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][2], b.z, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][3], b.w, a, 0, 0, 0);
-            *slot = make_float4(a[0], a[1], a[2], a[3]);
+            const float4 a0 = dW1L[((ta + t) * KT1 + kt) * 64 + lane];
+            a1[t][kt] = f32x4{a0.x, a0.y, a0.z, a0.w};
           }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int kt = 0; kt < KT1; ++kt) {
+            const float bq = q == 0 ? xb[kt].x : q == 1 ? xb[kt].y : q == 2 ? xb[kt].z : xb[kt].w;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a1[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1[t][q], bq, a1[t][kt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            dW1L[((ta + t) * KT1 + kt) * 64 + lane] = make_float4(a1[t][kt][0], a1[t][kt][1], a1[t][kt][2], a1[t][kt][3]);
         }
       }
     }
@@ -527,7 +613,10 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
       store_x(pb ^ 1, xn);
       preload16b<KT1, 2>(rsP, voff, so1, wb, P);
     }
+    if (fetch_loss) loss_park(lnext);
+    OLY_STAMP(11);
     __syncthreads();
+    OLY_STAMP(12);
   }
 
   // ---- this part's partial gradients, in parameter order: W1 [256, in] | b1 | W2 [256, 256] | b2 | W3 [out, 256] | b3
@@ -699,7 +788,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
 }
 
 // input images 4 XI, hidden images 3 HI, partial tiles, mirror rows, dZ3 images, constants, statistics; + dW1: 16 KT1 KB
-constexpr size_t UPD_LDS_BASE = sizeof(float) * (4 * XI + 3 * HI + 8 * UR * PP + 2 * UR * 16 + 512 + 128) + sizeof(double) * NSTAT * 64;
+constexpr size_t UPD_LDS_BASE = sizeof(float) * (4 * XI + 3 * HI + 8 * UR * PP + 2 * UR * 16 + 512 + 128 + 640 + 512) + sizeof(double) * NSTAT * 64;
 constexpr size_t upd_lds(int kt1) { return UPD_LDS_BASE + (size_t)16 * kt1 * 64 * sizeof(float4); }
 
 inline int grad_floats(int in_dim, int out_dim) { return HID * in_dim + HID + HID * HID + HID + out_dim * HID + out_dim; }
@@ -707,8 +796,10 @@ inline int grad_floats(int in_dim, int out_dim) { return HID * in_dim + HID + HI
 void choose_parts(const oly_ctx* ctx, int B, int mirror, int* pa, int* pc) {
   const int ntiles = (B + UR - 1) / UR;
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-  // MFMAs per tile: forward 336, backward 576 per wave-quartet; the mirror loss adds two forwards and a backward to the actor
-  const double wa = mirror ? 3.0 * 336 + 2.0 * 576 : 912.0, wc = 912.0;
+  // a network's share of the workgroups follows its tile's measured cost (tools/time_k14.py, K cycles per 16-row tile):
+  // critic 41.4, actor 45.4 (its loss phase is longer), actor with the mirror loss 45.4 + a forward-only sub-pass 15 + a
+  // forward + backward sub-pass 40
+  const double wa = mirror ? 45.4 + 15.0 + 40.0 : 45.4, wc = 41.4;
   int a = (int)(cus * wa / (wa + wc) + 0.5);
   a = a < 1 ? 1 : (a > cus - 1 ? cus - 1 : a);
   int cpart = cus - a;
@@ -770,8 +861,11 @@ extern "C" int oly_ppo_update_grads(oly_ctx* ctx, const oly_ppo_update* u, oly_s
   a.mirror_gscale = (float)(2.0 / ((double)u->B * u->act_dim));
   a.inv_b = 1.0f / (float)u->B;
   a.act_src = u->act_src; a.act_sign = u->act_sign;
-#ifdef OLY_K14_DUMP
-  a.dbg = u->ws + u->ws_floats - 2 * 8192;
+#ifdef OLY_DIAG
+  {   // tools/time_k14.py passes a workspace with 2 * 8 * 64 * 16 extra 8-byte slots at its end
+    const int64_t slots = 2L * 8 * 64 * 16 * 2;
+    a.stamps = (u->ws_floats >= need + slots) ? reinterpret_cast<unsigned long long*>(u->ws + ((u->ws_floats - slots) & ~(int64_t)1)) : nullptr;
+  }
 #endif
   const int kt1 = (u->in_dim + 15) / 16;
   const dim3 grid(pa + pc), block(UT);
