@@ -17,7 +17,7 @@
 // earlier products in the C/D register layout (lane l: column l & 15, rows 4 (l >> 4) + i), so dZ is used straight
 // from registers and H from a float4-per-lane LDS image: no transposes.  A workgroup ("part") walks tiles part,
 // part + parts, ...; at the end it stores its partial gradients in parameter order and a finishing launch adds the
-// parts in order (fp64).  256 workgroups = one per CU, split between the networks by their work.
+// parts (fp64, four contiguous groups in order, the group sums in order).  256 workgroups = one per CU, split between the networks by their work.
 //
 // Mirror-symmetry loss (ppo.py:261-268): an actor tile runs three sub-passes: forward of the mirrored rows (keeps
 // policy(mirror_obs) only), forward + loss + backward of the rows themselves (d mirror / d det joins d mu), forward
@@ -73,8 +73,8 @@ __device__ __forceinline__ float exp32(float x) {
 
 struct UpdNet {
   const float* packed;
-  float* partials;        // [parts][grad_floats]
-  int out_dim, normalize, parts, grad_floats;
+  float* partials;        // [parts][pstride]: a part's gradients in parameter order; pstride = grad_floats rounded up to 4
+  int out_dim, normalize, parts, grad_floats, pstride;
 };
 struct UpdArgs {
   int B, in_dim, act_dim, ntiles;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   }
 
   // ---- this part's partial gradients, in parameter order: W1 [256, in] | b1 | W2 [256, 256] | b2 | W3 [out, 256] | b3
-  float* __restrict__ G = net.partials + (size_t)part_id * net.grad_floats;
+  float* __restrict__ G = net.partials + (size_t)part_id * net.pstride;
   const size_t oW1 = 0, ob1 = (size_t)HID * in_dim, oW2 = ob1 + HID, ob2 = oW2 + (size_t)HID * HID, oW3 = ob2 + HID,
                ob3 = oW3 + (size_t)out_dim * HID;
 #pragma unroll
@@ -681,37 +681,43 @@ struct FinArgs {
   float vf_coeff;
 };
 
-// grad[e] = sum over the parts in order (fp64), rounded once; block 0 also finishes the six scalars.  A block owns
-// 512 consecutive elements of one network (thread t: elements t and 256 + t), eight parts in flight per thread.
+// grad[e] = the parts added in fp64 and rounded once; block 0 also finishes the six scalars.  A block owns 256 consecutive
+// elements of one network, a lane four of them (one 16-byte load per part: the rows are padded to a multiple of four
+// floats); wave g adds the parts of group g (four contiguous groups of ceil(parts / 4), each in order, eight loads in
+// flight per lane), the four group sums are combined as ((S0 + S1) + S2) + S3.  (One thread per element over all 128
+// parts ran at 0.8 TB/s: 1228 waves on the chip, each waiting out sixteen dependent HBM round trips.)
 __global__ __launch_bounds__(256) void ppo_update_finish_kernel(FinArgs f, int blocks_a) {
+  __shared__ double sh[4][64][4];
   const int n = (int)blockIdx.x >= blocks_a;
-  const long base = 512L * ((int)blockIdx.x - (n ? blocks_a : 0));
-  const long gf = f.net[n].grad_floats;
+  const long gf = f.net[n].grad_floats, ps = f.net[n].pstride;
   const int parts = f.net[n].parts;
   const float* __restrict__ src = f.net[n].partials;
-  const long e0 = base + threadIdx.x, e1 = e0 + 256;
-  const bool on0 = e0 < gf, on1 = e1 < gf;
-  double s0 = 0.0, s1 = 0.0;
-  int q = 0;
-  for (; q + 8 <= parts; q += 8) {
-    float a[8], b[8];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long e = 256L * ((int)blockIdx.x - (n ? blocks_a : 0)) + 4 * lane;
+  const bool on = e < ps;                     // whole float4s: the pad of a row is never stored (e + i < gf below)
+  const int chunk = (parts + 3) / 4;
+  const int q0 = grp * chunk, q1 = min(parts, q0 + chunk);
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  int q = q0;
+  for (; q + 8 <= q1; q += 8) {
+    float4 a[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      a[u] = on0 ? src[(size_t)(q + u) * gf + e0] : 0.f;
-      b[u] = on1 ? src[(size_t)(q + u) * gf + e1] : 0.f;
-    }
+    for (int u = 0; u < 8; ++u) a[u] = on ? *reinterpret_cast<const float4*>(src + (size_t)(q + u) * ps + e) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      s0 += (double)a[u];
-      s1 += (double)b[u];
-    }
+    for (int u = 0; u < 8; ++u) { s[0] += (double)a[u].x; s[1] += (double)a[u].y; s[2] += (double)a[u].z; s[3] += (double)a[u].w; }
   }
-  for (; q < parts; ++q) {
-    s0 += on0 ? (double)src[(size_t)q * gf + e0] : 0.0;
-    s1 += on1 ? (double)src[(size_t)q * gf + e1] : 0.0;
+  for (; q < q1; ++q) {
+    const float4 a = on ? *reinterpret_cast<const float4*>(src + (size_t)q * ps + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s[0] += (double)a.x; s[1] += (double)a.y; s[2] += (double)a.z; s[3] += (double)a.w;
   }
-  if (on0) f.grad[n][e0] = (float)s0;
-  if (on1) f.grad[n][e1] = (float)s1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sh[grp][lane][i] = s[i];
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (e + i < gf) f.grad[n][e + i] = (float)(((sh[0][lane][i] + sh[1][lane][i]) + sh[2][lane][i]) + sh[3][lane][i]);
+  }
   if (blockIdx.x == 0 && threadIdx.x < NSTAT) {
     const int qq = threadIdx.x;
     double s = 0.0;
@@ -766,15 +772,15 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(AdamArgs a) {
 
 // clip_grad_norm_: g *= min(max_norm / (||g|| + 1e-6), 1) per network; Adam (torch.optim.Adam, amsgrad off, no decay):
 //   m += (g - m)(1 - b1); v = v b2 + ((1 - b2) g) g; p += -(lr / (1 - b1^t)) (m / (sqrt(v) / sqrt(1 - b2^t) + eps))
-__global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
-  const long na = a.net[0].n;
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= na + a.net[1].n) return;
-  const int n = e >= na;
+__global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, int blocks_a) {
+  const int n = (int)blockIdx.x >= blocks_a;          // a block (hence a wave) belongs to ONE network
   const AdamNet nt = a.net[n];
-  const long i = n ? e - na : e;
+  const long i = 256L * ((int)blockIdx.x - (n ? blocks_a : 0)) + threadIdx.x;
+  // the squared norm from the block partials: lane l adds partials l, l + 64, ... in order, then the 64-lane tree
   double ss = 0.0;
-  for (int b = 0; b < nt.blocks; ++b) ss += a.sumsq[n * ADAM_MAX_BLOCKS + b];
+  for (int b = threadIdx.x & 63; b < nt.blocks; b += 64) ss += a.sumsq[n * ADAM_MAX_BLOCKS + b];
+  ss = __shfl(wave_sum(ss), 0, 64);
+  if (i >= nt.n) return;
   const float norm = (float)sqrt(ss);
   const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
   const float g = nt.grad[i] * coef;
@@ -792,6 +798,7 @@ constexpr size_t UPD_LDS_BASE = sizeof(float) * (4 * XI + 3 * HI + 8 * UR * PP +
 constexpr size_t upd_lds(int kt1) { return UPD_LDS_BASE + (size_t)16 * kt1 * 64 * sizeof(float4); }
 
 inline int grad_floats(int in_dim, int out_dim) { return HID * in_dim + HID + HID * HID + HID + out_dim * HID + out_dim; }
+inline int pad4(int n) { return (n + 3) & ~3; }
 
 void choose_parts(const oly_ctx* ctx, int B, int mirror, int* pa, int* pc) {
   const int ntiles = (B + UR - 1) / UR;
@@ -822,7 +829,7 @@ extern "C" int64_t oly_ppo_update_ws_floats(oly_ctx* ctx, int B, int in_dim, int
   if (parts_actor) *parts_actor = pa;
   if (parts_critic) *parts_critic = pc;
   // partial gradients of both networks, then the statistics (NSTAT doubles per part)
-  return (int64_t)pa * grad_floats(in_dim, act_dim) + (int64_t)pc * grad_floats(in_dim, 1) + 2 * (int64_t)NSTAT * (pa + pc) + 4;
+  return (int64_t)pa * pad4(grad_floats(in_dim, act_dim)) + (int64_t)pc * pad4(grad_floats(in_dim, 1)) + 2 * (int64_t)NSTAT * (pa + pc) + 4;
 }
 
 extern "C" int oly_ppo_update_grads(oly_ctx* ctx, const oly_ppo_update* u, oly_stream stream) {
@@ -844,16 +851,17 @@ extern "C" int oly_ppo_update_grads(oly_ctx* ctx, const oly_ppo_update* u, oly_s
   if (pa <= 0 || pc <= 0) choose_parts(ctx, u->B, mirror, &pa, &pc);
   if (pa > ntiles || pc > ntiles) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: more parts (%d, %d) than 16-row tiles (%d)", pa, pc, ntiles);
   const int gfa = grad_floats(u->in_dim, u->act_dim), gfc = grad_floats(u->in_dim, 1);
-  const int64_t need = (int64_t)pa * gfa + (int64_t)pc * gfc + 2 * (int64_t)NSTAT * (pa + pc) + 4;
+  const int psa = pad4(gfa), psc = pad4(gfc);
+  const int64_t need = (int64_t)pa * psa + (int64_t)pc * psc + 2 * (int64_t)NSTAT * (pa + pc) + 4;
   if (u->ws_floats < need) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: workspace of %lld floats, %lld needed", (long long)u->ws_floats, (long long)need);
   UpdArgs a;
   a.B = u->B; a.in_dim = u->in_dim; a.act_dim = u->act_dim; a.ntiles = ntiles;
   a.obs = u->obs; a.mir_obs = u->mir_obs; a.action = u->action; a.adv = u->adv; a.ret = u->ret; a.old_mu = u->old_mu;
   a.idx = u->idx;
   float* ws = u->ws;
-  a.net[0] = UpdNet{u->packed_actor, ws, u->act_dim, u->normalize_actor, pa, gfa};
-  a.net[1] = UpdNet{u->packed_critic, ws + (size_t)pa * gfa, 1, u->normalize_critic, pc, gfc};
-  size_t off = (size_t)pa * gfa + (size_t)pc * gfc;
+  a.net[0] = UpdNet{u->packed_actor, ws, u->act_dim, u->normalize_actor, pa, gfa, psa};
+  a.net[1] = UpdNet{u->packed_critic, ws + (size_t)pa * psa, 1, u->normalize_critic, pc, gfc, psc};
+  size_t off = (size_t)pa * psa + (size_t)pc * psc;
   off = (off + 3) & ~(size_t)3;                    // doubles: 8-byte aligned (ws is 16-byte aligned)
   a.stat_partials = reinterpret_cast<double*>(ws + off);
   a.sd = u->sd; a.log_sd = u->log_sd; a.old_sd = u->old_sd; a.old_log_sd = u->old_log_sd;
@@ -894,7 +902,7 @@ extern "C" int oly_ppo_update_grads(oly_ctx* ctx, const oly_ppo_update* u, oly_s
   f.log_sd = u->log_sd;
   f.B = u->B; f.act_dim = u->act_dim; f.mirror = mirror;
   f.vf_coeff = u->vf_coeff;
-  const int fba = (gfa + 511) / 512, fbc = (gfc + 511) / 512;
+  const int fba = (gfa + 255) / 256, fbc = (gfc + 255) / 256;
   hipLaunchKernelGGL(ppo_update_finish_kernel, dim3(fba + fbc), dim3(256), 0, oly_s(stream), f, fba);
   OLY_LAUNCH_CHECK(ctx, "ppo_update_finish_kernel");
   return OLY_OK;
@@ -927,8 +935,8 @@ extern "C" int oly_ppo_adam_step(oly_ctx* ctx, const oly_ppo_adam* a, oly_stream
   k.bc2_sqrt = (float)sqrt(bc2);
   k.max_norm = a->max_grad_norm;
   hipLaunchKernelGGL(grad_sumsq_kernel, dim3(k.net[0].blocks + k.net[1].blocks), dim3(256), 0, oly_s(stream), k);
-  const long total = (long)k.net[0].n + k.net[1].n;
-  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, oly_s(stream), k);
+  const int ba = (k.net[0].n + 255) / 256, bc = (k.net[1].n + 255) / 256;
+  hipLaunchKernelGGL(adam_step_kernel, dim3(ba + bc), dim3(256), 0, oly_s(stream), k, ba);
   OLY_LAUNCH_CHECK(ctx, "adam step kernels");
   for (int n = 0; n < 2; ++n) {
     const oly_adam_net& s = a->net[n];

@@ -1123,7 +1123,8 @@ int oly_rollout_cuts_cpu(int N, int max_traj_len, int last_step, const uint8_t* 
  *   dW, per part (tiles part, part + parts, ... of 16 rows): ONE fmaf chain over the part's rows in tile order,
  *               inside a tile rows 0,4,8,12,1,5,9,13,...; bias gradients as four running f32 sums per column
  *               (rows 4 g .. 4 g + 3 of every tile into sum g), combined as (s0 + s1) + (s2 + s3);
- *   the parts are added in order in fp64 and rounded once.
+ *   the parts are added in fp64 in four contiguous groups of ceil(parts / 4), each in order, the group sums as
+ *   ((S0 + S1) + S2) + S3, rounded once.
  * critic != 0: out_dim = 1, loss = vf_coeff * mse.  stats[6]: sums of surrogate, kl, clipped, mirror, critic, rows. */
 typedef struct {
   const float *w1, *b1, *w2, *b2, *w3, *b3, *mean, *std;
@@ -1176,7 +1177,7 @@ static int upd_network(int critic, int B, int in_dim, int out_dim, int parts, co
   const int ntiles = (B + R - 1) / R;
   const size_t oW1 = 0, ob1 = (size_t)H * in_dim, oW2 = ob1 + H, ob2 = oW2 + (size_t)H * H, oW3 = ob2 + H,
                ob3 = oW3 + (size_t)out_dim * H, gf = ob3 + out_dim;
-  double* total = (double*)calloc(gf, sizeof(double));
+  double* total = (double*)calloc(4 * gf, sizeof(double));      /* four group sums per element */
   float* G = (float*)malloc(gf * sizeof(float));
   float* sb2 = (float*)malloc(sizeof(float) * H * 4), *sb1 = (float*)malloc(sizeof(float) * H * 4);
   float* xin = (float*)malloc(sizeof(float) * R * 64), *h1 = (float*)malloc(sizeof(float) * R * H),
@@ -1299,9 +1300,15 @@ static int upd_network(int critic, int B, int in_dim, int out_dim, int parts, co
       G[ob1 + n] = (sb1[n * 4] + sb1[n * 4 + 1]) + (sb1[n * 4 + 2] + sb1[n * 4 + 3]);
     }
     for (int n = 0; n < out_dim; ++n) G[ob3 + n] = (sb3[n][0] + sb3[n][1]) + (sb3[n][2] + sb3[n][3]);
-    for (size_t e = 0; e < gf; ++e) total[e] += (double)G[e];
+    /* the finishing launch adds the parts in four contiguous groups of ceil(parts / 4), each in order: ((S0 + S1) + S2) + S3 */
+    {
+      const int chunk = (parts + 3) / 4, grp = part / chunk;
+      double* S = total + (size_t)grp * gf;
+      for (size_t e = 0; e < gf; ++e) S[e] += (double)G[e];
+    }
   }
-  for (size_t e = 0; e < gf; ++e) grad[e] = (float)total[e];
+  for (size_t e = 0; e < gf; ++e)
+    grad[e] = (float)(((total[e] + total[gf + e]) + total[2 * gf + e]) + total[3 * gf + e]);
   free(total); free(G); free(sb2); free(sb1); free(xin); free(h1); free(h2); free(dz2); free(dz1);
   return OLY_OK;
 }
@@ -1339,12 +1346,14 @@ int oly_ppo_update_cpu(int B, int in_dim, int act_dim, int parts_actor, int part
 /* oly_ppo_adam_step's twin for ONE network: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step
  * (rl/algos/ppo.py:399-410; amsgrad off, no weight decay) on flat buffers, float32 per element in the kernel's
  * order; the squared norm as the kernel sums it: blocks of 512 elements, thread t takes elements t and 256 + t,
- * a 64-lane tree per wave, the four waves in order, the blocks in order (fp64).                           */
+ * a 64-lane tree per wave, the four waves in order; the block partials b = l, l + 64, ... added in order into 64
+ * sums, those by the same tree (fp64).                                                                     */
 int oly_ppo_adam_step_cpu(int n, int step, float lr, float beta1, float beta2, float eps, float max_norm,
                           float* param, const float* grad, float* exp_avg, float* exp_avg_sq) {
   if (n <= 0 || step <= 0) return OLY_EINVAL;
   const int blocks = (n + 511) / 512;
-  double ss = 0.0;
+  double part[64];                 /* lane l of the stepping kernel adds block partials l, l + 64, ... in order */
+  for (int l = 0; l < 64; ++l) part[l] = 0.0;
   for (int b = 0; b < blocks; ++b) {
     double wsum[4];
     for (int w = 0; w < 4; ++w) {
@@ -1358,8 +1367,11 @@ int oly_ppo_adam_step_cpu(int n, int step, float lr, float beta1, float beta2, f
         for (int l = 0; l < off; ++l) v[l] += v[l + off];
       wsum[w] = v[0];
     }
-    ss += ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+    part[b & 63] += ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
   }
+  for (int off = 32; off > 0; off >>= 1)          /* then the 64-lane tree */
+    for (int l = 0; l < off; ++l) part[l] += part[l + off];
+  const double ss = part[0];
   const float norm = (float)sqrt(ss);
   const float coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
