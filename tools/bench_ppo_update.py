@@ -59,18 +59,14 @@ def main():
                 if fused == "kernel":
                     ku = KernelUpdate(eng, ppo.policy, ppo.critic, ppo.old_policy, 0.2, 0.5, 0.4,
                                       sym.mirror_clock_observation if mirror else None, a_src if mirror else None,
-                                      a_sgn if mirror else None)
+                                      a_sgn if mirror else None, lr=1e-4, eps=1e-5, max_grad_norm=0.05)
                     ku.begin(obs)
                     idx32 = torch.arange(B, device=dev, dtype=torch.int32)
                     ret1, adv1 = ret.reshape(-1).contiguous(), adv.reshape(-1).contiguous()
 
                 def step():
                     if fused == "kernel":
-                        ku.grads(obs, act, ret1, adv1, idx32)
-                        torch.nn.utils.clip_grad_norm_(ppo.policy.parameters(), 0.05)
-                        opt_a.step()
-                        torch.nn.utils.clip_grad_norm_(ppo.critic.parameters(), 0.05)
-                        opt_c.step()
+                        ku.step(obs, act, ret1, adv1, idx32)      # K14 gradients + clip + Adam + re-pack: six launches
                         return
                     if fused == "graph":
                         gu(obs, act, ret, adv, idx)
