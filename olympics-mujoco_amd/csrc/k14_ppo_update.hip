@@ -671,11 +671,14 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   }
 }
 
+constexpr int ADAM_MAX_BLOCKS = 512;   // 256-element blocks of a network's squared-norm partials
+
 struct FinArgs {
   UpdNet net[2];
   float* grad[2];
   const double* stat_partials;
   double* scal_out;
+  double* gnorm;          // [2][ADAM_MAX_BLOCKS] block partials of sum g^2 (for oly_ppo_adam_step) or NULL
   const float* log_sd;
   int B, act_dim, mirror;
   float vf_coeff;
@@ -714,9 +717,18 @@ __global__ __launch_bounds__(256) void ppo_update_finish_kernel(FinArgs f, int b
   for (int i = 0; i < 4; ++i) sh[grp][lane][i] = s[i];
   __syncthreads();
   if (grp == 0) {
+    // ... and this block's partial of the squared gradient norm (the same 256-element blocks as grad_sumsq_kernel)
+    double sq = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (e + i < gf) f.grad[n][e + i] = (float)(((sh[0][lane][i] + sh[1][lane][i]) + sh[2][lane][i]) + sh[3][lane][i]);
+    for (int i = 0; i < 4; ++i) {
+      if (e + i < gf) {
+        const float g = (float)(((sh[0][lane][i] + sh[1][lane][i]) + sh[2][lane][i]) + sh[3][lane][i]);
+        f.grad[n][e + i] = g;
+        sq += (double)g * (double)g;
+      }
+    }
+    sq = wave_sum(sq);
+    if (f.gnorm && lane == 0) f.gnorm[n * ADAM_MAX_BLOCKS + ((int)blockIdx.x - (n ? blocks_a : 0))] = sq;
   }
   if (blockIdx.x == 0 && threadIdx.x < NSTAT) {
     const int qq = threadIdx.x;
@@ -754,20 +766,24 @@ struct AdamArgs {
   double* sumsq;          // [2][OLY_ADAM_MAX_BLOCKS] block partials of sum g^2
   float w1, beta2, w2, eps, neg_step, bc2_sqrt, max_norm;
 };
-constexpr int ADAM_MAX_BLOCKS = 512;
 
-// block partials of sum g^2: thread t squares elements t and 256 + t of its 512, fp64, wave tree, waves in order
-__global__ __launch_bounds__(256) void grad_sumsq_kernel(AdamArgs a) {
-  __shared__ double sh[4];
-  const int n = (int)blockIdx.x >= a.net[0].blocks;
-  const int blk = (int)blockIdx.x - (n ? a.net[0].blocks : 0);
+// block partials of sum g^2 over 256-element blocks (the finishing launch leaves the same ones): lane l squares elements
+// 4 l .. 4 l + 3 of the block in order, fp64, then the 64-lane tree; one block per wave
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(AdamArgs a, int wgs_a) {
+  const int n = (int)blockIdx.x >= wgs_a;
   const AdamNet nt = a.net[n];
-  const long e0 = 512L * blk + threadIdx.x, e1 = e0 + 256;
-  const double g0 = e0 < nt.n ? (double)nt.grad[e0] : 0.0, g1 = e1 < nt.n ? (double)nt.grad[e1] : 0.0;
-  const double s = wave_sum(g0 * g0 + g1 * g1);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) a.sumsq[n * ADAM_MAX_BLOCKS + blk] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+  const int blk = 4 * ((int)blockIdx.x - (n ? wgs_a : 0)) + (threadIdx.x >> 6);
+  const long e = 256L * blk + 4 * (threadIdx.x & 63);
+  double sq = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (e + i < nt.n) {
+      const double g = (double)nt.grad[e + i];
+      sq += g * g;
+    }
+  }
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0 && blk < nt.blocks) a.sumsq[n * ADAM_MAX_BLOCKS + blk] = sq;
 }
 
 // clip_grad_norm_: g *= min(max_norm / (||g|| + 1e-6), 1) per network; Adam (torch.optim.Adam, amsgrad off, no decay):
@@ -899,6 +915,7 @@ extern "C" int oly_ppo_update_grads(oly_ctx* ctx, const oly_ppo_update* u, oly_s
   f.grad[0] = u->grad_actor; f.grad[1] = u->grad_critic;
   f.stat_partials = a.stat_partials;
   f.scal_out = u->scal_out;
+  f.gnorm = u->gnorm_ws;
   f.log_sd = u->log_sd;
   f.B = u->B; f.act_dim = u->act_dim; f.mirror = mirror;
   f.vf_coeff = u->vf_coeff;
@@ -921,7 +938,7 @@ extern "C" int oly_ppo_adam_step(oly_ctx* ctx, const oly_ppo_adam* a, oly_stream
     if (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq || s.out_dim <= 0 || s.out_dim > 16)
       OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_adam_step: network %d: NULL buffer or bad out_dim", n);
     const int gf = grad_floats(a->in_dim, s.out_dim);
-    k.net[n] = AdamNet{s.param, s.exp_avg, s.exp_avg_sq, s.grad, gf, (gf + 511) / 512};
+    k.net[n] = AdamNet{s.param, s.exp_avg, s.exp_avg_sq, s.grad, gf, (gf + 255) / 256};
     if (k.net[n].blocks > ADAM_MAX_BLOCKS) OLY_FAIL(ctx, OLY_ERANGE, "oly_ppo_adam_step: network too large");
   }
   k.sumsq = a->ws;
@@ -934,10 +951,21 @@ extern "C" int oly_ppo_adam_step(oly_ctx* ctx, const oly_ppo_adam* a, oly_stream
   k.neg_step = (float)(-((double)a->lr / bc1));
   k.bc2_sqrt = (float)sqrt(bc2);
   k.max_norm = a->max_grad_norm;
-  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(k.net[0].blocks + k.net[1].blocks), dim3(256), 0, oly_s(stream), k);
+  if (!a->norm_ready) {       // the finishing launch of oly_ppo_update_grads leaves the same partials (gnorm_ws)
+    const int wa = (k.net[0].blocks + 3) / 4, wc = (k.net[1].blocks + 3) / 4;
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(wa + wc), dim3(256), 0, oly_s(stream), k, wa);
+  }
   const int ba = (k.net[0].n + 255) / 256, bc = (k.net[1].n + 255) / 256;
   hipLaunchKernelGGL(adam_step_kernel, dim3(ba + bc), dim3(256), 0, oly_s(stream), k, ba);
   OLY_LAUNCH_CHECK(ctx, "adam step kernels");
+  if (a->net[0].packed && a->net[1].packed) {
+    const int od[2] = {a->net[0].out_dim, a->net[1].out_dim};
+    const float* const flat[2] = {a->net[0].param, a->net[1].param};
+    const float* const mean[2] = {a->net[0].in_mean, a->net[1].in_mean};
+    const float* const std[2] = {a->net[0].in_std, a->net[1].in_std};
+    float* const packed[2] = {a->net[0].packed, a->net[1].packed};
+    return oly_mlp_pack_pair(ctx, a->in_dim, od, flat, mean, std, packed, stream);      // both networks, one launch
+  }
   for (int n = 0; n < 2; ++n) {
     const oly_adam_net& s = a->net[n];
     if (!s.packed) continue;

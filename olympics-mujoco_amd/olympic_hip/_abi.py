@@ -116,7 +116,7 @@ A3_PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(A3Re
 
 # name -> (restype, argtypes); device/host pointers are void*.
 STD_SCALAR, STD_PER_DIM, STD_FULL = 0, 1, 2
-ABI_VERSION = 4          # OLY_ABI_VERSION of include/olympic_hip.h this table mirrors
+ABI_VERSION = 5          # OLY_ABI_VERSION of include/olympic_hip.h this table mirrors
 
 
 class AdamNet(C.Structure):
@@ -128,7 +128,7 @@ class AdamNet(C.Structure):
 class PPOAdam(C.Structure):
     """oly_ppo_adam (K14's optimiser half): clip_grad_norm_ + Adam.step + re-pack for actor and critic."""
     _fields_ = [("in_dim", C.c_int32), ("step", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("eps", C.c_float), ("max_grad_norm", C.c_float), ("pad", C.c_int32), ("net", AdamNet * 2), ("ws", vp)]
+                ("eps", C.c_float), ("max_grad_norm", C.c_float), ("norm_ready", C.c_int32), ("net", AdamNet * 2), ("ws", vp)]
 
 
 class PPOUpdate(C.Structure):
@@ -141,7 +141,7 @@ class PPOUpdate(C.Structure):
                 ("sd", vp), ("log_sd", vp), ("old_sd", vp), ("old_log_sd", vp),
                 ("act_src", vp), ("act_sign", vp),
                 ("clip", C.c_float), ("vf_coeff", C.c_float), ("mirror_coeff", C.c_float), ("pad1", C.c_int32),
-                ("grad_actor", vp), ("grad_critic", vp), ("scal_out", vp), ("ws", vp), ("ws_floats", C.c_int64)]
+                ("grad_actor", vp), ("grad_critic", vp), ("scal_out", vp), ("ws", vp), ("ws_floats", C.c_int64), ("gnorm_ws", vp)]
 
 SIGNATURES = {
     "oly_strerror": (C.c_char_p, [C.c_int]),

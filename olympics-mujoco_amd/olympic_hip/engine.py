@@ -471,9 +471,12 @@ class Engine:
     def ppo_update_grads(self, obs, action, adv, ret, old_mu, packed_actor, packed_critic, sd, log_sd, old_sd, old_log_sd,
                          grad_actor, grad_critic, scal_out, ws, idx=None, mir_obs=None, act_src=None, act_sign=None,
                          normalize_actor=True, normalize_critic=False, clip=0.2, vf_coeff=0.5, mirror_coeff=0.0,
-                         parts=(0, 0)):
+                         parts=(0, 0), gnorm_ws=None, prepare=False):
         """oly_ppo_update_grads: gradients of one PPO minibatch update (rl/algos/ppo.py:232-282,396-410) into the flat
-        buffers grad_actor / grad_critic (parameter order), the six scalars of update_policy into scal_out [6] f64."""
+        buffers grad_actor / grad_critic (parameter order), the six scalars of update_policy into scal_out [6] f64.
+        gnorm_ws [1024] f64: the finishing launch also leaves the squared-norm block partials ppo_adam_step(norm_ready=True)
+        reads.  prepare=True: validate now, launch nothing, return `launch(idx, scal_out)` for minibatches of the same size
+        on the same buffers (no per-call checks: at minibatch 64 they cost more host time than the kernels run)."""
         from ._ffi import lib
         f32, dv = torch.float32, self.device
         if obs.dim() != 2 or action.dim() != 2:
@@ -519,12 +522,33 @@ class Engine:
         u.clip, u.vf_coeff, u.mirror_coeff = float(clip), float(vf_coeff), float(mirror_coeff)
         u.grad_actor, u.grad_critic, u.scal_out = ptr(grad_actor), ptr(grad_critic), ptr(scal_out)
         u.ws, u.ws_floats = ptr(ws), int(ws.shape[0])
+        _req(gnorm_ws, "gnorm_ws", (1024,), torch.float64, dv, optional=True)
+        u.gnorm_ws = ptr(gnorm_ws)
+        if prepare:
+            from ._ffi import check
+            fn, h = lib().oly_ppo_update_grads, self.ctx.handle
+            keep = (obs, action, adv, ret, old_mu, mir_obs, packed_actor, packed_critic, sd, log_sd, old_sd, old_log_sd, act_src,
+                    act_sign, grad_actor, grad_critic, ws, gnorm_ws)
+            ref = C.byref(u)
+
+            def launch(idx_, scal_):
+                if idx_.dtype != torch.int32 or idx_.shape[0] != B or not idx_.is_contiguous():
+                    raise OlyError("prepared ppo_update_grads: idx must be a contiguous int32 [B] of the prepared size")
+                u.idx, u.scal_out = idx_.data_ptr(), scal_.data_ptr()
+                rc = fn(h, ref, self._s())
+                if rc:
+                    check(h, rc, "oly_ppo_update_grads")
+                return keep
+            return launch
         self.ctx.call("oly_ppo_update_grads", C.byref(u), self._s())
         return grad_actor, grad_critic, scal_out
 
-    def ppo_adam_step(self, in_dim, step, lr, eps, max_grad_norm, nets, ws, beta1=0.9, beta2=0.999):
+    def ppo_adam_step(self, in_dim, step, lr, eps, max_grad_norm, nets, ws, beta1=0.9, beta2=0.999, norm_ready=False,
+                      prepare=False):
         """oly_ppo_adam_step: clip_grad_norm_ + Adam.step + weight re-pack for (actor, critic).  nets: two dicts with
-        flat f32 tensors param / grad / exp_avg / exp_avg_sq, out_dim, and optionally packed / in_mean / in_std."""
+        flat f32 tensors param / grad / exp_avg / exp_avg_sq, out_dim, and optionally packed / in_mean / in_std.
+        norm_ready: `ws` already holds the squared-norm partials of these gradients (gnorm_ws of ppo_update_grads).
+        prepare=True: validate now, launch nothing, return `launch(step, norm_ready)`."""
         from ._ffi import lib
         f32, dv = torch.float32, self.device
         a = _abi.PPOAdam()
@@ -549,6 +573,18 @@ class Engine:
             s.packed, s.in_mean, s.in_std, s.out_dim = ptr(packed), ptr(nt.get("in_mean")), ptr(nt.get("in_std")), out_dim
         _req(ws, "ws", (1024,), torch.float64, dv)
         a.ws = ptr(ws)
+        a.norm_ready = int(bool(norm_ready))
+        if prepare:
+            from ._ffi import check
+            fn, h, ref, keep = lib().oly_ppo_adam_step, self.ctx.handle, C.byref(a), (nets, ws)
+
+            def launch(step_, ready_):
+                a.step, a.norm_ready = int(step_), 1 if ready_ else 0
+                rc = fn(h, ref, self._s())
+                if rc:
+                    check(h, rc, "oly_ppo_adam_step")
+                return keep
+            return launch
         self.ctx.call("oly_ppo_adam_step", C.byref(a), self._s())
 
     # -------------------------------------------------------------- K6

@@ -184,7 +184,7 @@ class KernelUpdate:
         self.scal = torch.zeros(6, dtype=torch.float64, device=dev)
         self.adam_ws = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.steps = 0
-        self._ws = {}
+        self._ws, self._launch, self._apply, self._norm_ready = {}, {}, None, False
         self.old_mu = self.mir_obs = None
 
     @staticmethod
@@ -219,30 +219,47 @@ class KernelUpdate:
 
     def grads(self, observations, actions, returns, advantages, idx, scal=None, repack=False):
         """Gradients of the minibatch `idx` (int32 row indices) into the parameters' .grad; -> scal [6] f64 (device):
-        actor_loss, entropy_penalty, critic_loss, approx_kl, mirror_loss, clip_fraction."""
+        actor_loss, entropy_penalty, critic_loss, approx_kl, mirror_loss, clip_fraction.  The call is validated once per
+        (minibatch size, buffers); later minibatches re-issue it with the new index vector only."""
         if repack:
-            self.fw.refresh()                               # someone else moved the weights (not `step`)
+            self.fw.refresh()                               # someone else moved the weights (not `apply`)
         B = int(idx.shape[0])
-        if B not in self._ws:
-            n_ws, pa, pc = self.eng.ppo_update_plan(B, self.fw.in_dim, self.fw.act_dim, self.mir_obs is not None)
-            self._ws[B] = (torch.empty(n_ws, dtype=torch.float32, device=self.eng.device), (pa, pc))
-        ws, parts = self._ws[B]
+        adv, ret = advantages.reshape(-1), returns.reshape(-1)
+        key = (B, observations.data_ptr(), actions.data_ptr(), adv.data_ptr(), ret.data_ptr(), self.old_mu.data_ptr(),
+               None if self.mir_obs is None else self.mir_obs.data_ptr(), self.fw.packed_a.data_ptr(), self.fw.norm_a, self.fw.norm_c)
         scal = self.scal if scal is None else scal
-        self.eng.ppo_update_grads(observations, actions, advantages.reshape(-1), returns.reshape(-1), self.old_mu,
-                                  self.fw.packed_a, self.fw.packed_c, self.sd, self.log_sd, self.old_sd, self.old_log_sd,
-                                  self.grad_actor, self.grad_critic, scal, ws, idx=idx, mir_obs=self.mir_obs,
-                                  act_src=self.act_src, act_sign=self.act_sign, normalize_actor=self.fw.norm_a,
-                                  normalize_critic=self.fw.norm_c, clip=self.clip, vf_coeff=self.vf_coeff,
-                                  mirror_coeff=self.mirror_coeff, parts=parts)
+        launch = self._launch.get(key)
+        if launch is None:
+            if B not in self._ws:
+                n_ws, pa, pc = self.eng.ppo_update_plan(B, self.fw.in_dim, self.fw.act_dim, self.mir_obs is not None)
+                self._ws[B] = (torch.empty(n_ws, dtype=torch.float32, device=self.eng.device), (pa, pc))
+            ws, parts = self._ws[B]
+            if len(self._launch) > 8:
+                self._launch.clear()
+            launch = self._launch[key] = self.eng.ppo_update_grads(
+                observations, actions, adv, ret, self.old_mu, self.fw.packed_a, self.fw.packed_c, self.sd, self.log_sd,
+                self.old_sd, self.old_log_sd, self.grad_actor, self.grad_critic, scal, ws, idx=idx, mir_obs=self.mir_obs,
+                act_src=self.act_src, act_sign=self.act_sign, normalize_actor=self.fw.norm_a, normalize_critic=self.fw.norm_c,
+                clip=self.clip, vf_coeff=self.vf_coeff, mirror_coeff=self.mirror_coeff, parts=parts, gnorm_ws=self.adam_ws,
+                prepare=True)
+        launch(idx, scal)
+        self._norm_ready = True                             # adam_ws holds the squared-norm partials of these gradients
         return scal
 
-    def apply(self):
-        """clip_grad_norm_ + Adam.step on both networks and the re-pack of the stepped weights (ppo.py:399-410)."""
+    def apply(self, norm_ready=None):
+        """clip_grad_norm_ + Adam.step on both networks and the re-pack of the stepped weights (ppo.py:399-410).  After
+        the gradients were changed outside (an all-reduce over ranks) pass norm_ready=False: the norm is formed anew."""
         self.steps += 1
-        for nt, norm, (mean, std) in zip(self.nets, (self.fw.norm_a, self.fw.norm_c), self.fw.norm_tables()):
-            nt["in_mean"], nt["in_std"] = (mean, std) if norm else (None, None)
-        self.eng.ppo_adam_step(self.fw.in_dim, self.steps, self.lr, self.eps, self.max_grad_norm, self.nets, self.adam_ws,
-                               beta1=self.betas[0], beta2=self.betas[1])
+        ready = self._norm_ready if norm_ready is None else bool(norm_ready)
+        self._norm_ready = False
+        key = (self.fw.packed_a.data_ptr(), self.fw.norm_a, self.fw.norm_c)
+        if self._apply is None or self._apply[0] != key:
+            for nt, norm, (mean, std) in zip(self.nets, (self.fw.norm_a, self.fw.norm_c), self.fw.norm_tables()):
+                nt["in_mean"], nt["in_std"] = (mean, std) if norm else (None, None)
+            self._apply = (key, self.eng.ppo_adam_step(self.fw.in_dim, self.steps, self.lr, self.eps, self.max_grad_norm,
+                                                       self.nets, self.adam_ws, beta1=self.betas[0], beta2=self.betas[1],
+                                                       prepare=True))
+        self._apply[1](self.steps, ready)
 
     def step(self, observations, actions, returns, advantages, idx, scal=None):
         scal = self.grads(observations, actions, returns, advantages, idx, scal)
@@ -675,7 +692,7 @@ class PPO:
                         if multi_rank:
                             kernel.grads(observations, actions, ret_flat, adv_flat, idx, slot)
                             odist.allreduce_flat([kernel.grad_actor, kernel.grad_critic], weight=minibatch, total_weight=rows_all)
-                            kernel.apply()
+                            kernel.apply(norm_ready=False)      # the norm of the REDUCED gradients
                         else:
                             kernel.step(observations, actions, ret_flat, adv_flat, idx, slot)
                         stats.append(slot)

@@ -1345,29 +1345,31 @@ int oly_ppo_update_cpu(int B, int in_dim, int act_dim, int parts_actor, int part
 
 /* oly_ppo_adam_step's twin for ONE network: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step
  * (rl/algos/ppo.py:399-410; amsgrad off, no weight decay) on flat buffers, float32 per element in the kernel's
- * order; the squared norm as the kernel sums it: blocks of 512 elements, thread t takes elements t and 256 + t,
- * a 64-lane tree per wave, the four waves in order; the block partials b = l, l + 64, ... added in order into 64
- * sums, those by the same tree (fp64).                                                                     */
+ * order; the squared norm as the kernels sum it: blocks of 256 elements, lane l squares elements 4 l .. 4 l + 3 in
+ * order, a 64-lane tree per block; the block partials b = l, l + 64, ... added in order into 64 sums, those by the
+ * same tree (fp64).                                                                     */
 int oly_ppo_adam_step_cpu(int n, int step, float lr, float beta1, float beta2, float eps, float max_norm,
                           float* param, const float* grad, float* exp_avg, float* exp_avg_sq) {
   if (n <= 0 || step <= 0) return OLY_EINVAL;
-  const int blocks = (n + 511) / 512;
+  const int blocks = (n + 255) / 256;
   double part[64];                 /* lane l of the stepping kernel adds block partials l, l + 64, ... in order */
   for (int l = 0; l < 64; ++l) part[l] = 0.0;
   for (int b = 0; b < blocks; ++b) {
-    double wsum[4];
-    for (int w = 0; w < 4; ++w) {
-      double v[64];
-      for (int l = 0; l < 64; ++l) {
-        const long e0 = 512L * b + 64 * w + l, e1 = e0 + 256;
-        const double g0 = e0 < n ? (double)grad[e0] : 0.0, g1 = e1 < n ? (double)grad[e1] : 0.0;
-        v[l] = g0 * g0 + g1 * g1;
+    double v[64];                  /* a block: 256 elements, lane l squares elements 4 l .. 4 l + 3 in order */
+    for (int l = 0; l < 64; ++l) {
+      double sq = 0.0;
+      for (int i = 0; i < 4; ++i) {
+        const long e = 256L * b + 4 * l + i;
+        if (e < n) {
+          const double g = (double)grad[e];
+          sq += g * g;
+        }
       }
-      for (int off = 32; off > 0; off >>= 1)
-        for (int l = 0; l < off; ++l) v[l] += v[l + off];
-      wsum[w] = v[0];
+      v[l] = sq;
     }
-    part[b & 63] += ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+    for (int off = 32; off > 0; off >>= 1)
+      for (int l = 0; l < off; ++l) v[l] += v[l + off];
+    part[b & 63] += v[0];
   }
   for (int off = 32; off > 0; off >>= 1)          /* then the 64-lane tree */
     for (int l = 0; l < off; ++l) part[l] += part[l + off];

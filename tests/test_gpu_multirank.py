@@ -100,25 +100,26 @@ def test_bench_starts_its_own_ranks(config):
 
 
 @pytest.mark.parametrize("config", [2, 5])
-def test_bench_six_ranks_in_the_drivers_command_shape(config):
-    """The driver's multi-GPU command shape with as many ranks as one box may put on its GPU (six processes; the
-    8-rank all-gather / tree sum itself runs on the CPU in test_host_cpu.py::test_adv_stats_allgather_two_ranks_gloo[8]):
-    `bench.py --gpus 6` starts six ranks, the process group sees six, the ONE all-gather returns six triples, the
-    default command's line carries config5_tail."""
+def test_bench_five_ranks_in_the_drivers_command_shape(config):
+    """The driver's multi-GPU command shape with as many ranks as one box may put on its GPU next to the test process
+    itself (the pool admits six processes on a GPU: this pytest process, whose earlier tests hold a context, + five
+    ranks; the 8-rank all-gather / tree sum itself runs on the CPU in
+    test_host_cpu.py::test_adv_stats_allgather_two_ranks_gloo[8]): `bench.py --gpus 5` starts five ranks, the process
+    group sees five, the ONE all-gather returns five triples, the default command's line carries config5_tail."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--backend", "gloo",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--backend", "gloo",
                           "--share-device", "--config", str(config), "--steps", "3", "--warmup", "1",
                           "--T", "50", "--N", "1024", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 6 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["n_gpus"] == 5 and line["scaling"] == "weak" and line["value"] > 0
     tail = line if config == 5 else line["config5_tail"]
     assert "error" not in tail, tail
     if config == 5:
-        assert line["config"]["ranks_seen"] == 6
+        assert line["config"]["ranks_seen"] == 5
     else:
-        assert tail["ranks_seen"] == 6 and tail["gathered_rows"] == 6 and tail["backend"] == "gloo"
+        assert tail["ranks_seen"] == 5 and tail["gathered_rows"] == 5 and tail["backend"] == "gloo"
     assert set(tail["stages_ms"]) >= {"scan_with_fused_stats", "all_gather_host_wall", "normalise"}
 
 
