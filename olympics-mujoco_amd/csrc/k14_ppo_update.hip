@@ -19,11 +19,13 @@
 // part + parts, ...; at the end it stores its partial gradients in parameter order and a finishing launch adds the
 // parts (fp64, four contiguous groups in order, the group sums in order).  256 workgroups = one per CU, split between the networks by their work.
 //
-// Mirror-symmetry loss (ppo.py:261-268): an actor tile runs three sub-passes: forward of the mirrored rows (keeps
-// policy(mirror_obs) only), forward + loss + backward of the rows themselves (d mirror / d det joins d mu), forward
-// again + backward of the mirrored rows with d mirror / d mir.  The mirrored observations are an input array (the
-// env's own mirror_clock_observation, rl/envs/wrappers.py:59-72, evaluated once per iteration); mirror_action is
-// its (index, sign) table.
+// Mirror-symmetry loss (ppo.py:261-268): an actor tile then holds EIGHT rows of the minibatch (tile rows 0-7) and their
+// mirrored observations (tile rows 8-15), so one forward gives policy(obs) and policy(mirror_obs) of the same rows, the
+// loss wave pairs row m with row m + 8 (d mirror / d det joins d mu of row m, d mirror / d mir becomes the output gradient
+// of row m + 8), and ONE backward carries both.  The mirrored observations are an input array (the env's own
+// mirror_clock_observation, rl/envs/wrappers.py:59-72, evaluated once per iteration); mirror_action is its (index, sign)
+// table.  (Round 4's first form ran three sub-passes per tile: mirrored forward, rows forward + backward, mirrored forward
+// again + backward: 101 K cycles per 16 rows against 2 x 46 K.)
 //
 // Numerics (restated bit for bit by the oracle twin, oly_ppo_update_cpu): forward as K11; dH chains run over
 // the layer's output index ascending; a weight-gradient element is ONE f32 fma chain over the part's rows in
@@ -74,10 +76,10 @@ __device__ __forceinline__ float exp32(float x) {
 struct UpdNet {
   const float* packed;
   float* partials;        // [parts][pstride]: a part's gradients in parameter order; pstride = grad_floats rounded up to 4
-  int out_dim, normalize, parts, grad_floats, pstride;
+  int out_dim, normalize, parts, grad_floats, pstride, ntiles;   // ntiles: 16-row tiles of this network's work
 };
 struct UpdArgs {
-  int B, in_dim, act_dim, ntiles;
+  int B, in_dim, act_dim, pad_;
   const float *obs, *mir_obs, *action, *adv, *ret, *old_mu;
   const int* idx;
   UpdNet net[2];          // actor, critic
@@ -251,18 +253,20 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   }
   const float lo = 1.0f - p.clip, hi = 1.0f + p.clip;
 
-  const int my_tiles = (p.ntiles - part_id + parts - 1) / parts;
-  const int per_tile = mirror ? 3 : 1;
-  const int n_items = my_tiles * per_tile;
+  // A tile is 16 rows of the network's forward / backward.  With the mirror loss an actor tile holds EIGHT rows of the
+  // minibatch (tile rows 0-7) and their mirrored observations (tile rows 8-15: row m + 8 mirrors row m), so that one
+  // forward gives policy(obs) and policy(mirror_obs) of the same rows, the loss sees both, and one backward carries
+  // d loss / d mu and d loss / d mirror together (ppo.py:261-268).
+  const int rpt = mirror ? 8 : UR;                 // rows of the minibatch per tile
+  const int n_items = (net.ntiles - part_id + parts - 1) / parts;
 
-  // the input rows of work item `it` (tile, sub-pass): thread's two elements, normalised, zero-padded
+  // the input rows of work item `it`: thread's two elements (tile rows sm and sm + 8), normalised, zero-padded
   auto load_x = [&](int it, float (&v)[2]) {
-    const int tile = part_id + (it / per_tile) * parts;
-    const int sp = mirror ? it % 3 : 1;
-    const float* __restrict__ src = (sp == 1) ? p.obs : p.mir_obs;
+    const int tile = part_id + it * parts;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = tile * UR + sm + 8 * i;
+      const int row = mirror ? tile * 8 + sm : tile * UR + sm + 8 * i;
+      const float* __restrict__ src = (mirror && i == 1) ? p.mir_obs : p.obs;
       float x = 0.f;
       if (row < B && sk < in_dim) {
         const long r = p.idx ? (long)p.idx[row] : (long)row;
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   auto loss_fetch = [&](int tile_, float (&v)[10]) {
 #pragma unroll
     for (int q = 0; q < 10; ++q) v[q] = 0.f;
-    const int row = tile_ * UR + c;
-    if (tile_ < p.ntiles && row < B) {
+    const int row = tile_ * rpt + c;
+    if (tile_ < net.ntiles && c < rpt && row < B) {
       const long r = p.idx ? (long)p.idx[row] : (long)row;
       if (critic) {
         v[9] = p.ret[r];
@@ -348,13 +352,12 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   __syncthreads();
 
   for (int it = 0; it < n_items; ++it) {
-    const int tile = part_id + (it / per_tile) * parts;
-    const int sp = mirror ? it % 3 : 1;     // 0: mirrored rows, forward only; 1: the rows; 2: mirrored rows, forward + backward
+    const int tile = part_id + it * parts;
     const int pb = it & 1;
     const bool more = it + 1 < n_items;
     if (more) load_x(it + 1, xn);           // in flight behind this item's layers
-    const int grow = tile * UR + c;
-    const bool valid = grow < B;
+    const int grow = tile * rpt + c;        // wave 0's loss lane: row c of the tile (c >= rpt: a mirrored row)
+    const bool valid = c < rpt && grow < B;
     const float4* xA4 = reinterpret_cast<const float4*>(xA + pb * XI);
     const float4* xC4 = reinterpret_cast<const float4*>(xC + pb * XI);
     float4* h1C4 = reinterpret_cast<float4*>(h1C);
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
       u32x4 wb1[RD + 1][1];
       preload16b<2, 1>(rsP, voff, so3, wb1, P);
       layer_tiles16b<2, 1>(reinterpret_cast<const float4*>(h2A) + (size_t)(2 * wave) * 64, rsP, voff, so3, lane, acc, wb1, P);
-      if (sp != 0) preload16b<1, 2>(rsP, voff, so3t, wb, P);
+      preload16b<1, 2>(rsP, voff, so3t, wb, P);
 #pragma unroll
       for (int i = 0; i < 4; ++i) part[(wave * UR + 4 * j + i) * PP + c] = acc[0][i];
     }
@@ -426,13 +429,17 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
         for (int w = 0; w < 4; ++w) { sq.x += pq[w].x; sq.y += pq[w].y; sq.z += pq[w].z; sq.w += pq[w].w; }
         o[0] = sq.x + b3v[0]; o[1] = sq.y + b3v[1]; o[2] = sq.z + b3v[2]; o[3] = sq.w + b3v[3];
       }
-      if (sp == 0) {
+      if (mirror) {      // every row's means where the partner row's lanes can read them; the mirrored rows' gradients start at 0
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) mirL[c * 16 + 4 * j + cc] = o[cc];
-      } else if (sp == 2) {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) g[cc] = (4 * j + cc < out_dim) ? dmirL[c * 16 + 4 * j + cc] : 0.f;
-      } else if (critic) {
+        for (int cc = 0; cc < 4; ++cc) {
+          mirL[c * 16 + 4 * j + cc] = o[cc];
+          dmirL[c * 16 + 4 * j + cc] = 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      if (critic) {
         // critic_loss = vf_coeff * mse(ret, value)   (ppo.py:256)
         const float v = o[0];
         if (j == 0 && valid) {
@@ -498,27 +505,33 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
           if (col < out_dim && valid) {
             float gm = g_lp * t[cc] / sd2[cc];
             if (mirror) {
-              // (det - mirror_action(policy(mirror_obs)))^2 mean   (ppo.py:261-268); det = mu
-              const float d = o[cc] - msg[cc] * mirL[c * 16 + msrc[cc]];
+              // (det - mirror_action(policy(mirror_obs)))^2 mean   (ppo.py:261-268); det = mu; the mirrored row is tile row c + 8
+              const float d = o[cc] - msg[cc] * mirL[(c + 8) * 16 + msrc[cc]];
               mir_sq += (double)(d * d);
               const float gg = p.mirror_gscale * d;
               gm = gm + p.mirror_coeff * gg;
-              dmirL[c * 16 + msrc[cc]] = p.mirror_coeff * (-msg[cc] * gg);
+              dmirL[(c + 8) * 16 + msrc[cc]] = p.mirror_coeff * (-msg[cc] * gg);
             }
             g[cc] = gm;
-          } else if (mirror && col < out_dim) {
-            dmirL[c * 16 + msrc[cc]] = 0.f;
           }
         }
-        if (mirror) stL[3 * 64 + lane] += mir_sq;
-      }
-      if (sp != 0) {
+        if (mirror) {
+          stL[3 * 64 + lane] += mir_sq;
+          // the mirrored rows' lanes pick up d loss / d policy(mirror_obs) their partner rows have just left
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (c >= 8) {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int col = 4 * j + cc;
-          dz3A[act16_index(col, c)] = g[cc];
-          dz3C[c16_index(col, c)] = g[cc];
+            for (int cc = 0; cc < 4; ++cc) g[cc] = (4 * j + cc < out_dim) ? dmirL[c * 16 + 4 * j + cc] : 0.f;
+          }
         }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int col = 4 * j + cc;
+        dz3A[act16_index(col, c)] = g[cc];
+        dz3C[c16_index(col, c)] = g[cc];
       }
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -529,9 +542,9 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     OLY_STAMP(7);
     // wave 0: the next tile's loss inputs, requested behind this item's backward phases (the item before a tile's loss)
     float lnext[10];
-    const bool fetch_loss = wave == 0 && more && sp == (mirror ? 2 : 1);
+    const bool fetch_loss = wave == 0 && more;
     if (fetch_loss) loss_fetch(tile + parts, lnext);
-    if (sp != 0) {
+    {
       __syncthreads();
       OLY_STAMP(8);
       // ---- dH2 (own tiles) = dZ3 W3; dZ2 = dH2 [H2 > 0]; dW3 (own columns) += dZ3^T H2; dW2 (own rows) += dZ2^T H1
@@ -816,18 +829,21 @@ constexpr size_t upd_lds(int kt1) { return UPD_LDS_BASE + (size_t)16 * kt1 * 64 
 inline int grad_floats(int in_dim, int out_dim) { return HID * in_dim + HID + HID * HID + HID + out_dim * HID + out_dim; }
 inline int pad4(int n) { return (n + 3) & ~3; }
 
+// 16-row tiles of a network's work: with the mirror loss an actor tile holds eight rows of the minibatch and their mirrors
+inline int tiles_actor(int B, int mirror) { return mirror ? (B + 7) / 8 : (B + UR - 1) / UR; }
+inline int tiles_critic(int B) { return (B + UR - 1) / UR; }
+
 void choose_parts(const oly_ctx* ctx, int B, int mirror, int* pa, int* pc) {
-  const int ntiles = (B + UR - 1) / UR;
+  const int ta = tiles_actor(B, mirror), tc = tiles_critic(B);
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-  // a network's share of the workgroups follows its tile's measured cost (tools/time_k14.py, K cycles per 16-row tile):
-  // critic 41.4, actor 45.4 (its loss phase is longer), actor with the mirror loss 45.4 + a forward-only sub-pass 15 + a
-  // forward + backward sub-pass 40
-  const double wa = mirror ? 45.4 + 15.0 + 40.0 : 45.4, wc = 41.4;
+  // a network's share of the workgroups follows its work: tiles x the measured cost of a tile (tools/time_k14.py, K cycles
+  // per 16-row tile: critic 41.4, actor 45.4: its loss phase is longer)
+  const double wa = 45.4 * ta, wc = 41.4 * tc;
   int a = (int)(cus * wa / (wa + wc) + 0.5);
   a = a < 1 ? 1 : (a > cus - 1 ? cus - 1 : a);
   int cpart = cus - a;
-  *pa = ntiles < a ? ntiles : a;
-  *pc = ntiles < cpart ? ntiles : cpart;
+  *pa = ta < a ? ta : a;
+  *pc = tc < cpart ? tc : cpart;
 }
 
 }  // namespace
@@ -863,20 +879,20 @@ extern "C" int oly_ppo_update_grads(oly_ctx* ctx, const oly_ppo_update* u, oly_s
   if (!al16(u->packed_actor) || !al16(u->packed_critic) || !al16(u->ws))
     OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: packed streams and workspace must be 16-byte aligned");
   int pa = u->parts_actor, pc = u->parts_critic;
-  const int ntiles = (u->B + UR - 1) / UR;
+  const int nta = tiles_actor(u->B, mirror), ntc = tiles_critic(u->B);
   if (pa <= 0 || pc <= 0) choose_parts(ctx, u->B, mirror, &pa, &pc);
-  if (pa > ntiles || pc > ntiles) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: more parts (%d, %d) than 16-row tiles (%d)", pa, pc, ntiles);
+  if (pa > nta || pc > ntc) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: more parts (%d, %d) than 16-row tiles (%d, %d)", pa, pc, nta, ntc);
   const int gfa = grad_floats(u->in_dim, u->act_dim), gfc = grad_floats(u->in_dim, 1);
   const int psa = pad4(gfa), psc = pad4(gfc);
   const int64_t need = (int64_t)pa * psa + (int64_t)pc * psc + 2 * (int64_t)NSTAT * (pa + pc) + 4;
   if (u->ws_floats < need) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_grads: workspace of %lld floats, %lld needed", (long long)u->ws_floats, (long long)need);
   UpdArgs a;
-  a.B = u->B; a.in_dim = u->in_dim; a.act_dim = u->act_dim; a.ntiles = ntiles;
+  a.B = u->B; a.in_dim = u->in_dim; a.act_dim = u->act_dim; a.pad_ = 0;
   a.obs = u->obs; a.mir_obs = u->mir_obs; a.action = u->action; a.adv = u->adv; a.ret = u->ret; a.old_mu = u->old_mu;
   a.idx = u->idx;
   float* ws = u->ws;
-  a.net[0] = UpdNet{u->packed_actor, ws, u->act_dim, u->normalize_actor, pa, gfa, psa};
-  a.net[1] = UpdNet{u->packed_critic, ws + (size_t)pa * psa, 1, u->normalize_critic, pc, gfc, psc};
+  a.net[0] = UpdNet{u->packed_actor, ws, u->act_dim, u->normalize_actor, pa, gfa, psa, nta};
+  a.net[1] = UpdNet{u->packed_critic, ws + (size_t)pa * psa, 1, u->normalize_critic, pc, gfc, psc, ntc};
   size_t off = (size_t)pa * psa + (size_t)pc * psc;
   off = (off + 3) & ~(size_t)3;                    // doubles: 8-byte aligned (ws is 16-byte aligned)
   a.stat_partials = reinterpret_cast<double*>(ws + off);

@@ -1118,7 +1118,8 @@ int oly_rollout_cuts_cpu(int N, int max_traj_len, int last_step, const uint8_t* 
  * matrix cores evaluate them:
  *   forward     as oly_mlp_forward_cpu (k-ascending fmaf chains, the output layer as eight partial chains);
  *   loss        oly_ppo_loss_cpu's per-row arithmetic with exp -> oly_exp32_cpu and log(std) given; the mirror
- *               loss of oly_mirror_loss_cpu (ppo.py:261-268) with d mirror / d det joined to d mu;
+ *               loss of oly_mirror_loss_cpu (ppo.py:261-268) with d mirror / d det joined to d mu; with it an actor
+ *               tile is 8 rows of the minibatch (tile rows 0-7) + their mirrored observations (tile rows 8-15);
  *   dH          fmaf chain over the layer's output index ascending (padded to 16 for the output layer);
  *   dW, per part (tiles part, part + parts, ... of 16 rows): ONE fmaf chain over the part's rows in tile order,
  *               inside a tile rows 0,4,8,12,1,5,9,13,...; bias gradients as four running f32 sums per column
@@ -1174,7 +1175,9 @@ static int upd_network(int critic, int B, int in_dim, int out_dim, int parts, co
   const float inv_b = 1.0f / (float)B;
   const float gscale = (float)(2.0 / ((double)B * out_dim));
   const int mirror = !critic && mir_obs != NULL;
-  const int ntiles = (B + R - 1) / R;
+  /* with the mirror loss a tile holds 8 rows of the minibatch (tile rows 0-7) and their mirrored observations (8-15) */
+  const int rpt = mirror ? 8 : R;
+  const int ntiles = (B + rpt - 1) / rpt;
   const size_t oW1 = 0, ob1 = (size_t)H * in_dim, oW2 = ob1 + H, ob2 = oW2 + (size_t)H * H, oW3 = ob2 + H,
                ob3 = oW3 + (size_t)out_dim * H, gf = ob3 + out_dim;
   double* total = (double*)calloc(4 * gf, sizeof(double));      /* four group sums per element */
@@ -1191,31 +1194,21 @@ static int upd_network(int critic, int B, int in_dim, int out_dim, int parts, co
     float sb3[16][4];
     memset(sb3, 0, sizeof(sb3));
     for (int tile = part; tile < ntiles; tile += parts) {
-      float mir_out[R][16], dmir[R][16];
-      memset(mir_out, 0, sizeof(mir_out));
-      memset(dmir, 0, sizeof(dmir));
-      for (int sp = mirror ? 0 : 1; sp < (mirror ? 3 : 2); ++sp) {
+      {
         float out[R][16], dz3[R][16];
         memset(dz3, 0, sizeof(dz3));
         for (int m = 0; m < R; ++m) {
-          const int r = tile * R + m;
+          const int r = mirror ? tile * 8 + (m & 7) : tile * R + m;
           const float* xrow = NULL;
           if (r < B) {
             const size_t s = idx ? (size_t)idx[r] : (size_t)r;
-            xrow = (sp == 1 ? obs : mir_obs) + s * in_dim;
+            xrow = ((mirror && m >= 8) ? mir_obs : obs) + s * in_dim;
           }
           upd_forward(nw, in_dim, out_dim, xrow, xin + m * 64, h1 + m * H, h2 + m * H, out[m]);
         }
-        if (sp == 0) {
-          memcpy(mir_out, out, sizeof(out));
-          continue;
-        }
-        if (sp == 2) {
-          for (int m = 0; m < R; ++m)
-            for (int j = 0; j < out_dim; ++j) dz3[m][j] = dmir[m][j];
-        } else {
-          for (int m = 0; m < R; ++m) {
-            const int r = tile * R + m;
+        {
+          for (int m = 0; m < rpt; ++m) {
+            const int r = tile * rpt + m;
             if (r >= B) continue;
             const size_t s = idx ? (size_t)idx[r] : (size_t)r;
             if (critic) {
@@ -1248,11 +1241,11 @@ static int upd_network(int critic, int B, int in_dim, int out_dim, int parts, co
               if (mirror) {
                 const int i = act_src[j];
                 const float sg = act_sign[j];
-                const float d = out[m][j] - sg * mir_out[m][i];
+                const float d = out[m][j] - sg * out[m + 8][i];     /* the mirrored row is tile row m + 8 */
                 stats[3] += (double)(d * d);
                 const float gg = gscale * d;
                 gm = gm + mirror_coeff * gg;
-                dmir[m][i] = mirror_coeff * (-sg * gg);
+                dz3[m + 8][i] = mirror_coeff * (-sg * gg);
               }
               dz3[m][j] = gm;
             }
