@@ -74,6 +74,22 @@ def test_ppo_update_kernel_equals_the_oracle(eng, oracle, n, B, mirror, normaliz
     np.testing.assert_allclose(scal, os_, rtol=1e-12, atol=1e-15)
 
 
+@pytest.mark.parametrize("in_dim,act_dim,mirror", [(10, 3, True), (16, 16, False), (30, 16, True), (49, 7, False), (64, 12, True)])
+def test_ppo_update_kernel_other_network_widths(eng, oracle, in_dim, act_dim, mirror):
+    """Every instantiation of the kernel (1 - 4 groups of 16 inputs) and action widths up to the loss wave's 16 columns:
+    bit-exact against the oracle, and the oracle against torch autograd."""
+    c = ppo_update_case(in_dim + act_dim, n=70, in_dim=in_dim, act_dim=act_dim, mirror=mirror)
+    idx = np.random.default_rng(3).permutation(70)[:53].astype(np.int32)
+    ga, gc, scal, used = run_kernel(eng, c, idx, mirror, (2, 3))
+    oa, oc, os_ = oracle_update(oracle, c, idx, mirror, used)
+    assert np.array_equal(ga, oa) and np.array_equal(gc, oc)
+    np.testing.assert_allclose(scal, os_, rtol=1e-12, atol=1e-15)
+    ta, tc, ts = torch_ppo_update_grads(c, idx=idx, mirror_coeff=0.4 if mirror else None)
+    np.testing.assert_allclose(scal, ts, rtol=3e-5, atol=3e-7)
+    assert_grads_close(ga, ta, in_dim, act_dim, GRAD_RTOL)
+    assert_grads_close(gc, tc, in_dim, 1, GRAD_RTOL)
+
+
 def test_ppo_update_kernel_larger_minibatch_equals_the_oracle(eng, oracle):
     """2085 gathered rows of a 6000-row buffer with the plan's own split (131 tiles over 128 + 128 workgroups)."""
     c = ppo_update_case(5, n=6000, mirror=True)

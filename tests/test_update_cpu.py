@@ -69,6 +69,21 @@ def test_ppo_update_oracle_gradients_match_torch_autograd(oracle, n, B, mirror, 
     assert np.abs(ga).max() > 0 and np.abs(gc).max() > 0
 
 
+@pytest.mark.parametrize("in_dim,act_dim,mirror", [(10, 3, True), (16, 16, False), (30, 16, True), (49, 7, False), (64, 12, True)])
+def test_ppo_update_oracle_other_network_widths(oracle, in_dim, act_dim, mirror):
+    """1 - 4 groups of 16 inputs, action widths up to 16: the oracle twin against torch autograd."""
+    c = ppo_update_case(in_dim + act_dim, n=70, in_dim=in_dim, act_dim=act_dim, mirror=mirror)
+    idx = np.random.default_rng(3).permutation(70)[:53].astype(np.int32)
+    kw = dict(mir_obs=c["mir_obs"], act_src=c["act_src"], act_sign=c["act_sign"]) if mirror else {}
+    ga, gc, scal = oracle.ppo_update(c["obs"], c["action"], c["adv"], c["ret"], c["old_mu"], c["actor"], c["critic"], c["sd"],
+                                     idx=idx, a_mean=c["a_mean"], a_std=c["a_std"], clip=0.2, vf_coeff=0.5, mirror_coeff=0.4,
+                                     parts_actor=2, parts_critic=3, **kw)
+    ta, tc, ts = torch_ppo_update_grads(c, idx=idx, mirror_coeff=0.4 if mirror else None)
+    np.testing.assert_allclose(scal, ts, rtol=3e-5, atol=3e-7)
+    assert_grads_close(ga, ta, in_dim, act_dim)
+    assert_grads_close(gc, tc, in_dim, 1)
+
+
 def test_ppo_update_oracle_part_count_changes_only_the_last_bits(oracle):
     """The split of the tiles over workgroups is a summation order: results agree to float32 rounding, and a
     single tile (B <= 16) does not depend on it at all."""
