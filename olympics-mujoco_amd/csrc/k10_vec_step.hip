@@ -164,13 +164,13 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
   // (the noise row eps[t] is touched for the first time here: its HBM latency hides behind the whole step)
   constexpr int ACT_PT = (EPW * MAX_NU + THREADS - 1) / THREADS;       // action elements per thread
   constexpr int OBS_PT = (EPW * MAX_NOBS + THREADS - 1) / THREADS;     // observation elements per thread
-  float pt_act[ACT_PT], pt_obs[OBS_PT], pt_val = 0.f;
+  float pt_act[ACT_PT], pt_mu[ACT_PT], pt_obs[OBS_PT], pt_val = 0.f;
   if (!reset_all) {
     const bool det = p.ro.deterministic != 0;
 #pragma unroll
     for (int q = 0; q < ACT_PT; ++q) {
       const int e = tid + q * THREADS;
-      pt_act[q] = 0.f;
+      pt_act[q] = pt_mu[q] = 0.f;
       if (e < rows * nu) {
         const int r = e / nu, j = e - r * nu;
         const size_t nn = (size_t)(row0 + r);
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
           a = mu + sc;
         }
         pt_act[q] = a;
+        pt_mu[q] = mu;
       }
     }
 #pragma unroll
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(THREADS) void a3_vec_kernel(VecArgs p) {
         const int r = e / nu, j = e - r * nu;
         const size_t nn = (size_t)(row0 + r);
         p.ro.buf_actions[(tN + nn) * nu + j] = pt_act[q];
+        if (p.ro.buf_mu) p.ro.buf_mu[(tN + nn) * nu + j] = pt_mu[q];
         p.ro.pd_target[nn * nu + j] = (double)pt_act[q] + m->motor_offset[j];
       }
     }

@@ -356,6 +356,7 @@ __global__ __launch_bounds__(THREADS_S, 1) void a3_rollout_kernel(RollArgs p) {
           a = s + scl;
         }
         p.ro.buf_actions[(tN + row0) * nu + rtid_t] = a;
+        if (p.ro.buf_mu) p.ro.buf_mu[(tN + row0) * nu + rtid_t] = s;
         if (last_step) {
           p.ro.pd_target[(size_t)row0 * nu + rtid_t] = (double)a + m->motor_offset[a_col];
           if (p.mu_out) p.mu_out[(size_t)row0 * nu + rtid_t] = s;

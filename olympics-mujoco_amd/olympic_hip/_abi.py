@@ -86,7 +86,7 @@ class A3Rollout(C.Structure):
                 ("buf_rew6", vp), ("traj_len", vp),
                 ("side_slots", C.c_int32), ("pad1", C.c_int32), ("side_obs", vp), ("side_t", vp), ("side_count", vp),
                 ("pool_depth", C.c_int32), ("pad2", C.c_int32), ("pool", vp), ("pool_count", vp),
-                ("ctr", vp)]
+                ("ctr", vp), ("buf_mu", vp)]
 
 
 VSTEP_RESET_ALL = 1
@@ -116,7 +116,7 @@ A3_PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(A3Re
 
 # name -> (restype, argtypes); device/host pointers are void*.
 STD_SCALAR, STD_PER_DIM, STD_FULL = 0, 1, 2
-ABI_VERSION = 5          # OLY_ABI_VERSION of include/olympic_hip.h this table mirrors
+ABI_VERSION = 6          # OLY_ABI_VERSION of include/olympic_hip.h this table mirrors
 
 
 class AdamNet(C.Structure):

@@ -327,7 +327,7 @@ class Engine:
           ro:     dict with T, max_traj_len, deterministic, side_slots, pool_depth (ints) and the
                   tensors mu, value, scale, eps, state, pd_target, buf_states, buf_actions,
                   buf_rewards, buf_values, buf_flags, buf_rew6 (or None), traj_len, side_obs, side_t,
-                  side_count, pool (uint8 [N*pool_depth*656]), pool_count, ctr."""
+                  side_count, pool (uint8 [N*pool_depth*656]), pool_count, ctr, buf_mu (or None)."""
         sp = self.a3_spec
         if sp is None or not self.contact_ok:
             raise OlyError("a3_vec_prepare before a3_configure / contact_configure")
@@ -355,8 +355,8 @@ class Engine:
                     buf_flags=((T, N), u8), buf_rew6=((T, N, 6), f32), traj_len=((N,), i32),
                     side_obs=((N * slots, nobs), f32), side_t=((N * slots,), i32), side_count=((N,), i32),
                     pool=((N * depth * C.sizeof(_abi.A3ResetRecord),), u8), pool_count=((N,), i32),
-                    ctr=((self.a3_vec_ctr_len(N),), i32))
-        optional = {"buf_rew6"} | ({"scale", "eps"} if det else set())
+                    ctr=((self.a3_vec_ctr_len(N),), i32), buf_mu=((T, N, nu), f32))
+        optional = {"buf_rew6", "buf_mu"} | ({"scale", "eps"} if det else set())
         for name, (shape, dt) in spec.items():
             tns = _req(ro.get(name), name, shape, dt, dv, optional=name in optional)
             setattr(cr, name, None if tns is None else tns.data_ptr())

@@ -186,6 +186,7 @@ class KernelUpdate:
         self.steps = 0
         self._ws, self._launch, self._apply, self._norm_ready = {}, {}, None, False
         self.old_mu = self.mir_obs = None
+        self._old_mu_buf = None
 
     @staticmethod
     def supports(policy, critic, act_mirr_is_table):
@@ -200,8 +201,12 @@ class KernelUpdate:
         return sd, torch.log(sd)
 
     @torch.no_grad()
-    def begin(self, observations):
-        """Once per iteration, after old_policy.load_state_dict(policy.state_dict())."""
+    def begin(self, observations, sampled_mu=None):
+        """Once per iteration, after old_policy.load_state_dict(policy.state_dict()).  `sampled_mu` [n, act_dim]: the
+        means the sampling policy produced for these rows with the fused forward's arithmetic (the rollout kernels store
+        them).  The old policy of this update phase IS the sampling policy (ppo.py:341), so they are taken as
+        old_policy(obs) when the two modules' input normalisation tables agree as well; otherwise (or without them) the
+        old policy runs over the buffer once (K11)."""
         from .mlp import FusedMLPForward
         self.fw.refresh()
         self.nets[0]["packed"], self.nets[1]["packed"] = self.fw.packed_a, self.fw.packed_c
@@ -210,9 +215,17 @@ class KernelUpdate:
         else:
             self.fw_old.refresh()
         n = int(observations.shape[0])
-        if self.old_mu is None or self.old_mu.shape[0] != n:
-            self.old_mu = torch.empty((n, self.fw.act_dim), dtype=torch.float32, device=self.eng.device)
-        self.eng.mlp_forward2(observations, self.fw_old.packed_a, self.fw.act_dim, self.old_mu, normalize_a=True)
+        reuse = (sampled_mu is not None and tuple(sampled_mu.shape) == (n, self.fw.act_dim) and sampled_mu.is_contiguous()
+                 and self.fw_old.norm_a == self.fw.norm_a
+                 and all(a is b or (a is not None and b is not None and torch.equal(a, b))
+                         for a, b in zip(self.fw_old.norm_tables()[0], self.fw.norm_tables()[0])))
+        if reuse:
+            self.old_mu = sampled_mu
+        else:
+            if self._old_mu_buf is None or self._old_mu_buf.shape[0] != n:
+                self._old_mu_buf = torch.empty((n, self.fw.act_dim), dtype=torch.float32, device=self.eng.device)
+            self.old_mu = self._old_mu_buf
+            self.eng.mlp_forward2(observations, self.fw_old.packed_a, self.fw.act_dim, self.old_mu, normalize_a=True)
         self.mir_obs = self.obs_mirr(observations).to(torch.float32).contiguous() if self.obs_mirr is not None else None
         self.sd, self.log_sd = self._std(self.policy)
         self.old_sd, self.old_log_sd = self._std(self.old_policy)
@@ -657,7 +670,8 @@ class PPO:
                                         self.mirror_coeff, obs_mirr, act_src, act_sign, lr=self.lr, eps=self.eps,
                                         max_grad_norm=self.grad_clip)
                 kernel = kupd
-                kernel.begin(observations)
+                kernel.begin(observations, buf.mu.reshape(n, -1) if getattr(buf, "mu", None) is not None
+                             and getattr(buf, "mu_from_fused_forward", False) else None)
                 kstats = torch.zeros((self.epochs * max(n_batches, 1), 6), dtype=torch.float64, device=observations.device)
                 adv_flat, ret_flat = advantages.reshape(-1).contiguous(), returns.reshape(-1).contiguous()
             elif use_graph and fused:

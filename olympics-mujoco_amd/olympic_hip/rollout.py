@@ -33,6 +33,8 @@ class RolloutBuffer:
         self.flags = torch.zeros((T, N), dtype=torch.uint8, device=device)
         self.returns = torch.empty((T, N), **f32)
         self.advantages = torch.empty((T, N), **f32)
+        self.mu = None                       # [T,N,act_dim] policy means, when the sampler stores them (vecstep.DeviceRollout)
+        self.mu_from_fused_forward = False
         self.ptr = 0
 
     def store(self, state, action, reward, value):

@@ -178,6 +178,8 @@ class A3DeviceRollout:
         nv = torch.zeros(T * N + 1, dtype=torch.float32, device=dev)      # + one dummy slot for unused side rows
         self._nv_flat, self.buf.next_values = nv, nv[:T * N].view(T, N)
         self.rew6 = torch.zeros((T, N, 6), dtype=torch.float32, device=dev) if self.keep_rew6 else None
+        # the policy mean behind every stored action: the update phase's old_policy(obs) (ppo.py:236-237, 341)
+        self.buf.mu = torch.empty((T, N, sp.nu), dtype=torch.float32, device=dev)
         self.eps = None if deterministic else torch.empty((T, N, sp.nu), dtype=torch.float32, device=dev)
         self.slots = T // max(1, max_traj_len) + 2            # time-limit cuts + the block end, per environment
         self.side_obs = torch.zeros((N * self.slots, sp.n_obs), dtype=torch.float32, device=dev)
@@ -192,7 +194,7 @@ class A3DeviceRollout:
                   buf_actions=self.buf.actions, buf_rewards=self.buf.rewards, buf_values=self.buf.values,
                   buf_flags=self.buf.flags, buf_rew6=self.rew6, traj_len=self.traj_len, side_obs=self.side_obs,
                   side_t=self.side_t, side_count=self.side_count, pool=self.pool, pool_count=self.pool_count,
-                  ctr=self.ctr)
+                  ctr=self.ctr, buf_mu=self.buf.mu)
         self.launch = self.eng.a3_vec_prepare(self.blocks, self.env.state, ro)
         self._shape = key
 
@@ -222,6 +224,7 @@ class A3DeviceRollout:
         self.launch(_abi.VSTEP_RESET_ALL)
         from .mlp import FusedMLPForward
         fused = isinstance(fw, FusedMLPForward)
+        buf.mu_from_fused_forward = fused                     # K11 / K13 arithmetic: bit-identical to a later oly_mlp_forward2
         if persistent is None:
             persistent = fused
         if persistent:

@@ -524,6 +524,7 @@ int oly_a3_vec_step_cpu(const oly_a3_model* m, int ngeom, const int32_t* geom_bo
           a = mu + sc;
         }
         ro->buf_actions[(tN + n) * nu + j] = a;
+        if (ro->buf_mu) ro->buf_mu[(tN + n) * nu + j] = mu;
         ro->pd_target[(size_t)n * nu + j] = (double)a + m->motor_offset[j];
       }
       memcpy(ro->buf_states + (tN + n) * n_obs, ro->state + (size_t)n * n_obs, sizeof(float) * n_obs);

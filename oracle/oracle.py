@@ -191,7 +191,7 @@ def a3_vec_step(spec, clock_lut, contact, blocks, state, ro, flags=0):
     cr.side_slots, cr.pool_depth = int(ro["side_slots"]), int(ro["pool_depth"])
     for name in ("mu", "value", "scale", "eps", "state", "pd_target", "buf_states", "buf_actions", "buf_rewards",
                  "buf_values", "buf_flags", "buf_rew6", "traj_len", "side_obs", "side_t", "side_count", "pool",
-                 "pool_count", "ctr"):
+                 "pool_count", "ctr", "buf_mu"):
         a = ro.get(name)
         if a is not None:
             assert a.flags["C_CONTIGUOUS"], name

@@ -281,7 +281,7 @@ def check_persistent_rollout_against_oracle(eng, orc, N=70, T=12, max_len=5, K=5
               buf_values=np.zeros((T, N), np.float32), buf_flags=np.zeros((T, N), np.uint8), buf_rew6=None,
               traj_len=z(np.int32), side_obs=np.zeros((N * slots, nobs), np.float32), side_t=np.full(N * slots, -1, np.int32),
               side_count=z(np.int32), pool=pool.view(np.uint8).reshape(-1).copy(), pool_count=z(np.int32),
-              ctr=np.array([0, 2], np.int32))
+              ctr=np.array([0, 2], np.int32), buf_mu=np.full((T, N, nu), np.nan, np.float32))
     wa = [rng.normal(0, s, sh).astype(np.float32) for s, sh in ((0.2, (256, nobs)), (0.1, (256,)), (0.08, (256, 256)), (0.1, (256,)),
                                                                  (0.05, (nu, 256)), (0.1, (nu,)))]
     wc = [rng.normal(0, s, sh).astype(np.float32) for s, sh in ((0.2, (256, nobs)), (0.1, (256,)), (0.08, (256, 256)), (0.1, (256,)),
@@ -317,6 +317,7 @@ def check_persistent_rollout_against_oracle(eng, orc, N=70, T=12, max_len=5, K=5
         orc.a3_vec_step(spec, lut, contact, blocks, state, ro, 0)
         assert np.array_equal(got["buf_values"][t], val), ("value", t)
         assert np.array_equal(got["buf_actions"][t], ro["buf_actions"][t]), ("action", t)
+        assert np.array_equal(got["buf_mu"][t], mu) and np.array_equal(ro["buf_mu"][t], mu), ("mean", t)
         assert np.array_equal(got["buf_flags"][t], ro["buf_flags"][t]), ("flags", t)
         np.testing.assert_allclose(got["buf_rewards"][t], ro["buf_rewards"][t], rtol=1e-11, atol=1e-13)
     assert np.array_equal(h(mu_out), ro["mu"]) and np.array_equal(h(value_out), ro["value"])     # the last step's forward

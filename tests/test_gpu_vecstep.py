@@ -298,7 +298,7 @@ def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K, C)
             torch.manual_seed(11 + it)                            # the action noise block
             env.device_rollout(pi, vf, T, max_len, deterministic=det, anneal=0.7, graph=False, persistent=persistent)
             r = env._dev_rollout
-            named = dict(states=r.buf.states, actions=r.buf.actions, rewards=r.buf.rewards, values=r.buf.values,
+            named = dict(states=r.buf.states, actions=r.buf.actions, means=r.buf.mu, rewards=r.buf.rewards, values=r.buf.values,
                          next_values=r.buf.next_values, flags=r.buf.flags, state_obs=r.state_obs, pd_target=r.pd_target,
                          traj_len=r.traj_len, side_obs=r.side_obs, side_t=r.side_t, side_count=r.side_count,
                          pool_count=r.pool_count, ctr=r.ctr, mu=r._fw.outputs(N)[0], value=r._fw.outputs(N)[1])
@@ -309,6 +309,12 @@ def test_persistent_rollout_equals_the_two_kernel_loop(N, T, max_len, det, K, C)
         for name in a:
             assert a[name].dtype == b[name].dtype and torch.equal(a[name], b[name]), name
         assert ia == ib and ka == kb
+    # the stored means are the old policy's forward over the stored observations, to the bit: what the update phase
+    # takes as old_mu instead of running the old policy over the buffer again (ppo.KernelUpdate.begin)
+    r = env._dev_rollout
+    again = torch.empty((T * N, 12), dtype=torch.float32, device="cuda")
+    env.eng.mlp_forward2(r.buf.states.reshape(T * N, -1), r._fw.packed_a, 12, again, normalize_a=True)
+    assert r.buf.mu_from_fused_forward and torch.equal(r.buf.mu.reshape(T * N, 12), again)
     last = (out[1][0][0]["flags"] & _abi.FLAG_LAST).bool()
     assert bool(last[-1].all()) and (N < 32 or int(last[:-1].sum()) > 0), "the case must exercise device-side resets"
     assert env._dev_rollout._fw.norm_c == bool(N % 2)
@@ -673,7 +679,7 @@ def test_persistent_rollout_random_configurations(seed):
         torch.manual_seed(100 + seed)
         env.device_rollout(pi, vf, T, max_len, deterministic=det, anneal=0.6, graph=False, persistent=persistent)
         r = env._dev_rollout
-        named = dict(states=r.buf.states, actions=r.buf.actions, rewards=r.buf.rewards, values=r.buf.values,
+        named = dict(states=r.buf.states, actions=r.buf.actions, means=r.buf.mu, rewards=r.buf.rewards, values=r.buf.values,
                      next_values=r.buf.next_values, flags=r.buf.flags, rew6=r.rew6, state_obs=r.state_obs,
                      pd_target=r.pd_target, traj_len=r.traj_len, side_obs=r.side_obs, side_t=r.side_t,
                      side_count=r.side_count, ctr=r.ctr)
