@@ -743,23 +743,35 @@ __global__ __launch_bounds__(256) void ppo_update_finish_kernel(FinArgs f, int b
     sq = wave_sum(sq);
     if (f.gnorm && lane == 0) f.gnorm[n * ADAM_MAX_BLOCKS + ((int)blockIdx.x - (n ? blocks_a : 0))] = sq;
   }
-  if (blockIdx.x == 0 && threadIdx.x < NSTAT) {
+  if (blockIdx.x != 0) return;
+  // the six scalars: every workgroup's partial, added in workgroup order (one fp64 chain per scalar).  The partials are
+  // fetched by all 256 threads at once and the chains run out of LDS: as plain global loads inside the chains they were
+  // `total` dependent memory round trips on ONE wave, the longest path of the whole launch.
+  __shared__ double stage[256 * NSTAT];
+  const int total = f.net[0].parts + f.net[1].parts;
+  double st = 0.0;
+  for (int b0 = 0; b0 < total; b0 += 256) {
+    const int nb = min(256, total - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * NSTAT; i += 256) stage[i] = f.stat_partials[(size_t)b0 * NSTAT + i];
+    __syncthreads();
+    if (threadIdx.x < NSTAT)
+      for (int b = 0; b < nb; ++b) st += stage[b * NSTAT + threadIdx.x];
+  }
+  if (threadIdx.x < NSTAT) {
     const int qq = threadIdx.x;
-    double s = 0.0;
-    const int total = f.net[0].parts + f.net[1].parts;
-    for (int b = 0; b < total; ++b) s += f.stat_partials[(size_t)b * NSTAT + qq];
     const double invB = 1.0 / (double)f.B;
     // scal_out: actor, entropy_penalty, critic, approx_kl, mirror, clip_fraction
-    if (qq == 0) f.scal_out[0] = -s * invB;
-    if (qq == 1) f.scal_out[3] = s * invB;
-    if (qq == 2) f.scal_out[5] = s * invB;
-    if (qq == 3) f.scal_out[4] = f.mirror ? s / ((double)f.B * f.act_dim) : 0.0;
-    if (qq == 4) f.scal_out[2] = (double)f.vf_coeff * s * invB;
+    if (qq == 0) f.scal_out[0] = -st * invB;
+    if (qq == 1) f.scal_out[3] = st * invB;
+    if (qq == 2) f.scal_out[5] = st * invB;
+    if (qq == 3) f.scal_out[4] = f.mirror ? st / ((double)f.B * f.act_dim) : 0.0;
+    if (qq == 4) f.scal_out[2] = (double)f.vf_coeff * st * invB;
     if (qq == 5) {
       // entropy of a fixed-std Gaussian: the same f32 row value for every row (Normal.entropy: 0.5 + 0.5 log(2 pi) + log(std))
       float ent = 0.f;
       for (int a = 0; a < f.act_dim; ++a) ent += (0.5f + LOG_SQRT_2PI) + f.log_sd[a];
-      f.scal_out[1] = -(s * (double)ent) / ((double)f.B * f.act_dim);
+      f.scal_out[1] = -(st * (double)ent) / ((double)f.B * f.act_dim);
     }
   }
 }
