@@ -39,6 +39,23 @@ def main():
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
     odist.allreduce_gradients(list(net.parameters()))
     res["g_after_allreduce"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    # unequal minibatches: rank r holds rows_r = 3 + 2 r rows of one data set; the row-weighted all-reduce of the ranks'
+    # mean-loss gradients is the gradient of the mean loss over the CONCATENATED rows (what one learner would see),
+    # through both entry points (module .grad lists and ppo.KernelUpdate's flat buffers)
+    rows = [3 + 2 * r for r in range(world)]
+    lo = sum(rows[:rank])
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(sum(rows), 5, generator=g), torch.randn(sum(rows), 2, generator=g)
+    net.zero_grad()
+    torch.nn.functional.mse_loss(net(X[lo:lo + rows[rank]]), Y[lo:lo + rows[rank]]).backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+    odist.allreduce_gradients(list(net.parameters()), weight=rows[rank], total_weight=sum(rows))
+    odist.allreduce_flat([flat], weight=rows[rank], total_weight=sum(rows))
+    res["g_weighted"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    res["g_weighted_flat"] = flat.numpy()
+    net.zero_grad()
+    torch.nn.functional.mse_loss(net(X), Y).backward()
+    res["g_concatenated"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
     np.savez(os.path.join(out, f"rank{rank}.npz"), **res)
     if rank == 0:
         np.save(os.path.join(out, "full.npy"), adv.astype(np.float64))

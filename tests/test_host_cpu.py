@@ -294,6 +294,10 @@ def test_adv_stats_allgather_two_ranks_gloo(tmp_path, world):
     want = np.concatenate([np.full(n, mean_rank * (i + 1), np.float32) for i, n in enumerate((35, 7, 14, 2))])
     for r in rs:
         np.testing.assert_allclose(r["g_after_allreduce"], want, rtol=1e-6)
+    # ranks with DIFFERENT minibatch sizes (3, 5, 7, ... rows): the row-weighted mean is the concatenated batch's gradient
+    for r in rs:
+        assert np.array_equal(r["g_weighted"], r0["g_weighted"]) and np.array_equal(r["g_weighted_flat"], r0["g_weighted"])
+        np.testing.assert_allclose(r["g_weighted"], r["g_concatenated"], rtol=2e-5, atol=1e-7)
 
 
 # ------------------------------------------------------------------------------ A3 host side
