@@ -103,10 +103,6 @@ __global__ void mlp_pack_kernel(PackLayout L, const float* __restrict__ W1, cons
   pack_stream(p, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
-// two networks in one launch (blockIdx.y): the re-pack after an optimiser step (oly_ppo_adam_step)
-__global__ void mlp_pack2_kernel(PackSrc a, PackSrc b) {
-  pack_stream(blockIdx.y ? b : a, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
-}
 
 struct MlpNet {
   const float* packed;
@@ -307,24 +303,6 @@ extern "C" int oly_mlp_pack(oly_ctx* ctx, int in_dim, int hidden, int out_dim, c
   hipLaunchKernelGGL(mlp_pack_kernel, dim3(128), dim3(256), 0, oly_s(stream), L, w1, b1, w2, b2, w3, b3, in_mean,
                      in_std, packed);
   OLY_LAUNCH_CHECK(ctx, "mlp_pack_kernel");
-  return OLY_OK;
-}
-
-// flat parameter buffers (W1 | b1 | W2 | b2 | W3 | b3, torch order) of two networks -> their packed streams, ONE launch
-int oly_mlp_pack_pair(oly_ctx* ctx, int in_dim, const int out_dim[2], const float* const flat[2], const float* const mean[2],
-                      const float* const std[2], float* const packed[2], oly_stream stream) {
-  PackSrc src[2];
-  for (int n = 0; n < 2; ++n) {
-    if (in_dim <= 0 || in_dim > MAX_IN || out_dim[n] <= 0 || out_dim[n] > MAX_OUT || !flat[n] || !packed[n] ||
-        (reinterpret_cast<uintptr_t>(packed[n]) & 15) != 0)
-      OLY_FAIL(ctx, OLY_EINVAL, "oly_mlp_pack_pair: bad argument for network %d", n);
-    const float* p = flat[n];
-    const size_t ob1 = (size_t)HID * in_dim, oW2 = ob1 + HID, ob2 = oW2 + (size_t)HID * HID, oW3 = ob2 + HID,
-                 ob3 = oW3 + (size_t)out_dim[n] * HID;
-    src[n] = PackSrc{pack_layout(in_dim, out_dim[n]), p, p + ob1, p + oW2, p + ob2, p + oW3, p + ob3, mean[n], std[n], packed[n]};
-  }
-  hipLaunchKernelGGL(mlp_pack2_kernel, dim3(128, 2), dim3(256), 0, oly_s(stream), src[0], src[1]);
-  OLY_LAUNCH_CHECK(ctx, "mlp_pack2_kernel");
   return OLY_OK;
 }
 

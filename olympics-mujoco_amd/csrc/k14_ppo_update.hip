@@ -778,13 +778,16 @@ __global__ __launch_bounds__(256) void ppo_update_finish_kernel(FinArgs f, int b
 
 // ---------------------------------------------------------------------------------------------------------------
 // The optimiser half of the update (rl/algos/ppo.py:396-410): torch.nn.utils.clip_grad_norm_ + Adam.step for both
-// networks on flat parameter / gradient / moment buffers, then the re-pack of the stepped weights: three launches
-// instead of torch's ~60 (the foreach Adam and the norm clip are ~30 small kernels per network; at every minibatch
-// size the host could not issue them as fast as the GPU ran them).
+// networks on flat parameter / gradient / moment buffers, the stepped value written straight to its places in the
+// packed streams: ONE launch instead of torch's ~60 (the foreach Adam and the norm clip are ~30 small kernels per
+// network; at every minibatch size the host could not issue them as fast as the GPU ran them).
 struct AdamNet {
   float *param, *exp_avg, *exp_avg_sq;
   const float* grad;
-  int n, blocks;          // elements; 512-element blocks of the norm pass
+  int n, blocks;          // elements; 256-element blocks of the norm pass
+  float* packed;          // the network's oly_mlp_pack stream (or NULL)
+  const float *mean, *std;
+  int in_dim, out_dim;
 };
 struct AdamArgs {
   AdamNet net[2];
@@ -811,6 +814,47 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(AdamArgs a, int wgs_a) 
   if ((threadIdx.x & 63) == 0 && blk < nt.blocks) a.sumsq[n * ADAM_MAX_BLOCKS + blk] = sq;
 }
 
+// Where parameter i of the flat order W1 [256, in] | b1 | W2 [256, 256] | b2 | W3 [out, 256] | b3 lives in the packed
+// stream (the inverse of k11_mlp.hip's pack_stream): every weight has one place per operand role, i.e. the 32-column
+// stream (K11), the 16-column stream (K13 / K14 forward) and, for W2 / W3, the transposed-role stream (K14 backward).
+__device__ __forceinline__ void scatter_packed(const PackLayout& L, float* __restrict__ out, long i, float p) {
+  const long ob1 = (long)HID * L.in_dim, oW2 = ob1 + HID, ob2 = oW2 + (long)HID * HID, oW3 = ob2 + HID, ob3 = oW3 + (long)L.out_dim * HID;
+  // P32[tile][g][lane][q] = W[n = 32 tile + (lane & 31)][k = 2 (4 g + q) + (lane >> 5)]
+  auto e32 = [](size_t base, int groups, int n, int k) {
+    const int kk = k >> 1;
+    return base + (((size_t)((n >> 5) * groups + (kk >> 2)) * 64 + ((n & 31) + 32 * (k & 1))) * 4 + (kk & 3));
+  };
+  // P16[tile][g][lane][q] = W[n = 16 tile + (lane & 15)][k = 16 g + 4 q + (lane >> 4)]
+  auto e16 = [](size_t base, int groups, int n, int k) {
+    return base + (((size_t)((n >> 4) * groups + (k >> 4)) * 64 + ((n & 15) + 16 * (k & 3))) * 4 + ((k >> 2) & 3));
+  };
+  // PT[tile][g][lane][q] = W[n = 16 g + 4 q + (lane >> 4)][k = 16 tile + (lane & 15)]
+  auto eT = [](size_t base, int groups, int n, int k) {
+    return base + (((size_t)((k >> 4) * groups + (n >> 4)) * 64 + ((k & 15) + 16 * (n & 3))) * 4 + ((n >> 2) & 3));
+  };
+  if (i < ob1) {
+    const int n = (int)(i / L.in_dim), k = (int)(i - (long)n * L.in_dim);
+    out[e32(L.w1, L.g1, n, k)] = p;
+    out[e16(L.w1n, G1N, n, k)] = p;
+  } else if (i < oW2) {
+    out[L.b1 + (i - ob1)] = p;
+  } else if (i < ob2) {
+    const int r = (int)(i - oW2), n = r >> 8, k = r & 255;
+    out[e32(L.w2, 32, n, k)] = p;
+    out[e16(L.w2n, HID / 16, n, k)] = p;
+    out[eT(L.w2t, HID / 16, n, k)] = p;
+  } else if (i < oW3) {
+    out[L.b2 + (i - ob2)] = p;
+  } else if (i < ob3) {
+    const int r = (int)(i - oW3), n = r >> 8, k = r & 255;
+    out[e32(L.w3, 32, n, k)] = p;            // one 32-column tile: n < 32
+    out[e16(L.w3n, HID / 16, n, k)] = p;
+    out[eT(L.w3t, T3N, n, k)] = p;
+  } else {
+    out[L.b3 + (i - ob3)] = p;
+  }
+}
+
 // clip_grad_norm_: g *= min(max_norm / (||g|| + 1e-6), 1) per network; Adam (torch.optim.Adam, amsgrad off, no decay):
 //   m += (g - m)(1 - b1); v = v b2 + ((1 - b2) g) g; p += -(lr / (1 - b1^t)) (m / (sqrt(v) / sqrt(1 - b2^t) + eps))
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, int blocks_a) {
@@ -821,6 +865,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, int blocks_a
   double ss = 0.0;
   for (int b = threadIdx.x & 63; b < nt.blocks; b += 64) ss += a.sumsq[n * ADAM_MAX_BLOCKS + b];
   ss = __shfl(wave_sum(ss), 0, 64);
+  PackLayout L;
+  if (nt.packed) {
+    L = pack_layout(nt.in_dim, nt.out_dim);
+    if (i < MAX_IN) {                                   // the stream's input-normalisation tables
+      nt.packed[L.mean + i] = (nt.mean && i < nt.in_dim) ? nt.mean[i] : 0.f;
+      nt.packed[L.std + i] = (nt.std && i < nt.in_dim) ? nt.std[i] : 1.f;
+    }
+  }
   if (i >= nt.n) return;
   const float norm = (float)sqrt(ss);
   const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
@@ -831,7 +883,9 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, int blocks_a
   nt.exp_avg[i] = m;
   nt.exp_avg_sq[i] = v;
   const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-  nt.param[i] = nt.param[i] + a.neg_step * (m / denom);
+  const float p = nt.param[i] + a.neg_step * (m / denom);
+  nt.param[i] = p;
+  if (nt.packed) scatter_packed(L, nt.packed, i, p);
 }
 
 // input images 4 XI, hidden images 3 HI, partial tiles, mirror rows, dZ3 images, constants, statistics; + dW1: 16 KT1 KB
@@ -966,7 +1020,7 @@ extern "C" int oly_ppo_adam_step(oly_ctx* ctx, const oly_ppo_adam* a, oly_stream
     if (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq || s.out_dim <= 0 || s.out_dim > 16)
       OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_adam_step: network %d: NULL buffer or bad out_dim", n);
     const int gf = grad_floats(a->in_dim, s.out_dim);
-    k.net[n] = AdamNet{s.param, s.exp_avg, s.exp_avg_sq, s.grad, gf, (gf + 255) / 256};
+    k.net[n] = AdamNet{s.param, s.exp_avg, s.exp_avg_sq, s.grad, gf, (gf + 255) / 256, s.packed, s.in_mean, s.in_std, a->in_dim, s.out_dim};
     if (k.net[n].blocks > ADAM_MAX_BLOCKS) OLY_FAIL(ctx, OLY_ERANGE, "oly_ppo_adam_step: network too large");
   }
   k.sumsq = a->ws;
@@ -986,22 +1040,33 @@ extern "C" int oly_ppo_adam_step(oly_ctx* ctx, const oly_ppo_adam* a, oly_stream
   const int ba = (k.net[0].n + 255) / 256, bc = (k.net[1].n + 255) / 256;
   hipLaunchKernelGGL(adam_step_kernel, dim3(ba + bc), dim3(256), 0, oly_s(stream), k, ba);
   OLY_LAUNCH_CHECK(ctx, "adam step kernels");
-  if (a->net[0].packed && a->net[1].packed) {
-    const int od[2] = {a->net[0].out_dim, a->net[1].out_dim};
-    const float* const flat[2] = {a->net[0].param, a->net[1].param};
-    const float* const mean[2] = {a->net[0].in_mean, a->net[1].in_mean};
-    const float* const std[2] = {a->net[0].in_std, a->net[1].in_std};
-    float* const packed[2] = {a->net[0].packed, a->net[1].packed};
-    return oly_mlp_pack_pair(ctx, a->in_dim, od, flat, mean, std, packed, stream);      // both networks, one launch
-  }
-  for (int n = 0; n < 2; ++n) {
-    const oly_adam_net& s = a->net[n];
-    if (!s.packed) continue;
-    const float* p = s.param;
-    const size_t ob1 = (size_t)HID * a->in_dim, oW2 = ob1 + HID, ob2 = oW2 + (size_t)HID * HID, oW3 = ob2 + HID,
-                 ob3 = oW3 + (size_t)s.out_dim * HID;
-    const int rc = oly_mlp_pack(ctx, a->in_dim, HID, s.out_dim, p, p + ob1, p + oW2, p + ob2, p + oW3, p + ob3, s.in_mean,
-                                s.in_std, s.packed, stream);
+  return OLY_OK;
+}
+
+// One epoch's minibatch loop (ppo.py:357-410) as ONE call: BatchSampler cuts the permutation into consecutive minibatches
+// of u->B rows; each gets update_policy's gradients and one optimiser step.  3 launches per minibatch, queued from C: at the
+// reference's minibatch size (64) the Python side of one call per launch group cost more than the kernels ran.
+extern "C" int oly_ppo_update_epoch(oly_ctx* ctx, const oly_ppo_update* u, const oly_ppo_adam* a, const int32_t* perm,
+                                    int n_batches, double* scal_out, oly_stream stream) {
+  if (!ctx) return OLY_EINVAL;
+  if (!u || !a || !perm || !scal_out || n_batches < 0)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_epoch: NULL argument or negative n_batches");
+  if (!u->gnorm_ws || u->gnorm_ws != a->ws)
+    OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_epoch: u->gnorm_ws must be a->ws (the gradient norm travels through it)");
+  for (int n = 0; n < 2; ++n)
+    if (a->net[n].grad != (n ? u->grad_critic : u->grad_actor) || a->net[n].packed != (n ? u->packed_critic : u->packed_actor))
+      OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_epoch: network %d: the optimiser's grad / packed buffers are not the update's", n);
+  if (a->step <= 0 || (long)a->step + n_batches > 0x7fffffffL) OLY_FAIL(ctx, OLY_EINVAL, "oly_ppo_update_epoch: bad step");
+  oly_ppo_update uu = *u;
+  oly_ppo_adam aa = *a;
+  aa.norm_ready = 1;
+  for (int b = 0; b < n_batches; ++b) {
+    uu.idx = perm + (size_t)b * (size_t)uu.B;
+    uu.scal_out = scal_out + 6 * (size_t)b;
+    int rc = oly_ppo_update_grads(ctx, &uu, stream);
+    if (rc != OLY_OK) return rc;
+    aa.step = a->step + b;
+    rc = oly_ppo_adam_step(ctx, &aa, stream);
     if (rc != OLY_OK) return rc;
   }
   return OLY_OK;

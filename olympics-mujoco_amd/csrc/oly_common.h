@@ -104,10 +104,6 @@ int oly_stats_finish(oly_ctx* ctx, int nblocks, int64_t n, double* stats3_out, o
 int oly_a3_step_strided(oly_ctx* ctx, int N, const oly_a3_inputs* in, const oly_a3_state* st, void* obs, float* rew6,
                         float* reward, uint8_t* done, int out_flags, int compact_base, oly_stream stream);
 
-// K11: flat parameter buffers of two networks -> their packed streams in one launch (oly_ppo_adam_step's re-pack)
-int oly_mlp_pack_pair(oly_ctx* ctx, int in_dim, const int out_dim[2], const float* const flat[2], const float* const mean[2],
-                      const float* const std[2], float* const packed[2], oly_stream stream);
-
 static inline hipStream_t oly_s(oly_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
 // 64-wide wavefront helpers (gfx950).

@@ -116,7 +116,7 @@ A3_PHYSICS_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(A3Re
 
 # name -> (restype, argtypes); device/host pointers are void*.
 STD_SCALAR, STD_PER_DIM, STD_FULL = 0, 1, 2
-ABI_VERSION = 6          # OLY_ABI_VERSION of include/olympic_hip.h this table mirrors
+ABI_VERSION = 7          # OLY_ABI_VERSION of include/olympic_hip.h this table mirrors
 
 
 class AdamNet(C.Structure):
@@ -224,6 +224,7 @@ SIGNATURES = {
     "oly_ppo_update_ws_floats": (C.c_int64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "oly_ppo_update_grads": (C.c_int, [vp, C.POINTER(PPOUpdate), vp]),
     "oly_ppo_adam_step": (C.c_int, [vp, C.POINTER(PPOAdam), vp]),
+    "oly_ppo_update_epoch": (C.c_int, [vp, C.POINTER(PPOUpdate), C.POINTER(PPOAdam), vp, C.c_int, vp, vp]),
     "oly_event_create": (C.c_int, [C.POINTER(vp)]),
     "oly_event_destroy": (C.c_int, [vp]),
     "oly_event_record": (C.c_int, [vp, vp]),

@@ -539,6 +539,7 @@ class Engine:
                 if rc:
                     check(h, rc, "oly_ppo_update_grads")
                 return keep
+            launch.struct, launch.B, launch.keep = u, B, keep
             return launch
         self.ctx.call("oly_ppo_update_grads", C.byref(u), self._s())
         return grad_actor, grad_critic, scal_out
@@ -584,8 +585,22 @@ class Engine:
                 if rc:
                     check(h, rc, "oly_ppo_adam_step")
                 return keep
+            launch.struct, launch.keep = a, keep
             return launch
         self.ctx.call("oly_ppo_adam_step", C.byref(a), self._s())
+
+    def ppo_update_epoch(self, grads_launch, adam_launch, first_step, perm, n_batches, scal_out):
+        """oly_ppo_update_epoch: the minibatch loop of one epoch in one call, from the two prepared launches
+        (ppo_update_grads / ppo_adam_step with prepare=True): minibatch b takes rows perm[b B : (b + 1) B], leaves its six
+        scalars in scal_out[b] and is optimiser step first_step + b."""
+        u, a, B = grads_launch.struct, adam_launch.struct, grads_launch.B
+        n_batches = int(n_batches)
+        if perm.dim() != 1 or int(perm.shape[0]) < n_batches * B:
+            raise OlyError(f"ppo_update_epoch: perm holds {tuple(perm.shape)} indices, {n_batches} minibatches of {B} need {n_batches * B}")
+        _req(perm, "perm", (int(perm.shape[0]),), torch.int32, self.device)
+        _req(scal_out, "scal_out", (n_batches, 6), torch.float64, self.device)
+        a.step = int(first_step)
+        self.ctx.call("oly_ppo_update_epoch", C.byref(u), C.byref(a), ptr(perm), n_batches, ptr(scal_out), self._s())
 
     # -------------------------------------------------------------- K6
     def return_scan(self, mode, gamma, lam, rew, val, next_val, flags, ret=None, adv=None, stats3=None):

@@ -256,6 +256,7 @@ class KernelUpdate:
                 clip=self.clip, vf_coeff=self.vf_coeff, mirror_coeff=self.mirror_coeff, parts=parts, gnorm_ws=self.adam_ws,
                 prepare=True)
         launch(idx, scal)
+        self._last_launch = launch
         self._norm_ready = True                             # adam_ws holds the squared-norm partials of these gradients
         return scal
 
@@ -277,6 +278,19 @@ class KernelUpdate:
     def step(self, observations, actions, returns, advantages, idx, scal=None):
         scal = self.grads(observations, actions, returns, advantages, idx, scal)
         self.apply()
+        return scal
+
+    def epoch(self, observations, actions, returns, advantages, perm, minibatch, n_batches, scal):
+        """The epoch's whole minibatch loop in one C call (oly_ppo_update_epoch): minibatch b = rows perm[b * minibatch :
+        (b + 1) * minibatch], scalars into scal[b] ([n_batches, 6] f64), one optimiser step each.  Same launches in the
+        same order as n_batches calls of step()."""
+        if n_batches <= 0:
+            return scal
+        # the first minibatch through the ordinary path: it prepares (validates) the two launches
+        self.step(observations, actions, returns, advantages, perm[:minibatch], scal[0])
+        if n_batches > 1:
+            self.eng.ppo_update_epoch(self._last_launch, self._apply[1], self.steps + 1, perm[minibatch:], n_batches - 1, scal[1:])
+            self.steps += n_batches - 1
         return scal
 
 
@@ -669,12 +683,12 @@ class PPO:
                     kupd = KernelUpdate(env.eng, policy, critic, self.old_policy, self.clip, self.vf_coeff,
                                         self.mirror_coeff, obs_mirr, act_src, act_sign, lr=self.lr, eps=self.eps,
                                         max_grad_norm=self.grad_clip)
-                kernel = kupd
+                kernel = self.kupd = kupd
                 kernel.begin(observations, buf.mu.reshape(n, -1) if getattr(buf, "mu", None) is not None
                              and getattr(buf, "mu_from_fused_forward", False) else None)
                 kstats = torch.zeros((self.epochs * max(n_batches, 1), 6), dtype=torch.float64, device=observations.device)
                 adv_flat, ret_flat = advantages.reshape(-1).contiguous(), returns.reshape(-1).contiguous()
-            elif use_graph and fused:
+            elif use_graph and fused and self.target_kl is None:   # (a replayed graph contains the optimiser steps: no KL check)
                 # Captured anew for every iteration's update phase (~15 ms).  profiles/r02/graph_drift/README.md:
                 # a captured torch update replays bit-exactly until a [synchronize -> kernel write into a newly
                 # allocated block of >= 1 MB] happens between two replays; after that the multi-block
@@ -685,6 +699,21 @@ class PPO:
                 # lifetime is one update phase.
                 graphed = GraphedUpdate(self, env.eng, minibatch, observations.shape[1], actions.shape[1],
                                         obs_mirr, act_src, act_sign)
+            continue_training = True                           # False once 1.5 * target_kl is breached (ppo.py:343, 391-393)
+
+            def kl_breached(kl):
+                """ppo.py:391: stop the update phase BEFORE this minibatch's optimiser steps when its approximate KL exceeds
+                1.5 target_kl (over ranks: their mean, so that the replicas of the one learner stop together)."""
+                if self.target_kl is None:
+                    return False
+                kl = float(kl)
+                if multi_rank:
+                    kl = odist.allreduce_sum([kl])[0] / torch.distributed.get_world_size()
+                if kl > 1.5 * self.target_kl:
+                    if verbose:
+                        print(f"Early stopping at step {epoch} due to reaching max kl: {kl:.2f}")
+                    return True
+                return False
             for epoch in range(self.epochs):
                 # BatchSampler(SubsetRandomSampler(range(n)), minibatch, drop_last=True) draws ONE
                 # torch.randperm(n) from the default CPU generator and cuts it into consecutive
@@ -699,17 +728,26 @@ class PPO:
                         else torch.randperm(n)
                     self._next_perm = None
                     perm = (perm_host.to(torch.int32) if kernel is not None else perm_host).to(observations.device)
-                for b in range(n_batches):
+                one_call = kernel is not None and not multi_rank and self.target_kl is None
+                if one_call:
+                    # the whole minibatch loop of the epoch in one C call (the per-minibatch KL check below needs the host)
+                    rows = kstats[len(stats):len(stats) + n_batches]
+                    kernel.epoch(observations, actions, ret_flat, adv_flat, perm, minibatch, n_batches, rows)
+                    stats.extend(rows.unbind(0))
+                for b in (() if one_call else range(n_batches)):
                     idx = perm[b * minibatch:(b + 1) * minibatch]
                     if kernel is not None:
                         slot = kstats[len(stats)]
+                        kernel.grads(observations, actions, ret_flat, adv_flat, idx, slot)
+                        stats.append(slot)
+                        if kl_breached(slot[3]):
+                            continue_training = False
+                            break
                         if multi_rank:
-                            kernel.grads(observations, actions, ret_flat, adv_flat, idx, slot)
                             odist.allreduce_flat([kernel.grad_actor, kernel.grad_critic], weight=minibatch, total_weight=rows_all)
                             kernel.apply(norm_ready=False)      # the norm of the REDUCED gradients
                         else:
-                            kernel.step(observations, actions, ret_flat, adv_flat, idx, slot)
-                        stats.append(slot)
+                            kernel.apply()
                         continue
                     if graphed is not None:
                         every = getattr(self, "graph_recapture_every", None)     # test hook: fresh graph every k replays
@@ -726,6 +764,10 @@ class PPO:
                     else:
                         a_l, ent, c_l, kl, m_l, clipf = self.update_policy(
                             observations[idx], actions[idx], returns[idx], advantages[idx], 1, obs_mirr, act_mirr)
+                    if kl_breached(kl):
+                        stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), float(clipf)))
+                        continue_training = False
+                        break
                     self.actor_optimizer.zero_grad()
                     self.critic_optimizer.zero_grad()
                     if fused:
@@ -743,6 +785,8 @@ class PPO:
                     torch.nn.utils.clip_grad_norm_(critic.parameters(), self.grad_clip)
                     self.critic_optimizer.step()
                     stats.append((a_l.item(), ent.item(), c_l.item(), kl.item(), float(m_l), float(clipf)))
+                if not continue_training:
+                    break
                 if kernel is not None and not device_perm and (epoch + 1 < self.epochs or itr + 1 < n_itr):
                     self._next_perm = torch.randperm(n)            # behind the queued minibatches
             if stats and torch.is_tensor(stats[0]):

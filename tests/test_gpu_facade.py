@@ -234,7 +234,8 @@ def test_vec_a3_env_replays_golden_sequence(golden):
 
 
 @pytest.mark.parametrize("minibatch,n_itr", [(2048, 2), (256, 2)])
-@pytest.mark.parametrize("mode", ["torch_losses", "fused", "fused_graph", "fused_graph_fresh", "kernel"])
+@pytest.mark.parametrize("mode", ["torch_losses", "fused", "fused_graph", "fused_graph_fresh", "kernel", "fused_target_kl",
+                                  "kernel_target_kl"])
 def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr):
     """Config 3 end to end: VecA3Env (synthetic physics readback) -> PPO.train: rollout,
     return scan + adv-norm on the device, clipped-surrogate updates in PyTorch."""
@@ -281,7 +282,9 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr
     ppo = PPO(args, str(tmp_path))
     ppo.use_device_rollout = False               # this test drives the per-step host loop (custom reset above)
     ppo.fused_loss, ppo.use_graph = mode != "torch_losses", mode.startswith("fused_graph")
-    ppo.update_kernel = mode == "kernel"         # K14: forward + losses + backward of a minibatch in one launch
+    ppo.update_kernel = mode.startswith("kernel")   # K14: forward + losses + backward of a minibatch in one launch
+    if mode.endswith("target_kl"):
+        ppo.target_kl = 1e-8
     ppo.device_permutation = False               # every mode cuts the same host-drawn permutation: same seed, same batches
     if mode == "fused_graph_fresh":
         ppo.graph_recapture_every = 1            # every update runs as the FIRST replay of a new capture
@@ -291,6 +294,13 @@ def test_ppo_train_iterations_on_vec_a3(golden, tmp_path, mode, minibatch, n_itr
     hist = ppo.train(Env, pi, vf, n_itr=n_itr, verbose=False)
     assert len(hist) == n_itr and all(np.isfinite(h["losses"]).all() for h in hist)
     assert not torch.equal(w0, pi.means.weight)                      # the optimiser stepped
+    if mode.endswith("target_kl"):
+        # ppo.py:391-393, 412-414: the first minibatch of an iteration sees ratio one (KL exactly 0) and steps; the second
+        # sees the stepped policy, breaches 1.5 target_kl and ends the whole update phase BEFORE its own optimiser step
+        steps = ppo.kupd.steps if mode.startswith("kernel") else int(ppo.actor_optimizer.state[pi.means.weight]["step"])
+        assert steps == n_itr, steps
+        assert all(h["losses"][3] > 1.5e-8 / 2 for h in hist)            # mean KL of the two minibatches it evaluated
+        return
     assert ppo.total_steps == n_itr * 16 * N
     lines = open(ppo.train_fn).read().strip().splitlines()
     assert lines[0] == "ep_returns,ep_lens" and len(lines) == n_itr + 1

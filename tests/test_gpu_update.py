@@ -234,3 +234,39 @@ def test_kernel_update_object_steps_like_torch(eng):
     for a, b in zip(list(pi.parameters()) + list(vf.parameters()), list(pi_t.parameters()) + list(vf_t.parameters())):
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-3)
     assert ku.steps == 3
+
+
+@pytest.mark.parametrize("B,n_batches", [(64, 7), (128, 1), (100, 4)])
+def test_kernel_update_epoch_call_equals_the_step_loop(eng, B, n_batches):
+    """oly_ppo_update_epoch (one C call per epoch) against n_batches calls of KernelUpdate.step on the consecutive cuts of
+    the same permutation: every parameter, both Adam moments, the packed streams and the scalars of every minibatch, to
+    the bit (the same launches in the same order); the step count advances by n_batches."""
+    import copy
+    from olympic_hip.ppo import KernelUpdate, MLPCritic, MLPGaussianActor
+    torch.manual_seed(4)
+    n = 900
+    obs, act = torch.randn(n, 41, device="cuda"), torch.randn(n, 12, device="cuda") * 0.3
+    ret, adv = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    perm = torch.randperm(n, device="cuda").to(torch.int32)
+    runs = []
+    for one_call in (False, True):
+        torch.manual_seed(5)
+        pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+        pi.obs_mean, pi.obs_std = torch.linspace(-0.2, 0.2, 41).cuda(), torch.linspace(0.7, 1.4, 41).cuda()
+        ku = KernelUpdate(eng, pi, vf, copy.deepcopy(pi), 0.2, 0.5, 0.0, lr=1e-3, eps=1e-5, max_grad_norm=0.05)
+        ku.begin(obs)
+        scal = torch.zeros((2 * n_batches, 6), dtype=torch.float64, device="cuda")
+        for ep in range(2):                              # a second epoch: the call continues the step count
+            rows = scal[ep * n_batches:(ep + 1) * n_batches]
+            if one_call:
+                ku.epoch(obs, act, ret, adv, perm, B, n_batches, rows)
+            else:
+                for b in range(n_batches):
+                    ku.step(obs, act, ret, adv, perm[b * B:(b + 1) * B], rows[b])
+        torch.cuda.synchronize()
+        assert ku.steps == 2 * n_batches
+        runs.append(dict(scal=scal, **{f"{k}{i}": nt[k].clone() for i, nt in enumerate(ku.nets)
+                                       for k in ("param", "exp_avg", "exp_avg_sq", "grad", "packed")}))
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    assert float(runs[0]["scal"][:, 3].abs().max()) > 0                    # the policy moved between minibatches

@@ -63,6 +63,18 @@ def main():
         wall = time.perf_counter() - t0
         out["epoch_%d" % rep] = dict(updates=nb, host_enqueue_ms_per_update=t_enq / nb * 1e3, wall_ms_per_update=wall / nb * 1e3,
                                      hip_event_ms_per_update=tm.elapsed_ms() / nb)
+    for rep in range(2):                                  # the same epoch as ONE C call (oly_ppo_update_epoch)
+        torch.cuda.synchronize()
+        tm = HipTimer()
+        t0 = time.perf_counter()
+        tm.start(eng._s())
+        ku.epoch(obs, act, ret, adv, perm, B, nb, stats)
+        t_enq = time.perf_counter() - t0
+        tm.stop(eng._s())
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        out["epoch_one_call_%d" % rep] = dict(updates=nb, host_enqueue_ms_per_update=t_enq / nb * 1e3,
+                                              wall_ms_per_update=wall / nb * 1e3, hip_event_ms_per_update=tm.elapsed_ms() / nb)
     print(json.dumps(out, indent=1))
 
 
