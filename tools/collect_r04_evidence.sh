@@ -31,4 +31,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
   python3 $R/tools/pmc_summary.py $f ppo_update > $O/k14_pmc_$c.json
 done
+# 5. how a vec step's bytes can cross PCIe (host batcher design data)
+$R/tools/hip/pcie_paths.bin > $O/pcie_paths.json 2>/tmp/pcie.err || tail -3 /tmp/pcie.err
 ls -la $O
