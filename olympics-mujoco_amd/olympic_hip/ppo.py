@@ -138,17 +138,17 @@ class FusedMirrorLoss(torch.autograd.Function):
 
 
 class KernelUpdate:
-    """One PPO minibatch update (rl/algos/ppo.py:232-282,396-410) as six launches of this repository's own kernels:
+    """One PPO minibatch update (rl/algos/ppo.py:232-282,396-410) as three launches of this repository's own kernels:
       oly_ppo_update_grads (K14)  actor and critic forward, the loss terms of update_policy (mirror loss included) and the
                                   backward pass on the f32 matrix cores, + the finishing launch that adds the parts;
       oly_ppo_adam_step           torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step for both networks on flat
-                                  buffers (2 launches) and the re-pack of the stepped weights (2 launches).
+                                  buffers, the stepped weights written into the packed streams in the same launch.
     The modules keep their parameters: `.data` of every weight / bias becomes a view of one flat buffer per network
     (same values), `.grad` a view of the flat gradient buffer the kernel writes; Adam's moments and the step count live
-    here.  Per iteration (`begin`): the old policy's means of every rollout row (the old policy is constant during an
-    update phase: one K11 forward instead of one per minibatch) and the mirrored observations (the env's own
-    mirror_clock_observation, any function).  Per minibatch (`step`): the rows are gathered by index inside the
-    kernel."""
+    here.  Per iteration (`begin`): the old policy's means of every rollout row (the means the rollout kernels stored, or
+    one K11 forward: the old policy is constant during an update phase) and the mirrored observations (the env's own
+    mirror_clock_observation, any function).  Per minibatch (`step`) or per epoch (`epoch`, one C call): the rows are
+    gathered by index inside the kernel."""
 
     def __init__(self, eng, policy, critic, old_policy, clip, vf_coeff, mirror_coeff, obs_mirr=None, act_src=None,
                  act_sign=None, lr=1e-4, eps=1e-5, max_grad_norm=0.05, betas=(0.9, 0.999)):

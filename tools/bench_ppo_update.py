@@ -66,7 +66,7 @@ def main():
 
                 def step():
                     if fused == "kernel":
-                        ku.step(obs, act, ret1, adv1, idx32)      # K14 gradients + clip + Adam + re-pack: six launches
+                        ku.step(obs, act, ret1, adv1, idx32)      # K14 gradients + clip + Adam: three launches
                         return
                     if fused == "graph":
                         gu(obs, act, ret, adv, idx)
