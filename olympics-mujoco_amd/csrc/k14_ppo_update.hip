@@ -171,6 +171,10 @@ __device__ __forceinline__ void layer_tiles16b(const float4* __restrict__ a4, __
 #define OLY_STAMP(i)
 #endif
 
+// values the optimiser must treat as new (see the loss block)
+__device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float opaque_s(float x) { asm volatile("" : "+s"(x)); return x; }
+
 template <int KT1>      // groups of 16 inputs
 __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   // the input rows of work item `it`: thread's two elements (tile rows sm and sm + 8), normalised, zero-padded
   auto load_x = [&](int it, float (&v)[2]) {
     const int tile = part_id + it * parts;
+    const int sk_here = opaque_v(sk);              // (as a loop invariant the per-thread base address was spilled)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = mirror ? tile * 8 + sm : tile * UR + sm + 8 * i;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
       float x = 0.f;
       if (row < B && sk < in_dim) {
         const long r = p.idx ? (long)p.idx[row] : (long)row;
-        x = src[r * in_dim + sk];
+        x = src[r * in_dim + sk_here];
         if (net.normalize) x = (x - nmean) / nstd;
       }
       v[i] = x;
@@ -296,12 +301,20 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
   // wave 0's loss inputs (lane: row c, columns 4 j ..) of a tile: fetched one tile ahead into registers behind the
   // backward phases, parked in LDS at the item's end (a random row of HBM costs ~2 us: in front of the loss they were
   // 4 K of a tile's 47 K cycles on every wave)
-  auto loss_fetch = [&](int tile_, float (&v)[10]) {
+  // the buffer row behind a tile's loss lane (-1: none).  Resolved at the TOP of the item before: as the first step of
+  // loss_fetch the index load was a memory round trip on wave 0 between its loss and the barrier the other seven
+  // waves were already waiting at (1.5 K of a tile's 46 K cycles)
+  auto loss_row = [&](int tile_) -> int {
+    const int row = tile_ * rpt + c;
+    if (tile_ < net.ntiles && c < rpt && row < B) return p.idx ? p.idx[row] : row;
+    return -1;
+  };
+  auto loss_fetch = [&](int r32, float (&v)[10]) {
 #pragma unroll
     for (int q = 0; q < 10; ++q) v[q] = 0.f;
-    const int row = tile_ * rpt + c;
-    if (tile_ < net.ntiles && c < rpt && row < B) {
-      const long r = p.idx ? (long)p.idx[row] : (long)row;
+    if (r32 >= 0) {
+      const long r = r32;
+      const int j = opaque_v(lane) >> 4;          // (the hoisted per-lane base addresses came back as scratch reloads)
       if (critic) {
         v[9] = p.ret[r];
       } else {
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     preload16b<KT1, 2>(rsP, voff, so1, wb, P);
     if (wave == 0) {
       float lv[10];
-      loss_fetch(part_id, lv);
+      loss_fetch(loss_row(part_id), lv);
       loss_park(lv);
     }
   }
@@ -356,6 +369,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     const int pb = it & 1;
     const bool more = it + 1 < n_items;
     if (more) load_x(it + 1, xn);           // in flight behind this item's layers
+    const int lrow_next = (wave == 0 && more) ? loss_row(tile + parts) : -1;
     const int grow = tile * rpt + c;        // wave 0's loss lane: row c of the tile (c >= rpt: a mirrored row)
     const bool valid = c < rpt && grow < B;
     const float4* xA4 = reinterpret_cast<const float4*>(xA + pb * XI);
@@ -380,9 +394,12 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     __syncthreads();
     OLY_STAMP(2);
     f32x4 h2own[2];
+    u32x4 wb1[RD + 1][1];                   // the output layer's two weight groups: requested in front of barrier 2 (behind
+                                            // it they were an exposed L2 round trip in a phase of eight MFMAs)
     {  // ---- layer 2
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       layer_tiles16b<HID / 16, 2>(reinterpret_cast<const float4*>(h1A), rsP, voff, so2, lane, acc, wb, P);
+      preload16b<2, 1>(rsP, voff, so3, wb1, P);
 
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -396,8 +413,6 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     OLY_STAMP(4);
     {  // ---- output layer: chain `wave` of the eight partial chains (k in [32 wave, 32 wave + 32))
       f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-      u32x4 wb1[RD + 1][1];
-      preload16b<2, 1>(rsP, voff, so3, wb1, P);
       layer_tiles16b<2, 1>(reinterpret_cast<const float4*>(h2A) + (size_t)(2 * wave) * 64, rsP, voff, so3, lane, acc, wb1, P);
       preload16b<1, 2>(rsP, voff, so3t, wb, P);
 #pragma unroll
@@ -407,6 +422,16 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     __syncthreads();
     OLY_STAMP(6);
     if (wave == 0) {  // ---- out = partial chains in order + bias; loss terms; d loss / d out   (lane: row c, columns 4 j ..)
+      // Everything this block derives from the lane number or from launch constants is derived HERE, from copies the
+      // compiler cannot trace back (an empty asm): as loop invariants they were hoisted in front of the tile loop, could not
+      // keep a register through the matrix phases, and came back as ~17 scratch reloads, each waited for on the spot, in
+      // the one phase seven waves wait for.
+      const int lane_here = opaque_v(lane);
+      const float clip_here = opaque_s(p.clip), vf_here = opaque_s(p.vf_coeff);
+      const int lane = lane_here, c = lane_here & 15, j = lane_here >> 4;
+      const float lo = 1.0f - clip_here, hi = 1.0f + clip_here;
+      const float zero_here = __int_as_float(opaque_v(0));
+      const bool valid = c < rpt && tile * rpt + c < B;
 #pragma unroll
       for (int k = 0; k < 16; ++k) parkL[k * 64 + lane] = make_float4(dW2[0][k][0], dW2[0][k][1], dW2[0][k][2], dW2[0][k][3]);
       float o[4], g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -433,7 +458,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           mirL[c * 16 + 4 * j + cc] = o[cc];
-          dmirL[c * 16 + 4 * j + cc] = 0.f;
+          dmirL[c * 16 + 4 * j + cc] = zero_here;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -445,7 +470,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
         if (j == 0 && valid) {
           const float dv = retv - v;
           stL[4 * 64 + lane] += (double)(dv * dv);
-          g[0] = p.vf_coeff * 2.0f * (v - retv) * p.inv_b;
+          g[0] = vf_here * 2.0f * (v - retv) * p.inv_b;
         }
       } else {
         float t[4], lt[4], olt[4];
@@ -543,7 +568,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     // wave 0: the next tile's loss inputs, requested behind this item's backward phases (the item before a tile's loss)
     float lnext[10];
     const bool fetch_loss = wave == 0 && more;
-    if (fetch_loss) loss_fetch(tile + parts, lnext);
+    if (fetch_loss) loss_fetch(lrow_next, lnext);
     {
       __syncthreads();
       OLY_STAMP(8);
