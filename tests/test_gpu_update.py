@@ -270,3 +270,35 @@ def test_kernel_update_epoch_call_equals_the_step_loop(eng, B, n_batches):
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]), k
     assert float(runs[0]["scal"][:, 3].abs().max()) > 0                    # the policy moved between minibatches
+
+
+@pytest.mark.parametrize("in_dim,out_a", [(10, 3), (16, 16), (33, 7), (64, 12)])
+def test_ppo_adam_step_keeps_the_packed_streams_current_for_other_widths(eng, in_dim, out_a):
+    """The optimiser launch writes every stepped weight to its places in the packed stream (the inverse of oly_mlp_pack's
+    map): after two steps on random gradients the stream equals a fresh oly_mlp_pack of the stepped parameters, element
+    for element, for 1 - 4 groups of 16 inputs and several output widths (tables and zero padding included)."""
+    from olympic_hip._ffi import lib
+    g = torch.Generator(device="cuda").manual_seed(in_dim + out_a)
+    mean = torch.empty(in_dim, device="cuda").normal_(0, 0.3, generator=g)
+    std = torch.empty(in_dim, device="cuda").uniform_(0.5, 2.0, generator=g)
+    nets = []
+    for out_dim in (out_a, 1):
+        n = int(lib().oly_ppo_update_grad_floats(in_dim, 256, out_dim))
+        p0 = torch.empty(n, device="cuda").normal_(0, 0.2, generator=g)
+        z = torch.zeros(n, device="cuda")
+        nets.append(dict(param=p0, grad=z.clone(), exp_avg=z.clone(), exp_avg_sq=z.clone(), out_dim=out_dim,
+                         packed=torch.zeros(eng._mlp_floats(in_dim, out_dim), device="cuda"),
+                         in_mean=mean if out_dim == out_a else None, in_std=std if out_dim == out_a else None))
+    ws = torch.zeros(1024, dtype=torch.float64, device="cuda")
+    for t in range(2):
+        for nt in nets:
+            nt["grad"].normal_(0, 1e-3, generator=g)
+        before = [nt["param"].clone() for nt in nets]
+        eng.ppo_adam_step(in_dim, t + 1, 1e-3, 1e-5, 0.05, nets, ws)
+        assert all(not torch.equal(b, nt["param"]) for b, nt in zip(before, nets))
+    for nt in nets:
+        od = nt["out_dim"]
+        parts = [a.contiguous() for a in torch.split(nt["param"], [256 * in_dim, 256, 65536, 256, od * 256, od])]
+        fresh = eng.mlp_pack(parts[0].view(256, in_dim), parts[1], parts[2].view(256, 256), parts[3], parts[4].view(-1, 256),
+                             parts[5], nt["in_mean"], nt["in_std"])
+        assert torch.equal(fresh, nt["packed"]), (in_dim, od, int((fresh != nt["packed"]).sum()))
