@@ -36,6 +36,7 @@
 using oly_mlp::act16_index;
 using oly_mlp::f32x4;
 using oly_mlp::layer_tiles16;
+using oly_mlp::preload16;
 using oly_mlp::store_relu16;
 
 namespace {
@@ -394,6 +395,35 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward16_kernel(DiscArgs p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, h2 = lane >> 4;
 
+  // This kernel serves SMALL batches: one tile per workgroup, one workgroup per CU, nothing else on the CU to hide a
+  // memory round trip.  So every load that does not depend on a barrier is requested before the barrier in front of its
+  // use: the first tile's rows and layer-1 weights here, ahead of the statistics; each later layer's first two weight
+  // groups ahead of the barrier that ends the layer before (they were five exposed L2 / HBM round trips per tile).
+  float xr[XPT];
+  auto load_x = [&](long tile) {
+    const long row0 = tile * RT16;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int e = tid + THREADS * i, m = e / KIN, k = e - m * KIN;
+      float v = 0.f;
+      if (row0 + m < p.B && k < p.D) v = p.x[(size_t)(row0 + m) * p.Dx + (p.mask ? p.mask[k] : k)];
+      xr[i] = v;
+    }
+  };
+  auto w1_of = [&](const float4* P4, const float4* (&w)[4]) {
+    const float4* base = P4 + (L.w0n >> 2) + (size_t)(4 * wave) * G1N16 * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w[t] = base + (size_t)t * G1N16 * 64;
+  };
+  float4 b1[3][4], b2[3][2], b3[3][4];       // the three layers' weight rings (first two groups requested early)
+  long tile = blockIdx.x;
+  if (tile < p.ntiles) {
+    load_x(tile);
+    const float4* w[4];
+    w1_of(reinterpret_cast<const float4*>(Pbase), w);
+    preload16<G1, 4>(w, lane, b1);
+  }
+
   if (tid < ZD + 4) wd[tid] = Pbase[L.wd + tid];
   const bool standardise = p.mean || p.colstats;
   if (tid < p.D && standardise) {
@@ -411,17 +441,6 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward16_kernel(DiscArgs p) 
   }
   __syncthreads();
 
-  float xr[XPT];
-  auto load_x = [&](long tile) {
-    const long row0 = tile * RT16;
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      const int e = tid + THREADS * i, m = e / KIN, k = e - m * KIN;
-      float v = 0.f;
-      if (row0 + m < p.B && k < p.D) v = p.x[(size_t)(row0 + m) * p.Dx + (p.mask ? p.mask[k] : k)];
-      xr[i] = v;
-    }
-  };
   auto stage_x = [&](long tile) {
     const long row0 = tile * RT16;
 #pragma unroll
@@ -433,11 +452,7 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward16_kernel(DiscArgs p) 
     }
   };
 
-  long tile = blockIdx.x;
-  if (tile < p.ntiles) {
-    load_x(tile);
-    stage_x(tile);
-  }
+  if (tile < p.ntiles) stage_x(tile);
   __syncthreads();
   for (; tile < p.ntiles; tile += gridDim.x) {
     const long row0 = tile * RT16;
@@ -446,20 +461,26 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward16_kernel(DiscArgs p) 
     asm volatile("" : "+s"(opaque0));
     const float* P = Pbase + opaque0;
     const float4* P4 = reinterpret_cast<const float4*>(P);
+    const float4* const base2 = P4 + (L.w1n >> 2) + (size_t)(2 * wave) * (H1 / 16) * 64;
+    const float4* const w2[2] = {base2, base2 + (H1 / 16) * 64};
+    const float4* const bm = P4 + (L.wmun >> 2) + (size_t)(2 * wave) * (H2 / 16) * 64;
+    const float4* const bl = P4 + (L.wlvn >> 2) + (size_t)(2 * wave) * (H2 / 16) * 64;
+    const float4* const w3[4] = {bm, bm + (H2 / 16) * 64, bl, bl + (H2 / 16) * 64};
     {  // ---- layer 1: [16, in] x [in, 256]; wave w owns column tiles 4 w .. 4 w + 3
       f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-      const float4* base = P4 + (L.w0n >> 2) + (size_t)(4 * wave) * G1N16 * 64;
-      const float4* const w[4] = {base, base + G1N16 * 64, base + 2 * G1N16 * 64, base + 3 * G1N16 * 64};
-      layer_tiles16<G1, 4>(reinterpret_cast<const float4*>(xT), w, lane, acc);
+      const float4* w[4];
+      w1_of(P4, w);
+      const float4* const wc[4] = {w[0], w[1], w[2], w[3]};
+      layer_tiles16<G1, 4, true>(reinterpret_cast<const float4*>(xT), wc, lane, acc, b1);
+      preload16<H1 / 16, 2>(w2, lane, b2);
 #pragma unroll
       for (int t = 0; t < 4; ++t) store_relu16(acc[t], P + L.b0, 4 * wave + t, lane, hA);
     }
     __syncthreads();
     {  // ---- layer 2: [16, 256] x [256, 128]; wave w owns column tiles 2 w, 2 w + 1
       f32x4 acc[2] = {{0}, {0}};
-      const float4* base = P4 + (L.w1n >> 2) + (size_t)(2 * wave) * (H1 / 16) * 64;
-      const float4* const w[2] = {base, base + (H1 / 16) * 64};
-      layer_tiles16<H1 / 16, 2>(reinterpret_cast<const float4*>(hA), w, lane, acc);
+      layer_tiles16<H1 / 16, 2, true>(reinterpret_cast<const float4*>(hA), w2, lane, acc, b2);
+      preload16<H2 / 16, 4>(w3, lane, b3);
 #pragma unroll
       for (int t = 0; t < 2; ++t) store_relu16(acc[t], P + L.b1, 2 * wave + t, lane, hB);
     }
@@ -476,10 +497,13 @@ __global__ __launch_bounds__(THREADS, 2) void disc_forward16_kernel(DiscArgs p) 
     __syncthreads();
     {  // ---- mu and logvar: [16, 128] x [128, 128] each; wave w owns column tiles 2 w, 2 w + 1 of BOTH
       f32x4 acc[4] = {{0}, {0}, {0}, {0}};
-      const float4* bm = P4 + (L.wmun >> 2) + (size_t)(2 * wave) * (H2 / 16) * 64;
-      const float4* bl = P4 + (L.wlvn >> 2) + (size_t)(2 * wave) * (H2 / 16) * 64;
-      const float4* const w[4] = {bm, bm + (H2 / 16) * 64, bl, bl + (H2 / 16) * 64};
-      layer_tiles16<H2 / 16, 4>(reinterpret_cast<const float4*>(hB), w, lane, acc);
+      layer_tiles16<H2 / 16, 4, true>(reinterpret_cast<const float4*>(hB), w3, lane, acc, b3);
+      if (next < p.ntiles) {                 // the next tile's layer-1 weights (the same stream)
+        const float4* w[4];
+        w1_of(P4, w);
+        const float4* const wc[4] = {w[0], w[1], w[2], w[3]};
+        preload16<G1, 4>(wc, lane, b1);
+      }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int col = 16 * (2 * wave + t) + c;

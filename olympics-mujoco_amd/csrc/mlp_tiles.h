@@ -73,16 +73,23 @@ __device__ __forceinline__ int act16_index(int k, int row) {
 // NT 16-column tiles of  A W  that share the A operand, G groups (k = 0 .. 16 G - 1 in order): weights two groups
 // ahead, activations one group ahead, fully unrolled; NT >= 2 independent accumulators cover the 40-cycle dependent
 // latency of the 32-cycle instruction.
+// PRE: the caller has requested the first two groups already (preload16, in front of the barrier that ends the layer
+// before: weights do not depend on it, and behind it the first MFMA waits out an L2 round trip with nothing to hide it
+// when a workgroup is alone on its CU).
 template <int G, int NT>
-__device__ __forceinline__ void layer_tiles16(const float4* __restrict__ a4, const float4* const (&w)[NT], int lane,
-                                              f32x4 (&acc)[NT]) {
-  float4 b[3][NT];
-  float4 a[2];
+__device__ __forceinline__ void preload16(const float4* const (&w)[NT], int lane, float4 (&b)[3][NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     b[0][t] = w[t][lane];
     if (G > 1) b[1][t] = w[t][64 + lane];
   }
+}
+
+template <int G, int NT, bool PRE = false>
+__device__ __forceinline__ void layer_tiles16(const float4* __restrict__ a4, const float4* const (&w)[NT], int lane,
+                                              f32x4 (&acc)[NT], float4 (&b)[3][NT]) {
+  float4 a[2];
+  if (!PRE) preload16<G, NT>(w, lane, b);
   a[0] = a4[lane];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -103,6 +110,13 @@ __device__ __forceinline__ void layer_tiles16(const float4* __restrict__ a4, con
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+template <int G, int NT>
+__device__ __forceinline__ void layer_tiles16(const float4* __restrict__ a4, const float4* const (&w)[NT], int lane,
+                                              f32x4 (&acc)[NT]) {
+  float4 b[3][NT];
+  layer_tiles16<G, NT, false>(a4, w, lane, acc, b);
 }
 
 // The same tiles for a wave that is alone on its SIMD (K13's forward waves): nothing else hides an L2 round trip
