@@ -353,14 +353,16 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
 
   float xn[2];
   if (n_items > 0) {
+    // two memory round trips in front of the first tile, not four: the index behind the loss lane goes out with the
+    // indices behind the input rows, the loss inputs with the rows themselves (at the reference's minibatch of 64 a
+    // launch is one tile per workgroup and these were 3 of its 26 us)
+    const int lr = wave == 0 ? loss_row(part_id) : -1;
     load_x(0, xn);
-    store_x(0, xn);
+    float lv[10];
+    if (wave == 0) loss_fetch(lr, lv);
     preload16b<KT1, 2>(rsP, voff, so1, wb, P);
-    if (wave == 0) {
-      float lv[10];
-      loss_fetch(loss_row(part_id), lv);
-      loss_park(lv);
-    }
+    store_x(0, xn);
+    if (wave == 0) loss_park(lv);
   }
   __syncthreads();
 
