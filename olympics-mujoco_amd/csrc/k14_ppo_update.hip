@@ -255,7 +255,6 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
 #pragma unroll
     for (int f = 0; f < 8; ++f) cstL[f * 16 + col] = v[f];
   }
-  const float lo = 1.0f - p.clip, hi = 1.0f + p.clip;
 
   // A tile is 16 rows of the network's forward / backward.  With the mirror loss an actor tile holds EIGHT rows of the
   // minibatch (tile rows 0-7) and their mirrored observations (tile rows 8-15: row m + 8 mirrors row m), so that one
@@ -372,8 +371,6 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
     const bool more = it + 1 < n_items;
     if (more) load_x(it + 1, xn);           // in flight behind this item's layers
     const int lrow_next = (wave == 0 && more) ? loss_row(tile + parts) : -1;
-    const int grow = tile * rpt + c;        // wave 0's loss lane: row c of the tile (c >= rpt: a mirrored row)
-    const bool valid = c < rpt && grow < B;
     const float4* xA4 = reinterpret_cast<const float4*>(xA + pb * XI);
     const float4* xC4 = reinterpret_cast<const float4*>(xC + pb * XI);
     float4* h1C4 = reinterpret_cast<float4*>(h1C);
@@ -433,7 +430,7 @@ __global__ __launch_bounds__(UT, 2) void ppo_update_kernel(UpdArgs p) {
       const int lane = lane_here, c = lane_here & 15, j = lane_here >> 4;
       const float lo = 1.0f - clip_here, hi = 1.0f + clip_here;
       const float zero_here = __int_as_float(opaque_v(0));
-      const bool valid = c < rpt && tile * rpt + c < B;
+      const bool valid = c < rpt && tile * rpt + c < B;      // the loss lane: row c of the tile (c >= rpt: a mirrored row)
 #pragma unroll
       for (int k = 0; k < 16; ++k) parkL[k * 64 + lane] = make_float4(dW2[0][k][0], dW2[0][k][1], dW2[0][k][2], dW2[0][k][3]);
       float o[4], g[4] = {0.f, 0.f, 0.f, 0.f};
