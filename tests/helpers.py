@@ -206,11 +206,17 @@ def torch_mlp(x, wb, mean=None, std=None, grad=False):
     return y if grad else y.numpy()
 
 
-def torch_ppo_update_grads(c, idx=None, clip=0.2, vf_coeff=0.5, mirror_coeff=0.4, old_mu=None):
+def torch_ppo_update_grads(c, idx=None, clip=0.2, vf_coeff=0.5, mirror_coeff=0.4, old_mu=None, float64=False):
     """What the reference's update_policy + the two backward() calls leave in .grad (rl/algos/ppo.py:232-282,
     396-410), evaluated with torch ops and autograd on the CPU in float32: flat gradients in parameter order and
-    the six scalars.  `old_mu` overrides the old policy's forward (the kernel takes it as an input)."""
+    the six scalars.  `old_mu` overrides the old policy's forward (the kernel takes it as an input).  float64: the same
+    graph in double precision on the same float32 inputs (the yardstick for large minibatches, where a float32
+    reference's own summation error is as large as the kernel's)."""
     import torch
+    if float64:
+        up = lambda v: v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v
+        c = {k: ([up(a) for a in v] if isinstance(v, (list, tuple)) else up(v)) for k, v in c.items()}
+        old_mu = None if old_mu is None else up(old_mu)
     sel = slice(None) if idx is None else np.asarray(idx, np.int64)
     obs, act = torch.as_tensor(c["obs"][sel]), torch.as_tensor(c["action"][sel])
     adv, ret = torch.as_tensor(c["adv"][sel]).reshape(-1, 1), torch.as_tensor(c["ret"][sel]).reshape(-1, 1)

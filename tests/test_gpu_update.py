@@ -90,6 +90,36 @@ def test_ppo_update_kernel_other_network_widths(eng, oracle, in_dim, act_dim, mi
     assert_grads_close(gc, tc, in_dim, 1, GRAD_RTOL)
 
 
+def test_ppo_update_kernel_at_the_full_minibatch(eng):
+    """BASELINE config 3's own minibatch: 65 536 gathered rows of a 70 000-row buffer, the mirror loss on, the plan's own
+    split over all 256 workgroups; the oracle twin would need minutes here (the 16 384-row case below is bit-exact against
+    it).  Against torch autograd in float32: the six scalars to 1e-5; the critic's gradients to 2e-5 of each tensor's
+    largest element.  The actor's only to 2e-3: with 65 536 rows x 512 hidden units a few dozen pre-activations lie within
+    rounding of zero, every evaluation order (the kernel's chains, torch's GEMMs, float64: 7e-4 from BOTH) puts some of
+    them on the other side of the ReLU, and each such flip moves a row / column of a weight gradient by a whole row's
+    contribution.  What this case guards is the bookkeeping at full size: no tile lost or counted twice (>= 4e-3)."""
+    c = ppo_update_case(11, n=70000, mirror=True)
+    idx = np.random.default_rng(1).permutation(70000)[:65536].astype(np.int32)
+    ga, gc, scal, used = run_kernel(eng, c, idx, True)
+    assert used[0] + used[1] >= 200                       # the whole chip takes part
+    ta, tc, ts = torch_ppo_update_grads(c, idx=idx, mirror_coeff=0.4)
+    np.testing.assert_allclose(scal, ts, rtol=1e-5, atol=1e-8)
+    assert_grads_close(ga, ta, 41, 12, 2e-3)
+    assert_grads_close(gc, tc, 41, 1, GRAD_RTOL)
+
+
+def test_ppo_update_kernel_sixteen_thousand_rows_equal_the_oracle(eng, oracle):
+    """16 384 gathered rows, mirror loss on, the plan's own split: every one of the 256 workgroups runs 6 - 13 tiles.
+    Bit-exact against the oracle twin (about 20 s of scalar fma chains on the host)."""
+    c = ppo_update_case(12, n=20000, mirror=True)
+    idx = np.random.default_rng(2).permutation(20000)[:16384].astype(np.int32)
+    ga, gc, scal, used = run_kernel(eng, c, idx, True)
+    assert used[0] + used[1] >= 200
+    oa, oc, os_ = oracle_update(oracle, c, idx, True, used)
+    assert np.array_equal(ga, oa) and np.array_equal(gc, oc)
+    np.testing.assert_allclose(scal, os_, rtol=1e-12, atol=1e-15)
+
+
 def test_ppo_update_kernel_larger_minibatch_equals_the_oracle(eng, oracle):
     """2085 gathered rows of a 6000-row buffer with the plan's own split (131 tiles over 128 + 128 workgroups)."""
     c = ppo_update_case(5, n=6000, mirror=True)
