@@ -828,7 +828,10 @@ def config4_block(rk, args):
             except Exception:
                 traffic = None
         out["shapes"][label] = {
-            "samples": B, "disc_forward_us": 1e3 * ms_k12, "col_stats_plus_disc_forward_us": 1e3 * ms_all,
+            "samples": B, "disc_forward_us": 1e3 * ms_k12,
+            # DiscriminatorReward.forward as a user calls it from Python: per-call argument checks included (host-bound at
+            # B = 4096; the same launches issued through the prepared call: pipeline.stages_us.reward_step below)
+            "python_forward_call_us": 1e3 * ms_all,
             "samples_per_s": B / (ms_all * 1e-3),
             "roofline": {"bound": "mfma", "achieved": fl / (ms_k12 * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": fl / (ms_k12 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -863,6 +866,9 @@ def config4_block(rk, args):
         parts3 = post._stats.reshape(1, 3)
         ms_norm = event_ms(stream, reps, lambda: eng.adv_normalize(buf.advantages, parts3, 0, 1e-8), wake_s=0.0)
         scan_bytes = (21 + 8) * B                          # GAE scan 21 B / element, normalise 8 B / element
+        # the config's own step (Standardizer update + reward) as one prepared C call: round 3's 31.8 us at B = 4096
+        out["shapes"][label]["reward_step_us"] = 1e3 * ms_rew
+        out["shapes"][label]["reward_step_frozen_weights_us"] = 1e3 * ms_rew_frozen
         out["shapes"][label]["pipeline"] = {
             "stages": "Standardizer update + K12 reward | K6 GAE(0.99, 0.97) + statistics | K7 normalise (ddof 0, 1e-8)",
             "us": 1e3 * ms_pipe, "samples_per_s": B / (ms_pipe * 1e-3),
