@@ -332,3 +332,42 @@ def test_ppo_adam_step_keeps_the_packed_streams_current_for_other_widths(eng, in
         fresh = eng.mlp_pack(parts[0].view(256, in_dim), parts[1], parts[2].view(256, 256), parts[3], parts[4].view(-1, 256),
                              parts[5], nt["in_mean"], nt["in_std"])
         assert torch.equal(fresh, nt["packed"]), (in_dim, od, int((fresh != nt["packed"]).sum()))
+
+
+def test_update_epoch_call_rejects_inconsistent_arguments(eng):
+    """oly_ppo_update_epoch refuses what would silently train on the wrong buffers: an optimiser block whose gradient /
+    packed-stream pointers are not the update's, a norm workspace that is not shared, a permutation shorter than the
+    minibatches asked for (host side), a negative count."""
+    import copy
+    import ctypes as C
+    from olympic_hip._ffi import OlyError, lib
+    from olympic_hip.ppo import KernelUpdate, MLPCritic, MLPGaussianActor
+    torch.manual_seed(9)
+    pi, vf = MLPGaussianActor(41, 12).cuda(), MLPCritic(41).cuda()
+    n, B = 300, 64
+    obs, act = torch.randn(n, 41, device="cuda"), torch.randn(n, 12, device="cuda") * 0.3
+    ret, adv = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    ku = KernelUpdate(eng, pi, vf, copy.deepcopy(pi), 0.2, 0.5, 0.0)
+    ku.begin(obs)
+    perm = torch.randperm(n, device="cuda").to(torch.int32)
+    scal = torch.zeros((4, 6), dtype=torch.float64, device="cuda")
+    ku.step(obs, act, ret, adv, perm[:B], scal[0])                     # prepares the two launches
+    g, a = ku._last_launch, ku._apply[1]
+    with pytest.raises(OlyError, match="perm"):
+        eng.ppo_update_epoch(g, a, ku.steps + 1, perm[:100], 3, scal[1:])     # 3 x 64 rows asked of 100 indices
+    keep = a.struct.ws
+    a.struct.ws = scal.data_ptr()                                              # not the update's gnorm_ws
+    with pytest.raises(OlyError, match="gnorm_ws"):
+        eng.ppo_update_epoch(g, a, ku.steps + 1, perm[B:], 3, scal[1:])
+    a.struct.ws = keep
+    keep = a.struct.net[1].grad
+    a.struct.net[1].grad = a.struct.net[0].grad                                # the critic's optimiser on the actor's gradient
+    with pytest.raises(OlyError, match="network 1"):
+        eng.ppo_update_epoch(g, a, ku.steps + 1, perm[B:], 3, scal[1:])
+    a.struct.net[1].grad = keep
+    rc = lib().oly_ppo_update_epoch(eng.ctx.handle, C.byref(g.struct), C.byref(a.struct), perm.data_ptr(), -1, scal.data_ptr(), None)
+    assert rc != 0
+    before = ku.nets[0]["param"].clone()
+    eng.ppo_update_epoch(g, a, ku.steps + 1, perm[B:], 3, scal[1:])            # and the well-formed call runs
+    torch.cuda.synchronize()
+    assert not torch.equal(before, ku.nets[0]["param"]) and bool(torch.isfinite(scal).all())
